@@ -1,0 +1,38 @@
+// gfx950 (CDNA4) intrinsics used by the FrameDiff kernels.  wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define FD_BACKEND_NAME "gfx950"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace fd {
+
+// v_mfma_f32_32x32x2_f32: exact f32 (k-ordered fmaf chain), 64 cycles / SIMD.
+//   A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D reg r -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31
+__device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D reg r -> row 4*(l>>4)+r, col l&15
+__device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { T u = __shfl_xor(v, o); v = v > u ? v : u; }
+  return v;
+}
+
+}  // namespace fd

@@ -1,0 +1,146 @@
+"""ctypes binding of the C ABI declared in include/fd_hip.h.
+
+The product path loads exactly one library: ``se3_diffusion_amd/lib/libfd_hip.so``
+(hipcc, gfx950).  There is no CPU fallback: if the library is missing, or a
+kernel is asked to run on a tensor that is not on an AMD GPU, we raise.
+
+(The test suite can hand a *different* FdLib to individual calls -- the host
+SIMT interpreter build under tests/emu -- to check kernel logic without a GPU.
+That hook lives in tests/, is never selected here, and the product singleton
+refuses any backend other than "gfx950".)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfd_hip.so")
+
+c_float_p = c_void_p  # raw device pointers travel as integers
+
+
+class FdError(RuntimeError):
+    pass
+
+
+class FdGemmDesc(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("a_rs", c_long), ("a_cs", c_long),
+        ("b_rs", c_long), ("b_cs", c_long),
+        ("ldc", c_long),
+        ("batch", c_int), ("bdiv", c_int),
+        ("a_so", c_long), ("a_si", c_long), ("b_so", c_long), ("b_si", c_long),
+        ("c_so", c_long), ("c_si", c_long),
+        ("alpha", c_float), ("beta", c_int),
+        ("bias", c_void_p),
+        ("pair_p", c_void_p), ("pair_q", c_void_p), ("ld_pair", c_long), ("nres", c_int),
+        ("resid", c_void_p), ("ld_resid", c_long),
+        ("gate", c_void_p), ("ld_gate", c_long),
+        ("rowscale", c_void_p),
+        ("relu", c_int), ("tile", c_int), ("ksplit", c_int),
+    ]
+
+
+def _ptr(t, off=0):
+    if t is None:
+        return None
+    return t.data_ptr() + 4 * int(off) if t.dtype == torch.float32 else t.data_ptr() + t.element_size() * int(off)
+
+
+# name -> (restype, argtypes); every symbol include/fd_hip.h declares.
+_SIGNATURES = {
+    "fd_last_error": (c_char_p, []),
+    "fd_abi_version": (c_int, []),
+    "fd_backend": (c_char_p, []),
+    "fd_gemm": (c_int, [POINTER(FdGemmDesc), c_void_p]),
+}
+
+
+class FdLib:
+    """One loaded build of the C ABI (product: gfx950)."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise FdError(
+                f"HIP extension not found at {path}. Build it with "
+                f"`python -m se3_diffusion_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        self.backend = self.cdll.fd_backend().decode()
+        self.is_device = self.backend == "gfx950"
+
+    # -- helpers ---------------------------------------------------------
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise FdError(f"{what} failed ({rc}): {self.cdll.fd_last_error().decode()}")
+
+    def _stream(self, *tensors):
+        if not self.is_device:
+            for t in tensors:
+                if t is not None and t.is_cuda:
+                    raise FdError("emulator build called with a GPU tensor")
+            return None
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise FdError("HIP kernel called with a CPU tensor; the hot path has no CPU fallback")
+        return torch.cuda.current_stream().cuda_stream
+
+    # -- dense -----------------------------------------------------------
+    def gemm(self, A, B, C, M, N, K, a_str, b_str, ldc, *, a_off=0, b_off=0, c_off=0,
+             batch=1, bdiv=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), alpha=1.0, beta=False,
+             bias=None, pair=None, resid=None, ld_resid=0, gate=None, ld_gate=0,
+             rowscale=None, relu=False, tile=0, ksplit=1):
+        d = FdGemmDesc()
+        d.A, d.B, d.C = _ptr(A, a_off), _ptr(B, b_off), _ptr(C, c_off)
+        d.M, d.N, d.K = int(M), int(N), int(K)
+        d.a_rs, d.a_cs = a_str
+        d.b_rs, d.b_cs = b_str
+        d.ldc = ldc
+        d.batch, d.bdiv = batch, bdiv
+        d.a_so, d.a_si = a_bs
+        d.b_so, d.b_si = b_bs
+        d.c_so, d.c_si = c_bs
+        d.alpha, d.beta = float(alpha), int(bool(beta))
+        d.bias = _ptr(bias)
+        if pair is not None:
+            P, Q, ld, nres = pair
+            d.pair_p, d.pair_q, d.ld_pair, d.nres = _ptr(P), _ptr(Q), ld, nres
+        d.resid, d.ld_resid = _ptr(resid), ld_resid
+        d.gate, d.ld_gate = _ptr(gate), ld_gate
+        d.rowscale = _ptr(rowscale)
+        d.relu, d.tile, d.ksplit = int(bool(relu)), int(tile), int(ksplit)
+        keep = (A, B, C, bias, resid, gate, rowscale, pair)
+        s = self._stream(A, B, C, bias, resid, gate, rowscale)
+        self._check(self.cdll.fd_gemm(ctypes.byref(d), s), "fd_gemm")
+        return keep
+
+
+_PRODUCT: FdLib | None = None
+_TEST_OVERRIDE: FdLib | None = None  # set only by tests/emu (never by product code)
+
+
+def get_lib() -> FdLib:
+    """The library every op dispatches to."""
+    global _PRODUCT
+    if _TEST_OVERRIDE is not None:
+        return _TEST_OVERRIDE
+    if _PRODUCT is None:
+        lib = FdLib(LIB_PATH)
+        if lib.backend != "gfx950":
+            raise FdError(f"{LIB_PATH} reports backend {lib.backend!r}; the product path only runs gfx950 code")
+        _PRODUCT = lib
+    return _PRODUCT
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)

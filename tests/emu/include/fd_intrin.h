@@ -1,0 +1,81 @@
+// TEST INFRASTRUCTURE ONLY -- host emulation of the gfx950 intrinsics wrapped by
+// se3_diffusion_amd/csrc/gfx950/fd_intrin.h (same names, same semantics).
+// Fragment maps follow /opt/skills/guides/cdna_hip_programming.md section 3:
+//   32x32x2 f32 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
+//                 D reg r -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31
+//   16x16x4 f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
+//                 D reg r -> row 4*(l>>4)+r, col l&15
+// Result is a k-ordered fmaf chain (bitwise the hardware behaviour).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define FD_BACKEND_NAME "emu"
+
+struct f32x16 {
+  float v[16];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
+struct f32x4 {
+  float v[4];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
+
+namespace fd {
+
+static inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+  struct AB { float a, b; } ab{a, b};
+  auto tab = hipemu::wave_exchange(&ab, sizeof(ab));
+  int l = hipemu::g_cur->lane;
+  int col = l & 31, hi = l >> 5;
+  f32x16 d;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) {
+      AB x, y;
+      memcpy(&x, tab[row + 32 * k], sizeof(AB));   // A[row][k]
+      memcpy(&y, tab[col + 32 * k], sizeof(AB));   // B[k][col]
+      acc = fmaf(x.a, y.b, acc);
+    }
+    d[r] = acc;
+  }
+  return d;
+}
+
+static inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
+  struct AB { float a, b; } ab{a, b};
+  auto tab = hipemu::wave_exchange(&ab, sizeof(ab));
+  int l = hipemu::g_cur->lane;
+  int col = l & 15, g = l >> 4;
+  f32x4 d;
+  for (int r = 0; r < 4; ++r) {
+    int row = 4 * g + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) {
+      AB x, y;
+      memcpy(&x, tab[row + 16 * k], sizeof(AB));
+      memcpy(&y, tab[col + 16 * k], sizeof(AB));
+      acc = fmaf(x.a, y.b, acc);
+    }
+    d[r] = acc;
+  }
+  return d;
+}
+
+static inline int lane_id() { return hipemu::g_cur->lane; }
+static inline int wave_id() { return hipemu::g_cur->wave; }
+
+template <typename T>
+static inline T wave_sum(T v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+template <typename T>
+static inline T wave_max(T v) {
+  for (int o = 32; o > 0; o >>= 1) { T u = __shfl_xor(v, o); v = v > u ? v : u; }
+  return v;
+}
+
+}  // namespace fd
