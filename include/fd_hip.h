@@ -32,8 +32,8 @@ const char* fd_backend(void);
  * :424-426 (qk^T, a*v); model/score_network.py:67-86 (embedder MLPs); and
  * their autograd.  A(m,k)=A[m*a_rs+k*a_cs], B(k,n)=B[k*b_rs+n*b_cs].
  * Batch index z in [0,batch): zo=z/bdiv, zi=z%bdiv; operand X is offset by
- * zo*x_so + zi*x_si.  Epilogue order: alpha, +bias[n], +pair_p/q, +resid,
- * relu, gate (zero where gate<=0), *rowscale[m], then C = v (+ C if beta). */
+ * zo*x_so + zi*x_si.  Epilogue order: alpha, +bias[n], +pair_p/q, relu,
+ * gate (zero where gate<=0), *rowscale[m], +resid, then C = v (+ C if beta). */
 typedef struct FdGemmDesc {
   const float* A;
   const float* B;
@@ -63,6 +63,86 @@ typedef struct FdGemmDesc {
 } FdGemmDesc;
 
 int fd_gemm(const FdGemmDesc* desc, void* stream);
+
+/* ---- LayerNorm / reductions (HBM-bound) -------------------------------
+ * torch.nn.LayerNorm (eps 1e-5, biased variance) at score_network.py:73,85,
+ * ipa_pytorch.py:189,231,577,632 and TransformerEncoderLayer.norm1/2; the
+ * optional rowscale fuses the `* mask` that follows (ipa_pytorch.py:641,649). */
+int fd_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, const float* rowscale,
+                     float* y, long ldy, float* mean, float* rstd, long rows, int C, float eps, void* stream);
+int fd_layernorm_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma,
+                     const float* rowscale, const float* mean, const float* rstd, float* dx, long lddx,
+                     int dx_accum, float* dgamma, float* dbeta, long rows, int C, void* stream);
+/* out[n] += sum_m X[m*ld+n] (bias gradients) */
+int fd_colsum_acc(const float* X, long ld, long rows, int ncols, float* out, void* stream);
+/* X [nbatch,n,n,C]: rowsum[b,i,:] += sum_j X[b,i,j,:], colsum[b,j,:] += sum_i X[b,i,j,:] (either may be null) */
+int fd_pair_reduce_acc(const float* X, int nbatch, int n, int C, float* rowsum, float* colsum, long ld_out,
+                       void* stream);
+int fd_axpby(float* y, const float* x, float a, float b, long n, void* stream);
+/* dst[r*ldd+c] += a*src[r*lds+c] */
+int fd_add2d(float* dst, long ldd, const float* src, long lds, long rows, int cols, float a, void* stream);
+int fd_rowscale(const float* x, long ldx, const float* rs, float* y, long ldy, long rows, int C, void* stream);
+
+/* ---- embedder features: score_network.py:14-47,97-148; data/utils.py:570-580 ----
+ * tscaled = (t*1e4) as fp32 [B]; tfreq[16], idenom[16], dg_lower[22], dg_upper[22] are the
+ * host-computed tables of the reference's own op sequence. */
+int fd_node_feats(const long* seq_idx, const float* tscaled, const float* fixed, const float* tfreq,
+                  const float* idenom, float* out /*[B*N,65]*/, int B, int N, void* stream);
+int fd_edge_feats(const long* seq_idx, const float* tscaled, const float* fixed, const float* sc_ca,
+                  const float* tfreq, const float* idenom, const float* dg_lower, const float* dg_upper,
+                  float* out /*[B*N*N,120]*/, int B, int N, void* stream);
+
+/* ---- Invariant Point Attention, non-GEMM parts: ipa_pytorch.py:303-471 ----
+ * layouts in se3_diffusion_amd/csrc/fd_ipa.hip.  Built for base.yaml dims
+ * (no_heads 8, c_hidden 256, no_qk_points 8, no_v_points 12). */
+int fd_ipa_points_fwd(const float* proj, const float* quat, const float* trans, float* qp, float* kp, float* vp,
+                      long R, int nheads, int c_hidden, int n_qk, int n_v, void* stream);
+int fd_ipa_points_bwd(const float* proj, const float* quat, const float* dqp, const float* dkp, const float* dvp,
+                      float* dproj, float* dframe, long R, int nheads, int c_hidden, int n_qk, int n_v,
+                      void* stream);
+int fd_ipa_softmax_fwd(float* S, const float* zb, const float* qp, const float* kp, const float* head_w,
+                       const float* mask, int B, int N, void* stream);
+int fd_ipa_softmax_bwd(const float* A, float* dA, const float* qp, const float* kp, const float* head_w,
+                       float* dzb, float* dqp, float* dkp, float* dhead_w, int B, int N, void* stream);
+int fd_ipa_opt_fwd(const float* optg, const float* quat, const float* trans, float* feats, long R, void* stream);
+int fd_ipa_opt_bwd(const float* dfeats, const float* feats, const float* quat, float* doptg, float* dframe,
+                   long R, void* stream);
+int fd_ipa_opair_fwd(const float* A, const float* zb, float* feats, int B, int N, void* stream);
+int fd_ipa_opair_bwd(const float* A, const float* zb, const float* dfeats, float* dA, float* dzb, int B, int N,
+                     void* stream);
+
+/* ---- sequence-transformer softmax (nn.MultiheadAttention, ipa_pytorch.py:584-593) ---- */
+int fd_row_softmax_fwd(float* S, const float* key_add, long rows, int N, int rows_per_batch, void* stream);
+int fd_row_softmax_bwd(const float* A, float* dA, long rows, int N, void* stream);
+
+/* ---- backbone update: ipa_pytorch.py:530-557,641-644; rigid_utils.py:266-275,587-616,1039-1063 ---- */
+int fd_bb_update_fwd(const float* node, long ldn, int cs, const float* dmask, const float* W6, const float* b6,
+                     const float* quat, const float* trans, float* upd, float* quat_out, float* trans_out,
+                     long R, void* stream);
+int fd_bb_update_bwd(const float* dquat_out, const float* dtrans_out, const float* dframe, const float* dmask,
+                     const float* upd, const float* quat, float* dquat, float* dtrans, float* dupd, float* dupd_s,
+                     long R, void* stream);
+
+/* ---- score heads + psi + backbone atoms: ipa_pytorch.py:650-672, se3_diffuser.py:115-125,
+ * so3_diffuser.py:9-117,182-213,274-305, r3_diffuser.py:42-43,148-166, all_atom.py:152-174 ---- */
+typedef struct FdHeadConst {
+  float atoms[15];       /* N, CA, C, CB, O idealised local coordinates (ALA) */
+  float Rd[9];           /* psi rigid-group default frame rotation */
+  float td[3];           /* ... translation */
+  float coord_scale;     /* 0.1 */
+  double exp_max_sigma, exp_min_sigma;
+  float min_b, max_b;
+  int L;                 /* IGSO(3) truncation (1000) */
+} FdHeadConst;
+int fd_heads_fwd(const float* rig0, const float* quatF, const float* transF, const float* upsi,
+                 const float* gt_psi, long gt_stride, const float* fixed, const float* mask, const float* t,
+                 const double* sigma_grid, int ng, const FdHeadConst* c, double* rot_score, float* trans_score,
+                 float* rigids, float* psi_out, float* atom37, float* atom14, int B, int N, void* stream);
+int fd_heads_bwd(const float* rig0, const float* quatF, const float* transF, const float* upsi,
+                 const float* psi_out, const float* fixed, const float* mask, const float* t,
+                 const double* sigma_grid, int ng, const FdHeadConst* c, const double* d_rot,
+                 const float* d_trans_score, const float* d_rigids, const float* d_psi, const float* d_atom37,
+                 float* dquatF, float* dtransF, float* dupsi, int B, int N, void* stream);
 
 #ifdef __cplusplus
 }

@@ -226,10 +226,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         float v = d.alpha * acc[i][j][r];
         if (d.bias) v += d.bias[n];
         if (d.pair_p) v += d.pair_p[prow * d.ld_pair + n] + d.pair_q[qrow * d.ld_pair + n];
-        if (d.resid) v += d.resid[(long)m * d.ld_resid + n];
         if (d.relu) v = v > 0.f ? v : 0.f;
         if (d.gate) v = d.gate[(long)m * d.ld_gate + n] > 0.f ? v : 0.f;
         v *= rs;
+        if (d.resid) v += d.resid[(long)m * d.ld_resid + n];
         float* cp = C + (long)m * d.ldc + n;
         if (d.beta) v += *cp;
         *cp = v;

@@ -1,0 +1,487 @@
+// Invariant Point Attention: the non-GEMM pieces (HBM / VALU bound), forward and backward.
+//
+// Reference: model/ipa_pytorch.py:303-471 (InvariantPointAttention.forward) with the frame
+// algebra of openfold/utils/rigid_utils.py (:82-106 rot_vec_mul, :173-205 quat_to_rot,
+// :1104-1130 Rigid.apply / invert_apply).  Dense contractions (q k^T, a v, a v_pts,
+// linear_b/down_z, linear_out) run on fd_gemm; this file holds
+//   points   : raw Linear outputs ([x|y|z] blocks, :351-352,:364-374) -> global-frame q/k/v points
+//   softmax  : logits = qk*sqrt(1/3C) + sqrt(1/3) b - 0.5 gamma_h sum_p |q_p - k_p|^2 + 1e5 (m_i m_j - 1)
+//              (:380-422), softmax over j
+//   opt      : o_pt = R^T (sum_j a v_pts - t), |o_pt| (:432-449)
+//   opair    : o_pair = sum_j a_ij (down_z z)_ij (:455-457)
+// Layouts (fp32): proj [R,6816] = [q 2048 | kv 8x(256 k,256 v) | qp raw 3x64 | kvp raw 3x160];
+// qp,kp [R,8,8,3]; vp [R,8,12,3]; S/A [B,8,N,N]; zb [P,40] = [linear_b 8 | down_z 32];
+// feats [R,2688] = [o 2048 | o_pt.x 96 | .y 96 | .z 96 | |o_pt| 96 | o_pair 256];
+// dframe [R,12] = dL/dR (row-major 3x3) followed by dL/dt, accumulated (+=).
+#include "fd_common.h"
+#include "../../include/fd_hip.h"
+
+namespace {
+
+constexpr int H = 8, C = 256, PQ = 8, PV = 12, CZ4 = 32, ZB = 40;
+constexpr int LDP = H * C * 3 + H * PQ * 3 + H * (PQ + PV) * 3;  // 6816
+constexpr int QP_OFF = H * C * 3;                                 // 6144
+constexpr int KVP_OFF = QP_OFF + H * PQ * 3;                      // 6336
+constexpr int NQP = H * PQ;                                       // 64
+constexpr int NKVP = H * (PQ + PV);                               // 160
+constexpr int LDF = H * (C + 4 * PV + CZ4);                       // 2688
+constexpr int F_PT = H * C;                                       // 2048
+constexpr int F_NORM = F_PT + 3 * H * PV;                         // 2336
+constexpr int F_PAIR = F_NORM + H * PV;                           // 2432
+constexpr int MAXN = 1024;
+
+struct Rot { float r[9]; };
+
+__device__ __forceinline__ Rot quat_to_rot(const float* __restrict__ q) {
+  const float a = q[0], b = q[1], c = q[2], d = q[3];
+  Rot R;
+  R.r[0] = a * a + b * b - c * c - d * d;
+  R.r[1] = 2.f * (b * c - a * d);
+  R.r[2] = 2.f * (b * d + a * c);
+  R.r[3] = 2.f * (b * c + a * d);
+  R.r[4] = a * a - b * b + c * c - d * d;
+  R.r[5] = 2.f * (c * d - a * b);
+  R.r[6] = 2.f * (b * d - a * c);
+  R.r[7] = 2.f * (c * d + a * b);
+  R.r[8] = a * a - b * b - c * c + d * d;
+  return R;
+}
+
+// ---------------------------------------------------------------- points
+__global__ __launch_bounds__(256) void ipa_points_fwd_kernel(const float* __restrict__ proj,
+                                                             const float* __restrict__ quat,
+                                                             const float* __restrict__ trans,
+                                                             float* __restrict__ qp, float* __restrict__ kp,
+                                                             float* __restrict__ vp, long R_) {
+  const long total = R_ * (NQP + NKVP);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / (NQP + NKVP);
+    const int pi = (int)(e % (NQP + NKVP));
+    const Rot R = quat_to_rot(quat + r * 4);
+    const float* pr = proj + r * LDP;
+    float x, y, z;
+    float* dst;
+    if (pi < NQP) {
+      x = pr[QP_OFF + pi]; y = pr[QP_OFF + NQP + pi]; z = pr[QP_OFF + 2 * NQP + pi];
+      dst = qp + (r * NQP + pi) * 3;
+    } else {
+      const int pk = pi - NQP;
+      x = pr[KVP_OFF + pk]; y = pr[KVP_OFF + NKVP + pk]; z = pr[KVP_OFF + 2 * NKVP + pk];
+      const int h = pk / (PQ + PV), p = pk % (PQ + PV);
+      dst = p < PQ ? kp + ((r * H + h) * PQ + p) * 3 : vp + ((r * H + h) * PV + (p - PQ)) * 3;
+    }
+    const float* t = trans + r * 3;
+    dst[0] = R.r[0] * x + R.r[1] * y + R.r[2] * z + t[0];
+    dst[1] = R.r[3] * x + R.r[4] * y + R.r[5] * z + t[1];
+    dst[2] = R.r[6] * x + R.r[7] * y + R.r[8] * z + t[2];
+  }
+}
+
+// block per residue: d raw = R^T d glob ; dR[a][c] += dg[a]*raw[c] ; dt += dg
+__global__ __launch_bounds__(256) void ipa_points_bwd_kernel(const float* __restrict__ proj,
+                                                             const float* __restrict__ quat,
+                                                             const float* __restrict__ dqp,
+                                                             const float* __restrict__ dkp,
+                                                             const float* __restrict__ dvp,
+                                                             float* __restrict__ dproj, float* __restrict__ dframe) {
+  __shared__ float red[4][12];
+  const long r = blockIdx.x;
+  const int pi = (int)threadIdx.x;
+  const Rot R = quat_to_rot(quat + r * 4);
+  float acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+  if (pi < NQP + NKVP) {
+    const float* pr = proj + r * LDP;
+    float* dpr = dproj + r * LDP;
+    float x, y, z;
+    const float* dg;
+    int cx, cy, cz;
+    if (pi < NQP) {
+      cx = QP_OFF + pi; cy = cx + NQP; cz = cy + NQP;
+      dg = dqp + (r * NQP + pi) * 3;
+    } else {
+      const int pk = pi - NQP;
+      cx = KVP_OFF + pk; cy = cx + NKVP; cz = cy + NKVP;
+      const int h = pk / (PQ + PV), p = pk % (PQ + PV);
+      dg = p < PQ ? dkp + ((r * H + h) * PQ + p) * 3 : dvp + ((r * H + h) * PV + (p - PQ)) * 3;
+    }
+    x = pr[cx]; y = pr[cy]; z = pr[cz];
+    const float g0 = dg[0], g1 = dg[1], g2 = dg[2];
+    dpr[cx] = R.r[0] * g0 + R.r[3] * g1 + R.r[6] * g2;
+    dpr[cy] = R.r[1] * g0 + R.r[4] * g1 + R.r[7] * g2;
+    dpr[cz] = R.r[2] * g0 + R.r[5] * g1 + R.r[8] * g2;
+    acc[0] = g0 * x; acc[1] = g0 * y; acc[2] = g0 * z;
+    acc[3] = g1 * x; acc[4] = g1 * y; acc[5] = g1 * z;
+    acc[6] = g2 * x; acc[7] = g2 * y; acc[8] = g2 * z;
+    acc[9] = g0; acc[10] = g1; acc[11] = g2;
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = fd::wave_sum(acc[k]);
+  const int lane = fd::lane_id(), wave = fd::wave_id();
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) red[wave][k] = acc[k];
+  __syncthreads();
+  if (pi < 12) dframe[r * 12 + pi] += red[0][pi] + red[1][pi] + red[2][pi] + red[3][pi];
+}
+
+// ---------------------------------------------------------------- softmax
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+__global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict__ S, const float* __restrict__ zb,
+                                                              const float* __restrict__ qp,
+                                                              const float* __restrict__ kp,
+                                                              const float* __restrict__ head_w,
+                                                              const float* __restrict__ mask, int N) {
+  __shared__ float lg[H][MAXN];
+  const long bi = blockIdx.x;
+  const int b = (int)(bi / N), i = (int)(bi % N);
+  const int lane = fd::lane_id(), wave = fd::wave_id();
+  const float mi = mask[bi];
+  const float sq13 = sqrtf(1.0f / 3.0f);
+  const float gscale = sqrtf(1.0f / (3.0f * ((float)PQ * 9.0f / 2.0f)));
+  for (int hh = 0; hh < 2; ++hh) {
+    const int h = wave * 2 + hh;
+    const float gamma = softplus_f(head_w[h]) * gscale;
+    float q[PQ * 3];
+    const float* qsrc = qp + (bi * H + h) * (PQ * 3);
+#pragma unroll
+    for (int k = 0; k < PQ * 3; ++k) q[k] = qsrc[k];
+    float* Srow = S + (((long)b * H + h) * N + i) * N;
+    float mx = -INFINITY;
+    for (int j = lane; j < N; j += 64) {
+      const long bj = (long)b * N + j;
+      const float* ksrc = kp + (bj * H + h) * (PQ * 3);
+      float pt = 0.f;
+#pragma unroll
+      for (int p = 0; p < PQ; ++p) {
+        const float dx = q[3 * p] - ksrc[3 * p], dy = q[3 * p + 1] - ksrc[3 * p + 1], dz = q[3 * p + 2] - ksrc[3 * p + 2];
+        pt += (dx * dx + dy * dy + dz * dz) * gamma;
+      }
+      float a = Srow[j] + sq13 * zb[(bi * N + j) * ZB + h];
+      a = a + pt * (-0.5f);
+      a = a + 1e5f * (mi * mask[bj] - 1.f);
+      lg[h][j] = a;
+      mx = fmaxf(mx, a);
+    }
+    mx = fd::wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < N; j += 64) {
+      const float e = expf(lg[h][j] - mx);
+      lg[h][j] = e;
+      sum += e;
+    }
+    sum = fd::wave_sum(sum);
+    for (int j = lane; j < N; j += 64) Srow[j] = lg[h][j] / sum;
+  }
+}
+
+// dL = A * (dA - sum_j A dA) written over dA; d(zb bias) = sqrt(1/3) dL; dqp_i; d head_w
+__global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __restrict__ A, float* __restrict__ dA,
+                                                              const float* __restrict__ qp,
+                                                              const float* __restrict__ kp,
+                                                              const float* __restrict__ head_w,
+                                                              float* __restrict__ dzb, float* __restrict__ dqp,
+                                                              float* __restrict__ dhead_w, int N) {
+  __shared__ float dl_s[H][MAXN];
+  const long bi = blockIdx.x;
+  const int b = (int)(bi / N), i = (int)(bi % N);
+  const int lane = fd::lane_id(), wave = fd::wave_id();
+  const float sq13 = sqrtf(1.0f / 3.0f);
+  const float gscale = sqrtf(1.0f / (3.0f * ((float)PQ * 9.0f / 2.0f)));
+  for (int hh = 0; hh < 2; ++hh) {
+    const int h = wave * 2 + hh;
+    const float w = head_w[h];
+    const float gamma = softplus_f(w) * gscale;
+    const long rowoff = (((long)b * H + h) * N + i) * N;
+    const float* Arow = A + rowoff;
+    float* dArow = dA + rowoff;
+    float dot = 0.f;
+    for (int j = lane; j < N; j += 64) dot += Arow[j] * dArow[j];
+    dot = fd::wave_sum(dot);
+    float q[PQ * 3], dq[PQ * 3];
+    const float* qsrc = qp + (bi * H + h) * (PQ * 3);
+#pragma unroll
+    for (int k = 0; k < PQ * 3; ++k) { q[k] = qsrc[k]; dq[k] = 0.f; }
+    float dgam = 0.f;
+    for (int j = lane; j < N; j += 64) {
+      const float dl = Arow[j] * (dArow[j] - dot);
+      dArow[j] = dl;
+      dl_s[h][j] = dl;
+      const float* ksrc = kp + (((long)b * N + j) * H + h) * (PQ * 3);
+      float d2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < PQ * 3; ++k) {
+        const float df = q[k] - ksrc[k];
+        d2 += df * df;
+        dq[k] -= gamma * dl * df;
+      }
+      dgam -= 0.5f * dl * d2;
+    }
+#pragma unroll
+    for (int k = 0; k < PQ * 3; ++k) dq[k] = fd::wave_sum(dq[k]);
+    dgam = fd::wave_sum(dgam);
+    if (lane == 0) {
+      float* dst = dqp + (bi * H + h) * (PQ * 3);
+#pragma unroll
+      for (int k = 0; k < PQ * 3; ++k) dst[k] = dq[k];
+      // gamma = softplus(w) * gscale ; d softplus = sigmoid
+      const float sig = w > 20.f ? 1.f : 1.f / (1.f + expf(-w));
+      atomicAdd(&dhead_w[h], dgam * gscale * sig);
+    }
+  }
+  __syncthreads();
+  for (int e = (int)threadIdx.x; e < N * H; e += 256) {
+    const int j = e / H, h = e % H;
+    dzb[(bi * N + j) * ZB + h] = sq13 * dl_s[h][j];
+  }
+}
+
+// dkp[b,j,h,:] = gamma_h * sum_i dL[b,h,i,j] * (qp[b,i,h,:] - kp[b,j,h,:]); block = (j-tile of 64, h, b)
+__global__ __launch_bounds__(256) void ipa_kpts_bwd_kernel(const float* __restrict__ dL, const float* __restrict__ qp,
+                                                           const float* __restrict__ kp,
+                                                           const float* __restrict__ head_w, float* __restrict__ dkp,
+                                                           int N) {
+  __shared__ float red[4][64][PQ * 3 + 1];
+  const int jt = (int)blockIdx.x, h = (int)blockIdx.y, b = (int)blockIdx.z;
+  const int lane = fd::lane_id(), wave = fd::wave_id();
+  const int j = jt * 64 + lane;
+  const float gscale = sqrtf(1.0f / (3.0f * ((float)PQ * 9.0f / 2.0f)));
+  const float gamma = softplus_f(head_w[h]) * gscale;
+  float k[PQ * 3], acc[PQ * 3];
+#pragma unroll
+  for (int c = 0; c < PQ * 3; ++c) { k[c] = 0.f; acc[c] = 0.f; }
+  if (j < N) {
+    const float* ksrc = kp + (((long)b * N + j) * H + h) * (PQ * 3);
+#pragma unroll
+    for (int c = 0; c < PQ * 3; ++c) k[c] = ksrc[c];
+  }
+  for (int i = wave; i < N; i += 4) {
+    const float dl = j < N ? dL[(((long)b * H + h) * N + i) * N + j] : 0.f;
+    const float* qsrc = qp + (((long)b * N + i) * H + h) * (PQ * 3);
+#pragma unroll
+    for (int c = 0; c < PQ * 3; ++c) acc[c] += dl * (qsrc[c] - k[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < PQ * 3; ++c) red[wave][lane][c] = acc[c];
+  __syncthreads();
+  if (wave == 0 && j < N) {
+    float* dst = dkp + (((long)b * N + j) * H + h) * (PQ * 3);
+#pragma unroll
+    for (int c = 0; c < PQ * 3; ++c)
+      dst[c] = gamma * (red[0][lane][c] + red[1][lane][c] + red[2][lane][c] + red[3][lane][c]);
+  }
+}
+
+// ---------------------------------------------------------------- o_pt
+__global__ __launch_bounds__(256) void ipa_opt_fwd_kernel(const float* __restrict__ optg,
+                                                          const float* __restrict__ quat,
+                                                          const float* __restrict__ trans, float* __restrict__ feats,
+                                                          long R_) {
+  const long total = R_ * H * PV;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / (H * PV);
+    const int hp = (int)(e % (H * PV));
+    const Rot R = quat_to_rot(quat + r * 4);
+    const float* t = trans + r * 3;
+    const float* g = optg + e * 3;
+    const float ux = g[0] - t[0], uy = g[1] - t[1], uz = g[2] - t[2];
+    const float lx = R.r[0] * ux + R.r[3] * uy + R.r[6] * uz;
+    const float ly = R.r[1] * ux + R.r[4] * uy + R.r[7] * uz;
+    const float lz = R.r[2] * ux + R.r[5] * uy + R.r[8] * uz;
+    float* f = feats + r * LDF;
+    f[F_PT + hp] = lx;
+    f[F_PT + H * PV + hp] = ly;
+    f[F_PT + 2 * H * PV + hp] = lz;
+    f[F_NORM + hp] = sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
+  }
+}
+
+// block per residue (128 threads, 96 active)
+__global__ __launch_bounds__(128) void ipa_opt_bwd_kernel(const float* __restrict__ dfeats,
+                                                          const float* __restrict__ feats,
+                                                          const float* __restrict__ quat,
+                                                          float* __restrict__ doptg, float* __restrict__ dframe) {
+  __shared__ float red[2][12];
+  const long r = blockIdx.x;
+  const int hp = (int)threadIdx.x;
+  const Rot R = quat_to_rot(quat + r * 4);
+  float acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+  if (hp < H * PV) {
+    const float* f = feats + r * LDF;
+    const float* df = dfeats + r * LDF;
+    const float lx = f[F_PT + hp], ly = f[F_PT + H * PV + hp], lz = f[F_PT + 2 * H * PV + hp];
+    const float nrm = f[F_NORM + hp];
+    const float dn = df[F_NORM + hp] / nrm;
+    const float dlx = df[F_PT + hp] + dn * lx;
+    const float dly = df[F_PT + H * PV + hp] + dn * ly;
+    const float dlz = df[F_PT + 2 * H * PV + hp] + dn * lz;
+    // o_local = R^T u  =>  du = R dl ; dR[a][c] += u[a] dl[c] ; dt = -du
+    const float dux = R.r[0] * dlx + R.r[1] * dly + R.r[2] * dlz;
+    const float duy = R.r[3] * dlx + R.r[4] * dly + R.r[5] * dlz;
+    const float duz = R.r[6] * dlx + R.r[7] * dly + R.r[8] * dlz;
+    const float ux = R.r[0] * lx + R.r[1] * ly + R.r[2] * lz;
+    const float uy = R.r[3] * lx + R.r[4] * ly + R.r[5] * lz;
+    const float uz = R.r[6] * lx + R.r[7] * ly + R.r[8] * lz;
+    float* dg = doptg + (r * H * PV + hp) * 3;
+    dg[0] = dux; dg[1] = duy; dg[2] = duz;
+    acc[0] = ux * dlx; acc[1] = ux * dly; acc[2] = ux * dlz;
+    acc[3] = uy * dlx; acc[4] = uy * dly; acc[5] = uy * dlz;
+    acc[6] = uz * dlx; acc[7] = uz * dly; acc[8] = uz * dlz;
+    acc[9] = -dux; acc[10] = -duy; acc[11] = -duz;
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = fd::wave_sum(acc[k]);
+  const int lane = fd::lane_id(), wave = fd::wave_id();
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) red[wave][k] = acc[k];
+  __syncthreads();
+  if (hp < 12) dframe[r * 12 + hp] += red[0][hp] + red[1][hp];
+}
+
+// ---------------------------------------------------------------- o_pair
+__global__ __launch_bounds__(256) void ipa_opair_fwd_kernel(const float* __restrict__ A, const float* __restrict__ zb,
+                                                            float* __restrict__ feats, int N) {
+  __shared__ float Ai[H][MAXN];
+  const long bi = blockIdx.x;
+  const int b = (int)(bi / N), i = (int)(bi % N);
+  for (int e = (int)threadIdx.x; e < H * N; e += 256) {
+    const int h = e / N, j = e % N;
+    Ai[h][j] = A[(((long)b * H + h) * N + i) * N + j];
+  }
+  __syncthreads();
+  const int h = (int)threadIdx.x / CZ4, c = (int)threadIdx.x % CZ4;
+  const float* z = zb + bi * N * ZB + H + c;
+  float acc = 0.f;
+  for (int j = 0; j < N; ++j) acc += Ai[h][j] * z[(long)j * ZB];
+  feats[bi * LDF + F_PAIR + h * CZ4 + c] = acc;
+}
+
+__global__ __launch_bounds__(256) void ipa_opair_bwd_kernel(const float* __restrict__ A, const float* __restrict__ zb,
+                                                            const float* __restrict__ dfeats,
+                                                            float* __restrict__ dA, float* __restrict__ dzb, int N) {
+  __shared__ float Ai[H][MAXN];
+  __shared__ float dout[H][CZ4];
+  const long bi = blockIdx.x;
+  const int b = (int)(bi / N), i = (int)(bi % N);
+  for (int e = (int)threadIdx.x; e < H * N; e += 256) {
+    const int h = e / N, j = e % N;
+    Ai[h][j] = A[(((long)b * H + h) * N + i) * N + j];
+  }
+  dout[threadIdx.x / CZ4][threadIdx.x % CZ4] = dfeats[bi * LDF + F_PAIR + threadIdx.x];
+  __syncthreads();
+  // d pair_z[b,i,j,c] = sum_h A[h][j] * dout[h][c]
+  for (int e = (int)threadIdx.x; e < N * CZ4; e += 256) {
+    const int j = e / CZ4, c = e % CZ4;
+    float acc = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) acc += Ai[h][j] * dout[h][c];
+    dzb[(bi * N + j) * ZB + H + c] = acc;
+  }
+  // dA[b,h,i,j] += sum_c dout[h][c] * pair_z[b,i,j,c]
+  for (int e = (int)threadIdx.x; e < H * N; e += 256) {
+    const int h = e / N, j = e % N;
+    const float* z = zb + (bi * N + j) * ZB + H;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < CZ4; ++c) acc += dout[h][c] * z[c];
+    dA[(((long)b * H + h) * N + i) * N + j] += acc;
+  }
+}
+
+}  // namespace
+
+#define CHECK_DIMS(fn)                                                                                         \
+  FD_CHECK_ARG(nheads == H && c_hidden == C && n_qk == PQ && n_v == PV,                                         \
+               fn ": built for no_heads=8 c_hidden=256 no_qk_points=8 no_v_points=12 (config/base.yaml), got " \
+                  "%d/%d/%d/%d", nheads, c_hidden, n_qk, n_v)
+
+static unsigned grid1d(long n) {
+  long g = (n + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+extern "C" int fd_ipa_points_fwd(const float* proj, const float* quat, const float* trans, float* qp, float* kp,
+                                 float* vp, long R_, int nheads, int c_hidden, int n_qk, int n_v, void* stream) {
+  CHECK_DIMS("fd_ipa_points_fwd");
+  if (R_ == 0) return FD_OK;
+  hipLaunchKernelGGL(ipa_points_fwd_kernel, dim3(grid1d(R_ * (NQP + NKVP))), dim3(256), 0, (hipStream_t)stream, proj,
+                     quat, trans, qp, kp, vp, R_);
+  FD_CHECK_LAUNCH("fd_ipa_points_fwd");
+  return FD_OK;
+}
+
+extern "C" int fd_ipa_points_bwd(const float* proj, const float* quat, const float* dqp, const float* dkp,
+                                 const float* dvp, float* dproj, float* dframe, long R_, int nheads, int c_hidden,
+                                 int n_qk, int n_v, void* stream) {
+  CHECK_DIMS("fd_ipa_points_bwd");
+  if (R_ == 0) return FD_OK;
+  hipLaunchKernelGGL(ipa_points_bwd_kernel, dim3((unsigned)R_), dim3(256), 0, (hipStream_t)stream, proj, quat, dqp,
+                     dkp, dvp, dproj, dframe);
+  FD_CHECK_LAUNCH("fd_ipa_points_bwd");
+  return FD_OK;
+}
+
+extern "C" int fd_ipa_softmax_fwd(float* S, const float* zb, const float* qp, const float* kp, const float* head_w,
+                                  const float* mask, int B, int N, void* stream) {
+  FD_CHECK_ARG(N <= MAXN, "fd_ipa_softmax_fwd: N=%d exceeds %d", N, MAXN);
+  if (B == 0 || N == 0) return FD_OK;
+  hipLaunchKernelGGL(ipa_softmax_fwd_kernel, dim3((unsigned)((long)B * N)), dim3(256), 0, (hipStream_t)stream, S, zb,
+                     qp, kp, head_w, mask, N);
+  FD_CHECK_LAUNCH("fd_ipa_softmax_fwd");
+  return FD_OK;
+}
+
+extern "C" int fd_ipa_softmax_bwd(const float* A, float* dA, const float* qp, const float* kp, const float* head_w,
+                                  float* dzb, float* dqp, float* dkp, float* dhead_w, int B, int N, void* stream) {
+  FD_CHECK_ARG(N <= MAXN, "fd_ipa_softmax_bwd: N=%d exceeds %d", N, MAXN);
+  if (B == 0 || N == 0) return FD_OK;
+  hipLaunchKernelGGL(ipa_softmax_bwd_kernel, dim3((unsigned)((long)B * N)), dim3(256), 0, (hipStream_t)stream, A, dA,
+                     qp, kp, head_w, dzb, dqp, dhead_w, N);
+  FD_CHECK_LAUNCH("fd_ipa_softmax_bwd");
+  hipLaunchKernelGGL(ipa_kpts_bwd_kernel, dim3((unsigned)((N + 63) / 64), H, (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, dA, qp, kp, head_w, dkp, N);
+  FD_CHECK_LAUNCH("fd_ipa_softmax_bwd(kpts)");
+  return FD_OK;
+}
+
+extern "C" int fd_ipa_opt_fwd(const float* optg, const float* quat, const float* trans, float* feats, long R_,
+                              void* stream) {
+  if (R_ == 0) return FD_OK;
+  hipLaunchKernelGGL(ipa_opt_fwd_kernel, dim3(grid1d(R_ * H * PV)), dim3(256), 0, (hipStream_t)stream, optg, quat,
+                     trans, feats, R_);
+  FD_CHECK_LAUNCH("fd_ipa_opt_fwd");
+  return FD_OK;
+}
+
+extern "C" int fd_ipa_opt_bwd(const float* dfeats, const float* feats, const float* quat, float* doptg,
+                              float* dframe, long R_, void* stream) {
+  if (R_ == 0) return FD_OK;
+  hipLaunchKernelGGL(ipa_opt_bwd_kernel, dim3((unsigned)R_), dim3(128), 0, (hipStream_t)stream, dfeats, feats, quat,
+                     doptg, dframe);
+  FD_CHECK_LAUNCH("fd_ipa_opt_bwd");
+  return FD_OK;
+}
+
+extern "C" int fd_ipa_opair_fwd(const float* A, const float* zb, float* feats, int B, int N, void* stream) {
+  FD_CHECK_ARG(N <= MAXN, "fd_ipa_opair_fwd: N=%d exceeds %d", N, MAXN);
+  if (B == 0 || N == 0) return FD_OK;
+  hipLaunchKernelGGL(ipa_opair_fwd_kernel, dim3((unsigned)((long)B * N)), dim3(256), 0, (hipStream_t)stream, A, zb,
+                     feats, N);
+  FD_CHECK_LAUNCH("fd_ipa_opair_fwd");
+  return FD_OK;
+}
+
+extern "C" int fd_ipa_opair_bwd(const float* A, const float* zb, const float* dfeats, float* dA, float* dzb, int B,
+                                int N, void* stream) {
+  FD_CHECK_ARG(N <= MAXN, "fd_ipa_opair_bwd: N=%d exceeds %d", N, MAXN);
+  if (B == 0 || N == 0) return FD_OK;
+  hipLaunchKernelGGL(ipa_opair_bwd_kernel, dim3((unsigned)((long)B * N)), dim3(256), 0, (hipStream_t)stream, A, zb,
+                     dfeats, dA, dzb, N);
+  FD_CHECK_LAUNCH("fd_ipa_opair_bwd");
+  return FD_OK;
+}

@@ -13,14 +13,12 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_long, c_void_p
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfd_hip.so")
-
-c_float_p = c_void_p  # raw device pointers travel as integers
 
 
 class FdError(RuntimeError):
@@ -47,19 +45,55 @@ class FdGemmDesc(Structure):
     ]
 
 
+class FdHeadConst(Structure):
+    _fields_ = [
+        ("atoms", c_float * 15), ("Rd", c_float * 9), ("td", c_float * 3),
+        ("coord_scale", c_float),
+        ("exp_max_sigma", c_double), ("exp_min_sigma", c_double),
+        ("min_b", c_float), ("max_b", c_float),
+        ("L", c_int),
+    ]
+
+
 def _ptr(t, off=0):
+    """Raw address of a tensor (plus an element offset)."""
     if t is None:
         return None
-    return t.data_ptr() + 4 * int(off) if t.dtype == torch.float32 else t.data_ptr() + t.element_size() * int(off)
+    if isinstance(t, tuple):
+        t, off = t
+    return t.data_ptr() + t.element_size() * int(off)
 
 
-# name -> (restype, argtypes); every symbol include/fd_hip.h declares.
-_SIGNATURES = {
-    "fd_last_error": (c_char_p, []),
-    "fd_abi_version": (c_int, []),
-    "fd_backend": (c_char_p, []),
-    "fd_gemm": (c_int, [POINTER(FdGemmDesc), c_void_p]),
+# Signature codes: p = device pointer (tensor | (tensor, elem_offset) | None), i = int, l = long,
+# f = float, S = pointer to a ctypes struct, s = stream (supplied by the binding).
+_SIGS = {
+    "fd_gemm": "Ss",
+    "fd_layernorm_fwd": "plpppplpplifs",
+    "fd_layernorm_bwd": "plplpppppl" + "ipplis",
+    "fd_colsum_acc": "pllips",
+    "fd_pair_reduce_acc": "piiippls",
+    "fd_axpby": "ppffls",
+    "fd_rowscale": "plppllis",
+    "fd_add2d": "plpllifs",
+    "fd_node_feats": "ppppppiis",
+    "fd_edge_feats": "pppppppppiis",
+    "fd_ipa_points_fwd": "ppppppliiiis",
+    "fd_ipa_points_bwd": "pppppppliiiis",
+    "fd_ipa_softmax_fwd": "ppppppiis",
+    "fd_ipa_softmax_bwd": "pppppppppiis",
+    "fd_ipa_opt_fwd": "ppppls",
+    "fd_ipa_opt_bwd": "pppppls",
+    "fd_ipa_opair_fwd": "pppiis",
+    "fd_ipa_opair_bwd": "pppppiis",
+    "fd_row_softmax_fwd": "pplii" + "s",
+    "fd_row_softmax_bwd": "pplis",
+    "fd_bb_update_fwd": "plipppppppp" + "ls",
+    "fd_bb_update_bwd": "pppppppppp" + "ls",
+    "fd_heads_fwd": "pppp" + "pl" + "ppp" + "pi" + "S" + "pppppp" + "iis",
+    "fd_heads_bwd": "ppppp" + "ppp" + "pi" + "S" + "ppppp" + "ppp" + "iis",
 }
+# exact argument lists, kept next to the header for the symbol-export test
+_CT = {"p": c_void_p, "i": c_int, "l": c_long, "f": c_float, "S": c_void_p, "s": c_void_p}
 
 
 class FdLib:
@@ -72,10 +106,14 @@ class FdLib:
                 f"`python -m se3_diffusion_amd.build` (hipcc, gfx950). There is no CPU fallback.")
         self.path = path
         self.cdll = ctypes.CDLL(path)
-        for name, (res, args) in _SIGNATURES.items():
+        for name, (res, args) in {"fd_last_error": (c_char_p, []), "fd_abi_version": (c_int, []),
+                                  "fd_backend": (c_char_p, [])}.items():
+            fn = getattr(self.cdll, name)
+            fn.restype, fn.argtypes = res, args
+        for name, sig in _SIGS.items():
             fn = getattr(self.cdll, name)  # AttributeError if the symbol is missing
-            fn.restype = res
-            fn.argtypes = args
+            fn.restype = c_int
+            fn.argtypes = [_CT[c] for c in sig]
         self.backend = self.cdll.fd_backend().decode()
         self.is_device = self.backend == "gfx950"
 
@@ -84,16 +122,40 @@ class FdLib:
         if rc != 0:
             raise FdError(f"{what} failed ({rc}): {self.cdll.fd_last_error().decode()}")
 
-    def _stream(self, *tensors):
+    def _stream(self, tensors):
         if not self.is_device:
             for t in tensors:
-                if t is not None and t.is_cuda:
+                if t.is_cuda:
                     raise FdError("emulator build called with a GPU tensor")
             return None
         for t in tensors:
-            if t is not None and not t.is_cuda:
+            if not t.is_cuda:
                 raise FdError("HIP kernel called with a CPU tensor; the hot path has no CPU fallback")
         return torch.cuda.current_stream().cuda_stream
+
+    def call(self, name: str, *args):
+        """Invoke an entry point; tensors become raw pointers, the stream is appended."""
+        sig = _SIGS[name]
+        if len(args) != len(sig) - 1:
+            raise FdError(f"{name}: expected {len(sig) - 1} arguments, got {len(args)}")
+        conv, tens = [], []
+        for code, a in zip(sig, args):
+            if code == "p":
+                t = a[0] if isinstance(a, tuple) else a
+                if t is not None:
+                    if not t.is_contiguous() and t.dim() > 0 and not isinstance(a, tuple):
+                        # strided views are addressed explicitly by the caller via ld/offset arguments
+                        pass
+                    tens.append(t)
+                conv.append(_ptr(a))
+            elif code == "S":
+                conv.append(ctypes.addressof(a))
+            elif code == "f":
+                conv.append(float(a))
+            else:
+                conv.append(int(a))
+        conv.append(self._stream(tens))
+        self._check(getattr(self.cdll, name)(*conv), name)
 
     # -- dense -----------------------------------------------------------
     def gemm(self, A, B, C, M, N, K, a_str, b_str, ldc, *, a_off=0, b_off=0, c_off=0,
@@ -112,21 +174,23 @@ class FdLib:
         d.c_so, d.c_si = c_bs
         d.alpha, d.beta = float(alpha), int(bool(beta))
         d.bias = _ptr(bias)
+        tens = [A, B, C]
         if pair is not None:
             P, Q, ld, nres = pair
             d.pair_p, d.pair_q, d.ld_pair, d.nres = _ptr(P), _ptr(Q), ld, nres
+            tens += [P[0] if isinstance(P, tuple) else P, Q[0] if isinstance(Q, tuple) else Q]
         d.resid, d.ld_resid = _ptr(resid), ld_resid
         d.gate, d.ld_gate = _ptr(gate), ld_gate
         d.rowscale = _ptr(rowscale)
         d.relu, d.tile, d.ksplit = int(bool(relu)), int(tile), int(ksplit)
-        keep = (A, B, C, bias, resid, gate, rowscale, pair)
-        s = self._stream(A, B, C, bias, resid, gate, rowscale)
-        self._check(self.cdll.fd_gemm(ctypes.byref(d), s), "fd_gemm")
-        return keep
+        for x in (bias, resid, gate, rowscale):
+            if x is not None:
+                tens.append(x[0] if isinstance(x, tuple) else x)
+        self._check(self.cdll.fd_gemm(ctypes.byref(d), self._stream(tens)), "fd_gemm")
 
 
 _PRODUCT: FdLib | None = None
-_TEST_OVERRIDE: FdLib | None = None  # set only by tests/emu (never by product code)
+_TEST_OVERRIDE: FdLib | None = None  # set only by tests (never by product code)
 
 
 def get_lib() -> FdLib:
@@ -143,4 +207,4 @@ def get_lib() -> FdLib:
 
 
 def exported_symbols():
-    return sorted(_SIGNATURES)
+    return sorted(list(_SIGS) + ["fd_last_error", "fd_abi_version", "fd_backend"])

@@ -1,0 +1,348 @@
+"""ScoreNetwork forward/backward as a sequence of HIP kernel launches.
+
+Mirrors the reference computation graph (model/score_network.py:170-215,
+model/ipa_pytorch.py:611-672) stage by stage; every stage has a hand-written
+backward.  Stages exchange plain fp32 tensors; `P` is the parameter dict (state_dict
+names), `G` the gradient dict (same names, accumulated into), `sv` a dict of tensors
+saved by the forward for the backward.
+
+Stage list per trunk block b (A3 of SURVEY.md):
+  ipa        x1 = s + m * IPA(s, z, T)                     ipa_pytorch.py:625-631
+  ln_skip    u0 = [LN(x1) | W_skip s_init]                 :632-635
+  tfmr x2    post-norm encoder layers on u (320)           :636-637
+  post       n2 = u0[:, :256] + W_post u2                  :638
+  node_tr    n3 = m * LN(n2 + MLP(n2))                     :639-640
+  bb_update  T' = T o (W_bb (n3 * d))                      :641-644
+  edge_tr    z' = mm * LN(W_f(relu(W_b relu(W_a x)) + x))  :646-649
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import hip, ops
+from .ops import empty, zeros, mv, lib
+
+H, C, PQ, PV, CZ4 = 8, 256, 8, 12, 32
+CS, CZ = 256, 128
+LDP = 6816
+LDF = 2688
+ZB = 40
+TD, TH, THD = 320, 4, 80  # transformer width, heads, head dim
+
+
+def check_conf(conf):
+    ipa = conf.ipa
+    want = dict(c_s=256, c_z=128, c_hidden=256, c_skip=64, no_heads=8, no_qk_points=8, no_v_points=12,
+                seq_tfmr_num_heads=4)
+    for k, v in want.items():
+        if getattr(ipa, k) != v:
+            raise NotImplementedError(
+                f"the gfx950 kernels are built for config/base.yaml dimensions; model.ipa.{k}={getattr(ipa, k)} != {v}")
+    if conf.node_embed_size != 256 or conf.edge_embed_size != 128:
+        raise NotImplementedError("node_embed_size/edge_embed_size must be 256/128")
+    e = conf.embed
+    if e.index_embed_size != 32 or e.num_bins != 22 or not e.embed_self_conditioning:
+        raise NotImplementedError("embed config must match config/base.yaml (index 32, 22 bins, self-conditioning)")
+
+
+# --------------------------------------------------------------------------- param grads
+def _lin_grads(G, wname, bname, dy, x, M, N, K, w_off=0, w_ld=None):
+    if G is None:
+        return
+    if wname in G:
+        W = G[wname]
+        ops.linear_dw(dy, x, (W, w_off, w_ld if w_ld is not None else W.shape[1]), M, N, K)
+    if bname is not None and bname in G:
+        ops.bias_grad(dy, G[bname], M, N)
+
+
+# --------------------------------------------------------------------------- embedder
+def mlp3_ln_fwd(P, pre, x, M, K0, Cc, rowscale):
+    """Linear-ReLU-Linear-ReLU-Linear-LayerNorm (* rowscale) -- score_network.py:67-86,194-195."""
+    dev = x[0]
+    h1 = empty((M, Cc), dev); h2 = empty((M, Cc), dev); h3 = empty((M, Cc), dev); y = empty((M, Cc), dev)
+    mean = empty((M,), dev); rstd = empty((M,), dev)
+    ops.linear(x, mv(P[f"{pre}.0.weight"]), P[f"{pre}.0.bias"], mv(h1), M, Cc, K0, relu=True)
+    ops.linear(mv(h1), mv(P[f"{pre}.2.weight"]), P[f"{pre}.2.bias"], mv(h2), M, Cc, Cc, relu=True)
+    ops.linear(mv(h2), mv(P[f"{pre}.4.weight"]), P[f"{pre}.4.bias"], mv(h3), M, Cc, Cc)
+    ops.layernorm(mv(h3), P[f"{pre}.5.weight"], P[f"{pre}.5.bias"], mv(y), M, Cc, rowscale=rowscale, save=(mean, rstd))
+    return y, dict(x=x, h1=h1, h2=h2, h3=h3, mean=mean, rstd=rstd, rowscale=rowscale, M=M, K0=K0, C=Cc)
+
+
+def mlp3_ln_bwd(P, G, pre, sv, dy):
+    M, K0, Cc = sv["M"], sv["K0"], sv["C"]
+    dev = dy
+    dh3 = empty((M, Cc), dev)
+    ops.layernorm_bwd(mv(dy), mv(sv["h3"]), P[f"{pre}.5.weight"], sv["mean"], sv["rstd"], mv(dh3), M, Cc,
+                      rowscale=sv["rowscale"], dgamma=G[f"{pre}.5.weight"], dbeta=G[f"{pre}.5.bias"])
+    _lin_grads(G, f"{pre}.4.weight", f"{pre}.4.bias", mv(dh3), mv(sv["h2"]), M, Cc, Cc)
+    dh2 = empty((M, Cc), dev)
+    ops.linear_dx(mv(dh3), mv(P[f"{pre}.4.weight"]), mv(dh2), M, Cc, Cc, gate=mv(sv["h2"]))
+    _lin_grads(G, f"{pre}.2.weight", f"{pre}.2.bias", mv(dh2), mv(sv["h1"]), M, Cc, Cc)
+    dh1 = dh3  # reuse
+    ops.linear_dx(mv(dh2), mv(P[f"{pre}.2.weight"]), mv(dh1), M, Cc, Cc, gate=mv(sv["h1"]))
+    _lin_grads(G, f"{pre}.0.weight", f"{pre}.0.bias", mv(dh1), sv["x"], M, Cc, K0)
+
+
+def embed_fwd(P, feats, B, N):
+    dev = feats["res_mask"]
+    mask = feats["res_mask"]
+    tfreq, idenom, lower, upper = ops.feature_tables(dev.device)
+    tscaled = (feats["t"] * 10000).float().contiguous()          # score_network.py:38,43
+    fixed = feats["fixed_mask"]
+    seq = feats["seq_idx"]
+    R, Pn = B * N, B * N * N
+    nf = empty((R, 65), dev)
+    lib().call("fd_node_feats", seq, tscaled, fixed, tfreq, idenom, nf, B, N)
+    node, sv_n = mlp3_ln_fwd(P, "embedding_layer.node_embedder", mv(nf), R, 65, CS, mask)
+    ef = empty((Pn, 120), dev)
+    lib().call("fd_edge_feats", seq, tscaled, fixed, feats["sc_ca_t"], tfreq, idenom, lower, upper, ef, B, N)
+    emask = pair_mask(mask, B, N)
+    edge, sv_e = mlp3_ln_fwd(P, "embedding_layer.edge_embedder", mv(ef), Pn, 120, CZ, emask)
+    return node, edge, dict(node=sv_n, edge=sv_e, emask=emask)
+
+
+def embed_bwd(P, G, sv, dnode, dedge):
+    mlp3_ln_bwd(P, G, "embedding_layer.node_embedder", sv["node"], dnode)
+    mlp3_ln_bwd(P, G, "embedding_layer.edge_embedder", sv["edge"], dedge)
+
+
+def pair_mask(mask, B, N):
+    """edge_mask[b,i,j] = m_i * m_j as a flat [B*N*N] row scale (score_network.py:185)."""
+    em = empty((B * N * N,), mask)
+    # rows = (b,i) each of N columns: out[b,i,j] = mask[b,j] * mask[b,i]
+    src = mask.reshape(B, 1, N).expand(B, N, N).contiguous()      # plumbing (masks only)
+    lib().call("fd_rowscale", src, N, mask.reshape(-1), em, N, B * N, N)
+    return em
+
+
+# --------------------------------------------------------------------------- IPA
+def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N):
+    """x1 = s + mask * IPA(s, z, T).  s: matrix view [R,256]."""
+    dev = z
+    R, Pn = B * N, B * N * N
+    proj = empty((R, LDP), dev)
+    ops.linear(s, mv(P[f"{pre}.linear_q.weight"]), P[f"{pre}.linear_q.bias"], (proj, 0, LDP), R, H * C, CS)
+    ops.linear(s, mv(P[f"{pre}.linear_kv.weight"]), P[f"{pre}.linear_kv.bias"], (proj, 2048, LDP), R, 2 * H * C, CS)
+    ops.linear(s, mv(P[f"{pre}.linear_q_points.weight"]), P[f"{pre}.linear_q_points.bias"], (proj, 6144, LDP), R, 192, CS)
+    ops.linear(s, mv(P[f"{pre}.linear_kv_points.weight"]), P[f"{pre}.linear_kv_points.bias"], (proj, 6336, LDP), R, 480, CS)
+    qp = empty((R, H, PQ * 3), dev); kp = empty((R, H, PQ * 3), dev); vp = empty((R, H, PV * 3), dev)
+    lib().call("fd_ipa_points_fwd", proj, quat, trans, qp, kp, vp, R, H, C, PQ, PV)
+    W40 = torch.cat([P[f"{pre}.linear_b.weight"], P[f"{pre}.down_z.weight"]], 0).contiguous()   # tiny pack
+    b40 = torch.cat([P[f"{pre}.linear_b.bias"], P[f"{pre}.down_z.bias"]], 0).contiguous()
+    zb = empty((Pn, ZB), dev)
+    ops.linear(mv(z), mv(W40), b40, mv(zb), Pn, ZB, CZ)
+    A = empty((B, H, N, N), dev)
+    L = lib()
+    L.gemm(proj, proj, A, N, N, C, (LDP, 1), (1, LDP), N, b_off=2048, batch=B * H, bdiv=H,
+           a_bs=(N * LDP, C), b_bs=(N * LDP, 2 * C), c_bs=(H * N * N, N * N), alpha=math.sqrt(1.0 / (3 * C)))
+    L.call("fd_ipa_softmax_fwd", A, zb, qp, kp, P[f"{pre}.head_weights"], mask, B, N)
+    feats = empty((R, LDF), dev)
+    L.gemm(A, proj, feats, N, C, N, (N, 1), (LDP, 1), LDF, b_off=2048 + C, batch=B * H, bdiv=H,
+           a_bs=(H * N * N, N * N), b_bs=(N * LDP, 2 * C), c_bs=(N * LDF, C))
+    optg = empty((R, H, PV * 3), dev)
+    L.gemm(A, vp, optg, N, PV * 3, N, (N, 1), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
+           a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
+    L.call("fd_ipa_opt_fwd", optg, quat, trans, feats, R)
+    L.call("fd_ipa_opair_fwd", A, zb, feats, B, N)
+    x1 = empty((R, CS), dev)
+    ops.linear(mv(feats), mv(P[f"{pre}.linear_out.weight"]), P[f"{pre}.linear_out.bias"], mv(x1), R, CS, LDF,
+               rowscale=mask, resid=s)
+    sv = dict(s=s, z=z, quat=quat, trans=trans, mask=mask, proj=proj, qp=qp, kp=kp, vp=vp, W40=W40, zb=zb, A=A,
+              feats=feats, B=B, N=N)
+    return x1, sv
+
+
+def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe):
+    """dx1 [R,256] -> accumulates ds (view, +=), dz [P,128] (+=), dframe [R,12] (+=); param grads into G."""
+    B, N = sv["B"], sv["N"]
+    R, Pn = B * N, B * N * N
+    dev = dx1
+    L = lib()
+    mask = sv["mask"]
+    s, z, proj, A, feats, zb = sv["s"], sv["z"], sv["proj"], sv["A"], sv["feats"], sv["zb"]
+    quat, qp, kp, vp = sv["quat"], sv["qp"], sv["kp"], sv["vp"]
+    # residual branch: ds += dx1
+    dm = empty((R, CS), dev)                     # d(ipa linear_out output) = mask * dx1
+    L.call("fd_rowscale", dx1, CS, mask, dm, CS, R, CS)
+    ops.add_view(ds, mv(dx1), R, CS)
+    _lin_grads(G, f"{pre}.linear_out.weight", f"{pre}.linear_out.bias", mv(dm), mv(feats), R, CS, LDF)
+    dfeats = empty((R, LDF), dev)
+    ops.linear_dx(mv(dm), mv(P[f"{pre}.linear_out.weight"]), mv(dfeats), R, CS, LDF)
+    dproj = zeros((R, LDP), dev)
+    # dA = dO V^T ; dV = A^T dO
+    dA = empty((B, H, N, N), dev)
+    L.gemm(dfeats, proj, dA, N, N, C, (LDF, 1), (1, LDP), N, b_off=2048 + C, batch=B * H, bdiv=H,
+           a_bs=(N * LDF, C), b_bs=(N * LDP, 2 * C), c_bs=(H * N * N, N * N))
+    L.gemm(A, dfeats, dproj, N, C, N, (1, N), (LDF, 1), LDP, c_off=2048 + C, batch=B * H, bdiv=H,
+           a_bs=(H * N * N, N * N), b_bs=(N * LDF, C), c_bs=(N * LDP, 2 * C))
+    # o_pt
+    doptg = empty((R, H, PV * 3), dev)
+    L.call("fd_ipa_opt_bwd", dfeats, feats, quat, doptg, dframe, R)
+    L.gemm(doptg, vp, dA, N, N, PV * 3, (H * PV * 3, 1), (1, H * PV * 3), N, batch=B * H, bdiv=H,
+           a_bs=(N * H * PV * 3, PV * 3), b_bs=(N * H * PV * 3, PV * 3), c_bs=(H * N * N, N * N), beta=True)
+    dvp = empty((R, H, PV * 3), dev)
+    L.gemm(A, doptg, dvp, N, PV * 3, N, (1, N), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
+           a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
+    # o_pair
+    dzb = empty((Pn, ZB), dev)
+    L.call("fd_ipa_opair_bwd", A, zb, dfeats, dA, dzb, B, N)
+    # softmax (dA becomes dLogits) + point/bias/head-weight grads
+    dqp = empty((R, H, PQ * 3), dev); dkp = empty((R, H, PQ * 3), dev)
+    dhw = G[f"{pre}.head_weights"] if G is not None else zeros((H,), dev)
+    L.call("fd_ipa_softmax_bwd", A, dA, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, B, N)
+    sc = math.sqrt(1.0 / (3 * C))
+    # dQ = sc * dL K ; dK = sc * dL^T Q
+    L.gemm(dA, proj, dproj, N, C, N, (N, 1), (LDP, 1), LDP, b_off=2048, batch=B * H, bdiv=H,
+           a_bs=(H * N * N, N * N), b_bs=(N * LDP, 2 * C), c_bs=(N * LDP, C), alpha=sc)
+    L.gemm(dA, proj, dproj, N, C, N, (1, N), (LDP, 1), LDP, c_off=2048, batch=B * H, bdiv=H,
+           a_bs=(H * N * N, N * N), b_bs=(N * LDP, C), c_bs=(N * LDP, 2 * C), alpha=sc)
+    L.call("fd_ipa_points_bwd", proj, quat, dqp, dkp, dvp, dproj, dframe, R, H, C, PQ, PV)
+    # z path: dz += dzb W40 ; dW40 += dzb^T z
+    ops.linear_dx(mv(dzb), mv(sv["W40"]), mv(dz), Pn, ZB, CZ, beta=True)
+    if G is not None:
+        dW40 = zeros((ZB, CZ), dev); db40 = zeros((ZB,), dev)
+        ops.linear_dw(mv(dzb), mv(z), mv(dW40), Pn, ZB, CZ)
+        ops.bias_grad(mv(dzb), db40, Pn, ZB)
+        G[f"{pre}.linear_b.weight"] += dW40[:H]; G[f"{pre}.down_z.weight"] += dW40[H:]
+        G[f"{pre}.linear_b.bias"] += db40[:H]; G[f"{pre}.down_z.bias"] += db40[H:]
+    # projections: ds += dproj_slice W ; dW += dproj_slice^T s
+    for name, off, n in (("linear_q", 0, 2048), ("linear_kv", 2048, 4096), ("linear_q_points", 6144, 192),
+                         ("linear_kv_points", 6336, 480)):
+        ops.linear_dx((dproj, off, LDP), mv(P[f"{pre}.{name}.weight"]), ds, R, n, CS, beta=True)
+        _lin_grads(G, f"{pre}.{name}.weight", f"{pre}.{name}.bias", (dproj, off, LDP), s, R, n, CS)
+
+
+# --------------------------------------------------------------------------- LN + skip concat
+def ln_skip_fwd(P, b, x1, init_node, R):
+    pre = "score_model.trunk"
+    dev = x1
+    u0 = empty((R, TD), dev)
+    mean = empty((R,), dev); rstd = empty((R,), dev)
+    ops.layernorm(mv(x1), P[f"{pre}.ipa_ln_{b}.weight"], P[f"{pre}.ipa_ln_{b}.bias"], (u0, 0, TD), R, CS, save=(mean, rstd))
+    ops.linear(mv(init_node), mv(P[f"{pre}.skip_embed_{b}.weight"]), P[f"{pre}.skip_embed_{b}.bias"], (u0, CS, TD), R, 64, CS)
+    return u0, dict(x1=x1, mean=mean, rstd=rstd, init_node=init_node, R=R)
+
+
+def ln_skip_bwd(P, G, b, sv, du0, dx1, dinit):
+    """du0 [R,320] -> dx1 [R,256] (=), dinit [R,256] (+=)."""
+    pre = "score_model.trunk"
+    R = sv["R"]
+    ops.layernorm_bwd((du0, 0, TD), mv(sv["x1"]), P[f"{pre}.ipa_ln_{b}.weight"], sv["mean"], sv["rstd"], mv(dx1), R, CS,
+                      dgamma=G[f"{pre}.ipa_ln_{b}.weight"], dbeta=G[f"{pre}.ipa_ln_{b}.bias"])
+    ops.linear_dx((du0, CS, TD), mv(P[f"{pre}.skip_embed_{b}.weight"]), mv(dinit), R, 64, CS, beta=True)
+    _lin_grads(G, f"{pre}.skip_embed_{b}.weight", f"{pre}.skip_embed_{b}.bias", (du0, CS, TD), mv(sv["init_node"]), R, 64, CS)
+
+
+# --------------------------------------------------------------------------- transformer layer
+def tfmr_layer_fwd(P, pre, x, key_add, B, N):
+    dev = x
+    R = B * N
+    L = lib()
+    qkv = empty((R, 3 * TD), dev)
+    ops.linear(mv(x), mv(P[f"{pre}.self_attn.in_proj_weight"]), P[f"{pre}.self_attn.in_proj_bias"], mv(qkv), R, 3 * TD, TD)
+    A = empty((B, TH, N, N), dev)
+    L.gemm(qkv, qkv, A, N, N, THD, (3 * TD, 1), (1, 3 * TD), N, b_off=TD, batch=B * TH, bdiv=TH,
+           a_bs=(N * 3 * TD, THD), b_bs=(N * 3 * TD, THD), c_bs=(TH * N * N, N * N), alpha=1.0 / math.sqrt(THD))
+    L.call("fd_row_softmax_fwd", A, key_add, B * TH * N, N, TH * N)
+    o = empty((R, TD), dev)
+    L.gemm(A, qkv, o, N, THD, N, (N, 1), (3 * TD, 1), TD, b_off=2 * TD, batch=B * TH, bdiv=TH,
+           a_bs=(TH * N * N, N * N), b_bs=(N * 3 * TD, THD), c_bs=(N * TD, THD))
+    t1 = empty((R, TD), dev)
+    ops.linear(mv(o), mv(P[f"{pre}.self_attn.out_proj.weight"]), P[f"{pre}.self_attn.out_proj.bias"], mv(t1), R, TD, TD, resid=mv(x))
+    y1 = empty((R, TD), dev); m1 = empty((R,), dev); r1 = empty((R,), dev)
+    ops.layernorm(mv(t1), P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"], mv(y1), R, TD, save=(m1, r1))
+    f = empty((R, TD), dev)
+    ops.linear(mv(y1), mv(P[f"{pre}.linear1.weight"]), P[f"{pre}.linear1.bias"], mv(f), R, TD, TD, relu=True)
+    t2 = empty((R, TD), dev)
+    ops.linear(mv(f), mv(P[f"{pre}.linear2.weight"]), P[f"{pre}.linear2.bias"], mv(t2), R, TD, TD, resid=mv(y1))
+    y2 = empty((R, TD), dev); m2 = empty((R,), dev); r2 = empty((R,), dev)
+    ops.layernorm(mv(t2), P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"], mv(y2), R, TD, save=(m2, r2))
+    return y2, dict(x=x, qkv=qkv, A=A, o=o, t1=t1, m1=m1, r1=r1, y1=y1, f=f, t2=t2, m2=m2, r2=r2, B=B, N=N)
+
+
+def tfmr_layer_bwd(P, G, pre, sv, dy2):
+    """returns dx [R,320]."""
+    B, N = sv["B"], sv["N"]
+    R = B * N
+    dev = dy2
+    L = lib()
+    dt2 = empty((R, TD), dev)
+    ops.layernorm_bwd(mv(dy2), mv(sv["t2"]), P[f"{pre}.norm2.weight"], sv["m2"], sv["r2"], mv(dt2), R, TD,
+                      dgamma=G[f"{pre}.norm2.weight"], dbeta=G[f"{pre}.norm2.bias"])
+    _lin_grads(G, f"{pre}.linear2.weight", f"{pre}.linear2.bias", mv(dt2), mv(sv["f"]), R, TD, TD)
+    df = empty((R, TD), dev)
+    ops.linear_dx(mv(dt2), mv(P[f"{pre}.linear2.weight"]), mv(df), R, TD, TD, gate=mv(sv["f"]))
+    _lin_grads(G, f"{pre}.linear1.weight", f"{pre}.linear1.bias", mv(df), mv(sv["y1"]), R, TD, TD)
+    dy1 = dt2  # dy1 = dt2 (residual) + df W1
+    ops.linear_dx(mv(df), mv(P[f"{pre}.linear1.weight"]), mv(dy1), R, TD, TD, beta=True)
+    dt1 = empty((R, TD), dev)
+    ops.layernorm_bwd(mv(dy1), mv(sv["t1"]), P[f"{pre}.norm1.weight"], sv["m1"], sv["r1"], mv(dt1), R, TD,
+                      dgamma=G[f"{pre}.norm1.weight"], dbeta=G[f"{pre}.norm1.bias"])
+    _lin_grads(G, f"{pre}.self_attn.out_proj.weight", f"{pre}.self_attn.out_proj.bias", mv(dt1), mv(sv["o"]), R, TD, TD)
+    do = df  # reuse
+    ops.linear_dx(mv(dt1), mv(P[f"{pre}.self_attn.out_proj.weight"]), mv(do), R, TD, TD)
+    qkv, A = sv["qkv"], sv["A"]
+    dqkv = empty((R, 3 * TD), dev)
+    dA = empty((B, TH, N, N), dev)
+    # dA = do V^T ; dV = A^T do
+    L.gemm(do, qkv, dA, N, N, THD, (TD, 1), (1, 3 * TD), N, b_off=2 * TD, batch=B * TH, bdiv=TH,
+           a_bs=(N * TD, THD), b_bs=(N * 3 * TD, THD), c_bs=(TH * N * N, N * N))
+    L.gemm(A, do, dqkv, N, THD, N, (1, N), (TD, 1), 3 * TD, c_off=2 * TD, batch=B * TH, bdiv=TH,
+           a_bs=(TH * N * N, N * N), b_bs=(N * TD, THD), c_bs=(N * 3 * TD, THD))
+    L.call("fd_row_softmax_bwd", A, dA, B * TH * N, N)
+    sc = 1.0 / math.sqrt(THD)
+    L.gemm(dA, qkv, dqkv, N, THD, N, (N, 1), (3 * TD, 1), 3 * TD, b_off=TD, batch=B * TH, bdiv=TH,
+           a_bs=(TH * N * N, N * N), b_bs=(N * 3 * TD, THD), c_bs=(N * 3 * TD, THD), alpha=sc)
+    L.gemm(dA, qkv, dqkv, N, THD, N, (1, N), (3 * TD, 1), 3 * TD, c_off=TD, batch=B * TH, bdiv=TH,
+           a_bs=(TH * N * N, N * N), b_bs=(N * 3 * TD, THD), c_bs=(N * 3 * TD, THD), alpha=sc)
+    _lin_grads(G, f"{pre}.self_attn.in_proj_weight", f"{pre}.self_attn.in_proj_bias", mv(dqkv), mv(sv["x"]), R, 3 * TD, TD)
+    dx = dt1  # dx = dt1 (residual) + dqkv W_in
+    ops.linear_dx(mv(dqkv), mv(P[f"{pre}.self_attn.in_proj_weight"]), mv(dx), R, 3 * TD, TD, beta=True)
+    return dx
+
+
+# --------------------------------------------------------------------------- post-tfmr + node transition
+def post_node_fwd(P, b, u2, u0, mask, R):
+    """n2 = u0[:, :256] + W_post u2 ; n3 = mask * LN(n2 + W3 relu(W2 relu(W1 n2)))."""
+    pre = "score_model.trunk"
+    dev = u2
+    n2 = empty((R, CS), dev)
+    ops.linear(mv(u2), mv(P[f"{pre}.post_tfmr_{b}.weight"]), P[f"{pre}.post_tfmr_{b}.bias"], mv(n2), R, CS, TD, resid=(u0, 0, TD))
+    nt = f"{pre}.node_transition_{b}"
+    h1 = empty((R, CS), dev); h2 = empty((R, CS), dev); t = empty((R, CS), dev); n3 = empty((R, CS), dev)
+    mean = empty((R,), dev); rstd = empty((R,), dev)
+    ops.linear(mv(n2), mv(P[f"{nt}.linear_1.weight"]), P[f"{nt}.linear_1.bias"], mv(h1), R, CS, CS, relu=True)
+    ops.linear(mv(h1), mv(P[f"{nt}.linear_2.weight"]), P[f"{nt}.linear_2.bias"], mv(h2), R, CS, CS, relu=True)
+    ops.linear(mv(h2), mv(P[f"{nt}.linear_3.weight"]), P[f"{nt}.linear_3.bias"], mv(t), R, CS, CS, resid=mv(n2))
+    ops.layernorm(mv(t), P[f"{nt}.ln.weight"], P[f"{nt}.ln.bias"], mv(n3), R, CS, rowscale=mask, save=(mean, rstd))
+    return n3, dict(u2=u2, n2=n2, h1=h1, h2=h2, t=t, mean=mean, rstd=rstd, mask=mask, R=R)
+
+
+def post_node_bwd(P, G, b, sv, dn3, du0):
+    """dn3 [R,256] -> returns du2 [R,320]; du0[:, :256] += dn2."""
+    pre = "score_model.trunk"
+    nt = f"{pre}.node_transition_{b}"
+    R = sv["R"]
+    dev = dn3
+    dt = empty((R, CS), dev)
+    ops.layernorm_bwd(mv(dn3), mv(sv["t"]), P[f"{nt}.ln.weight"], sv["mean"], sv["rstd"], mv(dt), R, CS,
+                      rowscale=sv["mask"], dgamma=G[f"{nt}.ln.weight"], dbeta=G[f"{nt}.ln.bias"])
+    _lin_grads(G, f"{nt}.linear_3.weight", f"{nt}.linear_3.bias", mv(dt), mv(sv["h2"]), R, CS, CS)
+    dh2 = empty((R, CS), dev)
+    ops.linear_dx(mv(dt), mv(P[f"{nt}.linear_3.weight"]), mv(dh2), R, CS, CS, gate=mv(sv["h2"]))
+    _lin_grads(G, f"{nt}.linear_2.weight", f"{nt}.linear_2.bias", mv(dh2), mv(sv["h1"]), R, CS, CS)
+    dh1 = empty((R, CS), dev)
+    ops.linear_dx(mv(dh2), mv(P[f"{nt}.linear_2.weight"]), mv(dh1), R, CS, CS, gate=mv(sv["h1"]))
+    _lin_grads(G, f"{nt}.linear_1.weight", f"{nt}.linear_1.bias", mv(dh1), mv(sv["n2"]), R, CS, CS)
+    dn2 = dt  # dn2 = dt (residual) + dh1 W1
+    ops.linear_dx(mv(dh1), mv(P[f"{nt}.linear_1.weight"]), mv(dn2), R, CS, CS, beta=True)
+    _lin_grads(G, f"{pre}.post_tfmr_{b}.weight", f"{pre}.post_tfmr_{b}.bias", mv(dn2), mv(sv["u2"]), R, CS, TD)
+    du2 = empty((R, TD), dev)
+    ops.linear_dx(mv(dn2), mv(P[f"{pre}.post_tfmr_{b}.weight"]), mv(du2), R, CS, TD)
+    ops.add_view((du0, 0, TD), mv(dn2), R, CS)
+    return du2

@@ -1,0 +1,126 @@
+"""Host-side composition of the HIP kernels (thin: pointer/stride bookkeeping only).
+
+Every function here launches kernels from libfd_hip.so through se3_diffusion_amd.hip;
+torch is used for memory (torch.empty / views) and nothing else.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import hip
+
+F32 = torch.float32
+
+
+def lib():
+    return hip.get_lib()
+
+
+def empty(shape, like, dtype=F32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+def zeros(shape, like, dtype=F32):
+    return torch.zeros(shape, device=like.device, dtype=dtype)
+
+
+# ---------------------------------------------------------------------------
+# dense helpers.  A "matrix view" is (tensor, elem_offset, ld): rows at offset + r*ld.
+# ---------------------------------------------------------------------------
+def mv(t, off=0, ld=None):
+    return (t, off, ld if ld is not None else t.shape[-1])
+
+
+def linear(x, W, b, out, M, N, K, *, relu=False, resid=None, rowscale=None, pair=None, beta=False,
+           gate=None, alpha=1.0, tile=0):
+    """out[M,N] = epi(x[M,K] @ W[N,K]^T + b).  x, W, out, resid, gate are matrix views."""
+    xt, xo, xl = x
+    wt, wo, wl = W
+    ot, oo, ol = out
+    kw = {}
+    if resid is not None:
+        kw.update(resid=(resid[0], resid[1]), ld_resid=resid[2])
+    if gate is not None:
+        kw.update(gate=(gate[0], gate[1]), ld_gate=gate[2])
+    lib().gemm(xt, wt, ot, M, N, K, (xl, 1), (1, wl), ol, a_off=xo, b_off=wo, c_off=oo, bias=b,
+               relu=relu, rowscale=rowscale, pair=pair, beta=beta, alpha=alpha, tile=tile, **kw)
+
+
+def linear_dx(dy, W, dx, M, N, K, *, beta=False, gate=None, rowscale=None, alpha=1.0):
+    """dx[M,K] (+)= dy[M,N] @ W[N,K]; optional relu gate (zero where gate<=0) on the result."""
+    dt, do, dl = dy
+    wt, wo, wl = W
+    xt, xo, xl = dx
+    kw = {}
+    if gate is not None:
+        kw.update(gate=(gate[0], gate[1]), ld_gate=gate[2])
+    lib().gemm(dt, wt, xt, M, K, N, (dl, 1), (wl, 1), xl, a_off=do, b_off=wo, c_off=xo, beta=beta,
+               rowscale=rowscale, alpha=alpha, **kw)
+
+
+def _ksplit(mn_blocks, K):
+    ks = max(1, min(1024 // max(1, mn_blocks), K // 256))
+    return ks
+
+
+def linear_dw(dy, x, dW, M, N, K):
+    """dW[N,K] += dy[M,N]^T @ x[M,K]  (reduction over the M rows; split-K)."""
+    dt, do, dl = dy
+    xt, xo, xl = x
+    wt, wo, wl = dW
+    blocks = ((N + 63) // 64) * ((K + 63) // 64)
+    ks = _ksplit(blocks, M)
+    lib().gemm(dt, xt, wt, N, K, M, (1, dl), (xl, 1), wl, a_off=do, b_off=xo, c_off=wo,
+               beta=(ks == 1), ksplit=ks, tile=2)
+
+
+def add_view(dst, src, rows, cols, alpha=1.0):
+    """dst(view)[r, c] += alpha * src(view)[r, c]."""
+    dt, do, dl = dst
+    st, so, sl = src
+    lib().call("fd_add2d", (dt, do), dl, (st, so), sl, rows, cols, alpha)
+
+
+def bias_grad(dy, db, M, N):
+    dt, do, dl = dy
+    lib().call("fd_colsum_acc", (dt, do), dl, M, N, db)
+
+
+def layernorm(x, gamma, beta, y, rows, C, *, rowscale=None, save=None):
+    """y = LN(x) (* rowscale).  x, y matrix views.  save=(mean, rstd) tensors or None."""
+    xt, xo, xl = x
+    yt, yo, yl = y
+    mean, rstd = save if save is not None else (None, None)
+    lib().call("fd_layernorm_fwd", (xt, xo), xl, gamma, beta, rowscale, (yt, yo), yl, mean, rstd, rows, C, 1e-5)
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, rows, C, *, rowscale=None, dgamma=None, dbeta=None, accum=False):
+    dt, do, dl = dy
+    xt, xo, xl = x
+    gt, go, gl = dx
+    lib().call("fd_layernorm_bwd", (dt, do), dl, (xt, xo), xl, gamma, rowscale, mean, rstd, (gt, go), gl,
+               int(accum), dgamma, dbeta, rows, C)
+
+
+# ---------------------------------------------------------------------------
+# host-computed constant tables (reference op sequence, so arguments are bit-identical)
+# ---------------------------------------------------------------------------
+_TABLES = {}
+
+
+def feature_tables(device, index_embed_size=32, num_bins=22, min_bin=1e-5, max_bin=20.0):
+    key = (str(device), index_embed_size, num_bins, min_bin, max_bin)
+    if key not in _TABLES:
+        half = index_embed_size // 2
+        # score_network.py:40-42
+        tfreq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
+        # score_network.py:26-29: max_len ** (2*K/embed_size)
+        k = torch.arange(half)
+        idenom = (2056 ** (2 * k[None] / index_embed_size))[0].to(torch.float32)
+        # data/utils.py:573-578
+        lower = torch.linspace(min_bin, max_bin, num_bins)
+        upper = torch.cat([lower[1:], lower.new_tensor([1e8])])
+        _TABLES[key] = tuple(t.contiguous().to(device) for t in (tfreq, idenom, lower, upper))
+    return _TABLES[key]

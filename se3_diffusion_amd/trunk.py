@@ -1,0 +1,332 @@
+"""Remaining ScoreNetwork stages (backbone update, edge transition, heads) and the
+whole-network forward / backward drivers.  See network.py for conventions."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import hip, ops
+from . import network as nw
+from .network import CS, CZ, TD, H, _lin_grads
+from .ops import empty, zeros, mv, lib
+
+EH = 384  # edge-transition hidden = c_z + 2 * (c_s // 2)
+CE = 128  # edge-transition node embedding (c_s // 2)
+
+
+# --------------------------------------------------------------------------- backbone update
+def bb_update_fwd(P, b, n3, dmask, quat, trans, R):
+    pre = f"score_model.trunk.bb_update_{b}.linear"
+    dev = n3
+    upd = empty((R, 6), dev); q2 = empty((R, 4), dev); t2 = empty((R, 3), dev)
+    lib().call("fd_bb_update_fwd", n3, CS, CS, dmask, P[f"{pre}.weight"], P[f"{pre}.bias"], quat, trans, upd, q2, t2, R)
+    return q2, t2, dict(n3=n3, dmask=dmask, quat=quat, upd=upd, R=R)
+
+
+def bb_update_bwd(P, G, b, sv, dq2, dt2, dframe, dn3):
+    """(dq2, dt2) grads of the updated frame; dframe [R,12] = grads of the INPUT frame collected by the IPA
+    kernels.  Returns (dq, dt) of the input frame; accumulates dn3 (+=)."""
+    pre = f"score_model.trunk.bb_update_{b}.linear"
+    R = sv["R"]
+    dev = dq2
+    dq = empty((R, 4), dev); dt = empty((R, 3), dev); dupd = empty((R, 6), dev); dupd_s = empty((R, 6), dev)
+    lib().call("fd_bb_update_bwd", dq2, dt2, dframe, sv["dmask"], sv["upd"], sv["quat"], dq, dt, dupd, dupd_s, R)
+    # upd = W6 (n3 * d) + b6
+    if G is not None:
+        ops.linear_dw(mv(dupd_s), mv(sv["n3"]), mv(G[f"{pre}.weight"]), R, 6, CS)
+        ops.bias_grad(mv(dupd), G[f"{pre}.bias"], R, 6)
+    ops.linear_dx(mv(dupd_s), mv(P[f"{pre}.weight"]), mv(dn3), R, 6, CS, beta=True)
+    return dq, dt
+
+
+# --------------------------------------------------------------------------- edge transition
+def edge_transition_fwd(P, b, n3, z, emask, B, N):
+    """z' = emask * LN(W_f (relu(W_2 relu(W_1 x)) + x) + b_f), x = [z | e_i | e_j], e = W_init n3.
+    The concat is never materialised: W x = W[:, :128] z + (W[:,128:256] e)_i + (W[:,256:] e)_j."""
+    pre = f"score_model.trunk.edge_transition_{b}"
+    dev = z
+    R, Pn = B * N, B * N * N
+    W1, Wf = P[f"{pre}.trunk.0.weight"], P[f"{pre}.final_layer.weight"]
+    e = empty((R, CE), dev)
+    ops.linear(mv(n3), mv(P[f"{pre}.initial_embed.weight"]), P[f"{pre}.initial_embed.bias"], mv(e), R, CE, CS)
+    P1 = empty((R, EH), dev); Q1 = empty((R, EH), dev)
+    ops.linear(mv(e), (W1, CZ, EH), None, mv(P1), R, EH, CE)
+    ops.linear(mv(e), (W1, CZ + CE, EH), P[f"{pre}.trunk.0.bias"], mv(Q1), R, EH, CE)
+    h1 = empty((Pn, EH), dev)
+    ops.linear(mv(z), (W1, 0, EH), None, mv(h1), Pn, EH, CZ, relu=True, pair=(P1, Q1, EH, N))
+    h2 = empty((Pn, EH), dev)
+    ops.linear(mv(h1), mv(P[f"{pre}.trunk.2.weight"]), P[f"{pre}.trunk.2.bias"], mv(h2), Pn, EH, EH, relu=True)
+    Pf = empty((R, CZ), dev); Qf = empty((R, CZ), dev)
+    ops.linear(mv(e), (Wf, CZ, EH), None, mv(Pf), R, CZ, CE)
+    ops.linear(mv(e), (Wf, CZ + CE, EH), P[f"{pre}.final_layer.bias"], mv(Qf), R, CZ, CE)
+    y = empty((Pn, CZ), dev)
+    ops.linear(mv(h2), mv(Wf), None, mv(y), Pn, CZ, EH)
+    ops.linear(mv(z), (Wf, 0, EH), None, mv(y), Pn, CZ, CZ, pair=(Pf, Qf, CZ, N), beta=True)
+    z2 = empty((Pn, CZ), dev); mean = empty((Pn,), dev); rstd = empty((Pn,), dev)
+    ops.layernorm(mv(y), P[f"{pre}.layer_norm.weight"], P[f"{pre}.layer_norm.bias"], mv(z2), Pn, CZ, rowscale=emask,
+                  save=(mean, rstd))
+    return z2, dict(n3=n3, z=z, e=e, h1=h1, h2=h2, y=y, mean=mean, rstd=rstd, emask=emask, B=B, N=N)
+
+
+def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
+    """dz2 [P,128] -> dz [P,128] (=), dn3 (+=)."""
+    pre = f"score_model.trunk.edge_transition_{b}"
+    B, N = sv["B"], sv["N"]
+    R, Pn = B * N, B * N * N
+    dev = dz2
+    L = lib()
+    W1, W2, Wf = P[f"{pre}.trunk.0.weight"], P[f"{pre}.trunk.2.weight"], P[f"{pre}.final_layer.weight"]
+    z, e, h1, h2 = sv["z"], sv["e"], sv["h1"], sv["h2"]
+    dy = empty((Pn, CZ), dev)
+    ops.layernorm_bwd(mv(dz2), mv(sv["y"]), P[f"{pre}.layer_norm.weight"], sv["mean"], sv["rstd"], mv(dy), Pn, CZ,
+                      rowscale=sv["emask"], dgamma=G[f"{pre}.layer_norm.weight"], dbeta=G[f"{pre}.layer_norm.bias"])
+    # y = Wf h2 + Wf[:, :128] z + Pf_i + Qf_j (+bf inside Qf)
+    gWf = G[f"{pre}.final_layer.weight"]
+    ops.linear_dw(mv(dy), mv(h2), mv(gWf), Pn, CZ, EH)
+    ops.linear_dw(mv(dy), mv(z), (gWf, 0, EH), Pn, CZ, CZ)
+    dPf = zeros((R, CZ), dev); dQf = zeros((R, CZ), dev)
+    L.call("fd_pair_reduce_acc", dy, B, N, CZ, dPf, dQf, CZ)
+    ops.linear_dw(mv(dPf), mv(e), (gWf, CZ, EH), R, CZ, CE)
+    ops.linear_dw(mv(dQf), mv(e), (gWf, CZ + CE, EH), R, CZ, CE)
+    ops.bias_grad(mv(dQf), G[f"{pre}.final_layer.bias"], R, CZ)
+    de = empty((R, CE), dev)
+    ops.linear_dx(mv(dPf), (Wf, CZ, EH), mv(de), R, CZ, CE)
+    ops.linear_dx(mv(dQf), (Wf, CZ + CE, EH), mv(de), R, CZ, CE, beta=True)
+    ops.linear_dx(mv(dy), (Wf, 0, EH), mv(dz), Pn, CZ, CZ)                     # dz = dy Wf_z
+    dh2 = empty((Pn, EH), dev)
+    ops.linear_dx(mv(dy), mv(Wf), mv(dh2), Pn, CZ, EH, gate=mv(h2))
+    _lin_grads(G, f"{pre}.trunk.2.weight", f"{pre}.trunk.2.bias", mv(dh2), mv(h1), Pn, EH, EH)
+    dh1 = empty((Pn, EH), dev)
+    ops.linear_dx(mv(dh2), mv(W2), mv(dh1), Pn, EH, EH, gate=mv(h1))
+    del dh2
+    gW1 = G[f"{pre}.trunk.0.weight"]
+    ops.linear_dw(mv(dh1), mv(z), (gW1, 0, EH), Pn, EH, CZ)
+    dP1 = zeros((R, EH), dev); dQ1 = zeros((R, EH), dev)
+    L.call("fd_pair_reduce_acc", dh1, B, N, EH, dP1, dQ1, EH)
+    ops.linear_dw(mv(dP1), mv(e), (gW1, CZ, EH), R, EH, CE)
+    ops.linear_dw(mv(dQ1), mv(e), (gW1, CZ + CE, EH), R, EH, CE)
+    ops.bias_grad(mv(dQ1), G[f"{pre}.trunk.0.bias"], R, EH)
+    ops.linear_dx(mv(dP1), (W1, CZ, EH), mv(de), R, EH, CE, beta=True)
+    ops.linear_dx(mv(dQ1), (W1, CZ + CE, EH), mv(de), R, EH, CE, beta=True)
+    ops.linear_dx(mv(dh1), (W1, 0, EH), mv(dz), Pn, EH, CZ, beta=True)          # dz += dh1 W1_z
+    _lin_grads(G, f"{pre}.initial_embed.weight", f"{pre}.initial_embed.bias", mv(de), mv(sv["n3"]), R, CE, CS)
+    ops.linear_dx(mv(de), mv(P[f"{pre}.initial_embed.weight"]), mv(dn3), R, CE, CS, beta=True)
+
+
+# --------------------------------------------------------------------------- heads
+_HC = {}
+
+
+def head_const(conf_key=(0.1, 0.1, 20.0, 0.1, 1.5, 1000)):
+    """FdHeadConst from the reference constants (residue_constants.py:127-133, 769-781, 819-824)."""
+    if conf_key not in _HC:
+        cs, min_b, max_b, min_s, max_s, L = conf_key
+        n = np.array([-0.525, 1.363, 0.000]); ca = np.zeros(3); c = np.array([1.526, -0.000, -0.000])
+        cb = np.array([-0.529, -0.774, -1.205]); o = np.array([0.627, 1.062, 0.000])
+        ex = c - ca
+        ey = ca - n
+        exn = ex / np.linalg.norm(ex)
+        eyn = ey - np.dot(ey, exn) * exn
+        eyn = eyn / np.linalg.norm(eyn)
+        ez = np.cross(exn, eyn)
+        Rd = np.stack([exn, eyn, ez], 1)
+        hc = hip.FdHeadConst()
+        for i, v in enumerate(np.concatenate([n, ca, c, cb, o]).astype(np.float32)):
+            hc.atoms[i] = float(v)
+        for i, v in enumerate(Rd.astype(np.float32).reshape(-1)):
+            hc.Rd[i] = float(v)
+        for i, v in enumerate(c.astype(np.float32)):
+            hc.td[i] = float(v)
+        hc.coord_scale = cs
+        hc.exp_max_sigma = float(np.exp(max_s))
+        hc.exp_min_sigma = float(np.exp(min_s))
+        hc.min_b, hc.max_b, hc.L = min_b, max_b, L
+        _HC[conf_key] = hc
+    return _HC[conf_key]
+
+
+_SG = {}
+
+
+def sigma_grid(device, min_sigma=0.1, max_sigma=1.5, num_sigma=1000):
+    """so3_diffuser.py:182-186 discrete_sigma (float64, numpy op sequence) on the device."""
+    key = (str(device), min_sigma, max_sigma, num_sigma)
+    if key not in _SG:
+        t = np.linspace(0.0, 1.0, num_sigma)
+        g = np.log(t * np.exp(max_sigma) + (1 - t) * np.exp(min_sigma))
+        _SG[key] = torch.tensor(g, dtype=torch.float64, device=device)
+    return _SG[key]
+
+
+def heads_fwd(P, node, quat, trans, feats, B, N, dconf):
+    """Score heads, psi head, backbone atoms (ipa_pytorch.py:650-672, score_network.py:199-214)."""
+    tp = "score_model.torsion_pred"
+    dev = node
+    R = B * N
+    h1 = empty((R, CS), dev); h2 = empty((R, CS), dev); u = empty((R, 2), dev)
+    ops.linear(mv(node), mv(P[f"{tp}.linear_1.weight"]), P[f"{tp}.linear_1.bias"], mv(h1), R, CS, CS, relu=True)
+    ops.linear(mv(h1), mv(P[f"{tp}.linear_2.weight"]), P[f"{tp}.linear_2.bias"], mv(h2), R, CS, CS, resid=mv(node))
+    ops.linear(mv(h2), mv(P[f"{tp}.linear_final.weight"]), P[f"{tp}.linear_final.bias"], mv(u), R, 2, CS)
+    hc = head_const(dconf)
+    sg = sigma_grid(dev.device, dconf[3], dconf[4], 1000)
+    rot = empty((B, N, 3), dev, torch.float64); ts = empty((B, N, 3), dev); rig = empty((B, N, 7), dev)
+    psi = empty((B, N, 2), dev); a37 = empty((B, N, 37, 3), dev); a14 = empty((B, N, 14, 3), dev)
+    gt = feats["torsion_angles_sin_cos"]
+    tt = feats["t"].float().contiguous()
+    lib().call("fd_heads_fwd", feats["rigids_t"], quat, trans, u, (gt, 4), 14, feats["fixed_mask"], feats["res_mask"],
+               tt, sg, sg.numel(), hc, rot, ts, rig, psi, a37, a14, B, N)
+    out = dict(psi=psi, rot_score=rot, trans_score=ts, rigids=rig, atom37=a37, atom14=a14)
+    return out, dict(node=node, h1=h1, h2=h2, u=u, quat=quat, trans=trans, psi=psi, t=tt, hc=hc, sg=sg, B=B, N=N)
+
+
+def heads_bwd(P, G, sv, feats, d_out, dnode):
+    """d_out: dict of optional grads for psi/rot_score/trans_score/rigids/atom37.  Returns (dquat, dtrans)
+    of the final frame; accumulates dnode (+=)."""
+    tp = "score_model.torsion_pred"
+    B, N = sv["B"], sv["N"]
+    R = B * N
+    dev = sv["node"]
+    dq = empty((R, 4), dev); dt = empty((R, 3), dev); du = empty((R, 2), dev)
+
+    def g(k, dtype=torch.float32):
+        v = d_out.get(k)
+        return None if v is None else v.to(dtype).contiguous()
+
+    lib().call("fd_heads_bwd", feats["rigids_t"], sv["quat"], sv["trans"], sv["u"], sv["psi"], feats["fixed_mask"],
+               feats["res_mask"], sv["t"], sv["sg"], sv["sg"].numel(), sv["hc"], g("rot_score", torch.float64),
+               g("trans_score"), g("rigids"), g("psi"), g("atom37"), dq, dt, du, B, N)
+    _lin_grads(G, f"{tp}.linear_final.weight", f"{tp}.linear_final.bias", mv(du), mv(sv["h2"]), R, 2, CS)
+    dh2 = empty((R, CS), dev)
+    ops.linear_dx(mv(du), mv(P[f"{tp}.linear_final.weight"]), mv(dh2), R, 2, CS)
+    ops.add_view(mv(dnode), mv(dh2), R, CS)                                   # residual branch
+    _lin_grads(G, f"{tp}.linear_2.weight", f"{tp}.linear_2.bias", mv(dh2), mv(sv["h1"]), R, CS, CS)
+    dh1 = empty((R, CS), dev)
+    ops.linear_dx(mv(dh2), mv(P[f"{tp}.linear_2.weight"]), mv(dh1), R, CS, CS, gate=mv(sv["h1"]))
+    _lin_grads(G, f"{tp}.linear_1.weight", f"{tp}.linear_1.bias", mv(dh1), mv(sv["node"]), R, CS, CS)
+    ops.linear_dx(mv(dh1), mv(P[f"{tp}.linear_1.weight"]), mv(dnode), R, CS, CS, beta=True)
+    return dq, dt
+
+
+# --------------------------------------------------------------------------- whole network
+def _prep_feats(feats):
+    """Cast / lay out the reference input dict (score_network.py:183-193) for the kernels."""
+    f = {}
+    f["res_mask"] = feats["res_mask"].to(torch.float32).contiguous()
+    f["fixed_mask"] = feats["fixed_mask"].to(torch.float32).contiguous()
+    f["seq_idx"] = feats["seq_idx"].to(torch.int64).contiguous()
+    f["t"] = feats["t"].contiguous()
+    f["sc_ca_t"] = feats["sc_ca_t"].to(torch.float32).contiguous()
+    f["rigids_t"] = feats["rigids_t"].to(torch.float32).contiguous()
+    f["torsion_angles_sin_cos"] = feats["torsion_angles_sin_cos"].to(torch.float32).contiguous()
+    return f
+
+
+def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_bool_mask=False, save=True):
+    """ScoreNetwork.forward.  Returns (outputs, saved-for-backward or None)."""
+    f = _prep_feats(feats)
+    B, N = f["res_mask"].shape
+    R = B * N
+    L = lib()
+    mask = f["res_mask"]
+    dev = mask
+    node0, z, sv_embed = nw.embed_fwd(P, f, B, N)
+    emask = sv_embed["emask"]
+    dmask = empty((B, N), dev)
+    L.call("fd_rowscale", (1 - f["fixed_mask"]).contiguous(), 1, mask.reshape(-1), dmask, 1, R, 1)
+    rig = f["rigids_t"]
+    quat = rig[..., :4].contiguous().view(R, 4)
+    trans = (rig[..., 4:] * dconf[0]).contiguous().view(R, 3)                  # scale_rigids (A -> nm)
+    init_node = node0                                                          # already masked (LN rowscale)
+    node = node0
+    if tfmr_bool_mask:
+        key_add = torch.where(mask > 0, torch.zeros_like(mask), torch.full_like(mask, float("-inf")))
+    else:
+        key_add = (1 - mask).contiguous()
+    stages = []
+    for b in range(num_blocks):
+        pre = f"score_model.trunk.ipa_{b}"
+        x1, sv_ipa = nw.ipa_fwd(P, pre, mv(node), z, quat, trans, mask.view(-1), B, N)
+        u, sv_ln = nw.ln_skip_fwd(P, b, x1, init_node, R)
+        u0 = u
+        sv_t = []
+        for l in range(2):
+            u, s_ = nw.tfmr_layer_fwd(P, f"score_model.trunk.seq_tfmr_{b}.layers.{l}", u, key_add, B, N)
+            sv_t.append(s_)
+        if tfmr_bool_mask:
+            u2 = empty((R, TD), dev)
+            L.call("fd_rowscale", u, TD, mask.view(-1), u2, TD, R, TD)
+            u = u2
+        n3, sv_pn = nw.post_node_fwd(P, b, u, u0, mask.view(-1), R)
+        q2, t2, sv_bb = bb_update_fwd(P, b, n3, dmask.view(-1), quat, trans, R)
+        sv_et = None
+        if b < num_blocks - 1:
+            z, sv_et = edge_transition_fwd(P, b, n3, z, emask, B, N)
+        stages.append(dict(ipa=sv_ipa, ln=sv_ln, tfmr=sv_t, pn=sv_pn, bb=sv_bb, et=sv_et))
+        node, quat, trans = n3, q2, t2
+        if not save:
+            stages[-1] = None
+    out, sv_h = heads_fwd(P, node, quat, trans, f, B, N, dconf)
+    if not save:
+        return out, None
+    return out, dict(feats=f, embed=sv_embed, stages=stages, heads=sv_h, B=B, N=N, num_blocks=num_blocks,
+                     bool_mask=tfmr_bool_mask, mask=mask, dmask=dmask)
+
+
+def _const(dev, n, v):
+    return torch.full((n,), v, device=dev.device)
+
+
+def backward(P, G, sv, d_out):
+    """Gradients of sum_k <d_out[k], out[k]> w.r.t. every parameter, accumulated into G."""
+    B, N, nb = sv["B"], sv["N"], sv["num_blocks"]
+    R, Pn = B * N, B * N * N
+    f = sv["feats"]
+    dev = sv["mask"]
+    if sv["bool_mask"]:
+        raise NotImplementedError("backward is defined for the training-mode (additive) transformer mask")
+    dnode = zeros((R, CS), dev)
+    dq, dt = heads_bwd(P, G, sv["heads"], f, d_out, dnode)
+    dinit = zeros((R, CS), dev)
+    dz = None
+    for b in reversed(range(nb)):
+        st = sv["stages"][b]
+        dn3 = dnode
+        dz_in = None
+        if st["et"] is not None:
+            dz_in = empty((Pn, CZ), dev)
+            edge_transition_bwd(P, G, b, st["et"], dz, dz_in, dn3)
+        dframe = zeros((R, 12), dev)
+        # IPA backward needs dx1, which needs dn3 complete (incl. bb_update's contribution), but bb_update's
+        # input-frame gradient needs the IPA's dframe: split bb_update in two steps via a zero dframe first.
+        dq_in, dt_in = bb_update_bwd(P, G, b, st["bb"], dq, dt, None, dn3)
+        du0 = zeros((R, TD), dev)
+        du2 = nw.post_node_bwd(P, G, b, st["pn"], dn3, du0)
+        du = du2
+        for l in reversed(range(2)):
+            du = nw.tfmr_layer_bwd(P, G, f"score_model.trunk.seq_tfmr_{b}.layers.{l}", st["tfmr"][l], du)
+        ops.add_view(mv(du0), mv(du), R, TD)
+        dx1 = empty((R, CS), dev)
+        nw.ln_skip_bwd(P, G, b, st["ln"], du0, dx1, dinit)
+        ds = zeros((R, CS), dev)
+        if dz_in is None:
+            dz_in = zeros((Pn, CZ), dev)
+        nw.ipa_bwd(P, G, f"score_model.trunk.ipa_{b}", st["ipa"], dx1, mv(ds), dz_in, dframe)
+        # fold the IPA frame gradients (dL/dR, dL/dt of the block's input frame) into (dq, dt)
+        _frame_grad_fold(st["bb"]["quat"], dframe, dq_in, dt_in, R)
+        dq, dt, dnode, dz = dq_in, dt_in, ds, dz_in
+    # node = init_node at block 0 input; both carry gradient into the node embedder
+    ops.add_view(mv(dnode), mv(dinit), R, CS)
+    nw.embed_bwd(P, G, sv["embed"], dnode, dz)
+
+
+def _frame_grad_fold(quat, dframe, dq, dt, R):
+    """dq += d(dL/dR)/dq, dt += dL/dt, via fd_bb_update_bwd with zero upstream (identity update)."""
+    dev = quat
+    z4 = zeros((R, 4), dev); z3 = zeros((R, 3), dev); z6 = zeros((R, 6), dev); zm = zeros((R,), dev)
+    dq2 = empty((R, 4), dev); dt2 = empty((R, 3), dev); j1 = empty((R, 6), dev); j2 = empty((R, 6), dev)
+    # with dmask = 0, upd = 0 and zero upstream grads the kernel returns exactly the dframe contribution
+    lib().call("fd_bb_update_bwd", z4, z3, dframe, zm, z6, quat, dq2, dt2, j1, j2, R)
+    ops.add_view(mv(dq), mv(dq2), R, 4)
+    ops.add_view(mv(dt), mv(dt2), R, 3)

@@ -30,10 +30,9 @@ def _run(lib, dev, M, N, K, a_kc, b_kc, tile, epi=False, seed=0):
         resid = torch.randn(M, N, generator=g)
         gate = torch.randn(M, N, generator=g)
         rows = torch.rand(M, generator=g)
-        ref = ref + bias.double() + resid.double()
-        ref = torch.clamp(ref, min=0)
+        ref = torch.clamp(ref + bias.double(), min=0)
         ref = torch.where(gate > 0, ref, torch.zeros_like(ref)) * rows.double()[:, None]
-        ref = ref + 7.0
+        ref = ref + resid.double() + 7.0
         kw = dict(bias=bias.to(dev), resid=resid.to(dev), ld_resid=N, gate=gate.to(dev), ld_gate=N,
                   rowscale=rows.to(dev), relu=True, beta=True)
     At, Bt, C = At.to(dev), Bt.to(dev), C.to(dev)
