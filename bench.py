@@ -1,0 +1,169 @@
+"""Benchmark of the FrameDiff hot path on MI355X (contract: see the task statement / DESIGN.md).
+
+Workload at N GPUs (weak scaling): every rank runs the BASELINE.json configs[1] training step --
+config/base.yaml full depth (4 IPA blocks), one batch of B=30 backbones of N=128 residues
+(B = floor(5e5 / N^2), data/utils.py:395) -- forward + DSM loss + backward + flat-gradient RCCL
+all-reduce + Adam.  value = residues/s over all ranks, inputs resident in HBM.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One JSON line on stdout (rank 0).  `roofline` = the dominant kernel (128x128 fp32-MFMA fd_gemm),
+timed with HIP events on its own stream inside the timed region; `cpu_baseline` = the oracle
+(CPU port of the reference, oracle/framediff_oracle.py) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-res", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=0, help="0 = floor(5e5/N^2) as the reference's length_batching")
+    ap.add_argument("--blocks", type=int, default=4)
+    ap.add_argument("--mode", default="train", choices=["train", "forward"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(n_res, blocks, sample_b, steps=2):
+    """The oracle (CPU port) on a bounded sample: fwd + loss + bwd of `sample_b` backbones."""
+    from oracle import framediff_oracle as fo
+    from se3_diffusion_amd import train_step as ts
+    cores = max(1, (os.cpu_count() or 2) // 2)
+    torch.set_num_threads(cores)
+    conf = dict(fo.CONF, num_blocks=blocks)
+    P = {k: v.requires_grad_(True) for k, v in fo.synth_params(seed=0, conf=conf).items()}
+    batch = ts.synthetic_batch(sample_b, n_res, "cpu", seed=0)
+    gt37, _ = fo.backbone_atoms(batch["rigids_0"][..., :4], batch["rigids_0"][..., 4:],
+                                batch["torsion_angles_sin_cos"][..., 2, :])
+
+    def step():
+        out = fo.score_network_forward(P, batch, conf)
+        loss = ts.dsm_loss(batch, out, gt37)
+        loss.backward()
+        for p in P.values():
+            p.grad = None
+
+    step()
+    t0 = time.time()
+    for _ in range(steps):
+        step()
+    dt = (time.time() - t0) / steps
+    return dict(value=round(sample_b * n_res / dt, 2), unit="residues/s", cores=cores, kind="port",
+                sample=f"{steps} steps of fwd+DSM loss+bwd, B={sample_b} x N={n_res}, {blocks} blocks, "
+                       f"torch-CPU fp32 oracle, {cores} threads, {dt:.2f} s/step")
+
+
+def main():
+    a = parse()
+    from se3_diffusion_amd import dist as fdist
+    rank, world, local = fdist.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs an AMD GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from se3_diffusion_amd import hip, train_step as ts
+    from se3_diffusion_amd.model.score_network import ScoreNetwork
+    lib = hip.get_lib()
+
+    N = a.n_res
+    B = a.batch if a.batch > 0 else max(1, 500000 // (N * N))
+    torch.manual_seed(0)
+    model = ScoreNetwork(ts.base_model_conf(a.blocks), diffuser=None).to(dev)
+    ts.perturb_final_layers(model, seed=0)
+    fdist.broadcast_params(model)
+    model.train()
+    batch = ts.synthetic_batch(B, N, dev, seed=100 + rank)
+    gt37, _ = ts.backbone_atoms(batch["rigids_0"], batch["torsion_angles_sin_cos"][..., 2, :])
+    grads = fdist.FlatGrads(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+    def step():
+        if a.mode == "forward":
+            with torch.no_grad():
+                model(batch)
+            return
+        grads.zero()
+        out = model(batch)
+        loss = ts.dsm_loss(batch, out, gt37)
+        loss.backward()
+        grads.all_reduce_mean()
+        opt.step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    lib.gemm_profile = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, lib.gemm_profile = lib.gemm_profile, None
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank != 0:
+        return
+    # dominant kernel: gemm_kernel<128,128,2,2,*,*> (tile 1)
+    by = {}
+    for tile, akc, bkc, flops, e0, e1 in prof:
+        k = (tile, akc, bkc)
+        s = by.setdefault(k, [0.0, 0.0, 0])
+        s[0] += flops
+        s[1] += e0.elapsed_time(e1) * 1e-3
+        s[2] += 1
+    tot_t = sum(v[1] for v in by.values())
+    dom = [v for k, v in by.items() if k[0] == 1]
+    dflops, dtime, dn = (sum(v[0] for v in dom), sum(v[1] for v in dom), sum(v[2] for v in dom)) if dom else (0, 1e-9, 0)
+    all_flops = sum(v[0] for v in by.values())
+    achieved = dflops / dtime / 1e12
+    ms = dt / a.steps * 1e3
+    res = {
+        "metric": "residues/sec IPA fwd+bwd" if a.mode == "train" else "residues/sec IPA fwd",
+        "value": round(world * B * N * a.steps / dt, 1), "unit": "residues/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"config/base.yaml ScoreNetwork ({a.blocks} IPA blocks, 17.4M params), per-GPU batch "
+                               f"B={B} x N={N} residues, {'fwd + DSM loss + bwd + RCCL grad all-reduce + Adam' if a.mode == 'train' else 'forward only'}",
+                   "parallelism": f"dp{world}", "global_batch": world * B, "n_res": N},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s",
+                     "frac": round(achieved / 157.3, 4), "traffic": None,
+                     "kernel": "gemm_kernel<128,128,2,2,*,*> (fp32 v_mfma_f32_32x32x2_f32)",
+                     "launches_per_step": dn // max(1, a.steps),
+                     "avg_launch_us": round(dtime / max(1, dn) * 1e6, 2),
+                     "algorithmic_flops_per_launch": round(dflops / max(1, dn), 1),
+                     "gemm_time_frac_of_step": round(tot_t / dt, 4),
+                     "all_gemm_tflops": round(all_flops / max(tot_t, 1e-9) / 1e12, 2),
+                     "step_model_tflops": round(all_flops / dt / 1e12, 2)},
+    }
+    if not a.no_cpu_baseline and world == 1:
+        try:
+            res["cpu_baseline"] = cpu_baseline(N, a.blocks, a.cpu_sample_batch)
+        except Exception as e:  # noqa: BLE001 -- the baseline must not lose the GPU measurement
+            res["cpu_baseline"] = {"value": None, "error": repr(e)}
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -138,6 +138,9 @@ int fd_heads_fwd(const float* rig0, const float* quatF, const float* transF, con
                  const float* gt_psi, long gt_stride, const float* fixed, const float* mask, const float* t,
                  const double* sigma_grid, int ng, const FdHeadConst* c, double* rot_score, float* trans_score,
                  float* rigids, float* psi_out, float* atom37, float* atom14, int B, int N, void* stream);
+/* data/all_atom.py:152-174 compute_backbone as one kernel: rigids [R,7] (A), psi [R,2] (sin,cos) */
+int fd_backbone_atoms(const float* rigids, const float* psi, const FdHeadConst* c, float* atom37, float* atom14,
+                      long R, void* stream);
 int fd_heads_bwd(const float* rig0, const float* quatF, const float* transF, const float* upsi,
                  const float* psi_out, const float* fixed, const float* mask, const float* t,
                  const double* sigma_grid, int ng, const FdHeadConst* c, const double* d_rot,

@@ -1,0 +1,67 @@
+"""Data-parallel gradient exchange for the FrameDiff training step.
+
+The path shards by whole backbones: every rank holds a full 69.8 MB fp32 replica and the
+ONLY exchange step is one gradient all-reduce per step.  Instead of DDP's many ~25 MB
+buckets (reference train_se3_diffusion.py:273-277, find_unused_parameters=True) all
+parameter gradients live in ONE flat fp32 buffer (param.grad are views into it), so the
+step issues a single RCCL all-reduce sized for xGMI (one 70 MB message; per-link bound
+0.1-0.8 ms << the >= 25 ms step) and never touches unused-parameter bookkeeping: the two
+parameters that never receive gradient (linear_rbf, torsion_pred.linear_3) simply
+contribute zeros.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class FlatGrads:
+    """Flat gradient buffer + one all-reduce (mean) per step."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+
+
+def broadcast_params(module, src=0):
+    """Replicate rank-`src` parameters and buffers (what DDP does at wrap time)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src)
+
+
+def shard_indices(n_items, rank, world):
+    """Backbone i goes to rank i % world (reference DistributedTrainSampler: indices[rank::world])."""
+    return list(range(rank, n_items, world))

@@ -91,6 +91,7 @@ _SIGS = {
     "fd_bb_update_bwd": "pppppppppp" + "ls",
     "fd_heads_fwd": "pppp" + "pl" + "ppp" + "pi" + "S" + "pppppp" + "iis",
     "fd_heads_bwd": "ppppp" + "ppp" + "pi" + "S" + "ppppp" + "ppp" + "iis",
+    "fd_backbone_atoms": "ppSppls",
 }
 # exact argument lists, kept next to the header for the symbol-export test
 _CT = {"p": c_void_p, "i": c_int, "l": c_long, "f": c_float, "S": c_void_p, "s": c_void_p}
@@ -186,7 +187,29 @@ class FdLib:
         for x in (bias, resid, gate, rowscale):
             if x is not None:
                 tens.append(x[0] if isinstance(x, tuple) else x)
-        self._check(self.cdll.fd_gemm(ctypes.byref(d), self._stream(tens)), "fd_gemm")
+        if d.tile == 0:
+            d.tile = auto_tile(d.M, d.N, max(1, batch))
+        stream = self._stream(tens)
+        prof = self.gemm_profile
+        if prof is not None and self.is_device:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._check(self.cdll.fd_gemm(ctypes.byref(d), stream), "fd_gemm")
+            e1.record()
+            prof.append((d.tile, d.a_cs == 1, d.b_rs == 1, 2.0 * d.M * d.N * d.K * max(1, batch), e0, e1))
+            return
+        self._check(self.cdll.fd_gemm(ctypes.byref(d), stream), "fd_gemm")
+
+    gemm_profile = None  # set to a list to record (tile, a_kc, b_kc, flops, ev0, ev1) per fd_gemm launch
+
+
+def auto_tile(M, N, batch):
+    """Same selection rule as fd_gemm (csrc/fd_gemm.hip): 1 = 128x128, 2 = 64x64, 3 = 128x32."""
+    if N <= 48:
+        return 3
+    blocks128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
+    return 1 if (blocks128 >= 512 and N >= 96) else 2
 
 
 _PRODUCT: FdLib | None = None
