@@ -147,6 +147,25 @@ int fd_heads_bwd(const float* rig0, const float* quatF, const float* transF, con
                  const float* d_trans_score, const float* d_rigids, const float* d_psi, const float* d_atom37,
                  float* dquatF, float* dtransF, float* dupsi, int B, int N, void* stream);
 
+/* ---- SE(3) diffuser (fp64 arithmetic, fp32 [..,7] frames in Angstrom) ----------------
+ * Random draws are inputs in the reference's call order, so identical noise gives identical frames.
+ * fd_igso3_tables     data/so3_diffuser.py:122-180   pdf/cdf/score_norms [ns, no] (8 MB each at 1000^2)
+ * fd_sample_ref       data/se3_diffuser.py:216-268   prior: IGSO3(t=1) x N(0, I) (scaled units -> A)
+ * fd_forward_marginal data/se3_diffuser.py:43-110    noised frames + DSM score targets at time t
+ * fd_se3_reverse_step data/se3_diffuser.py:160-214   one Euler-Maruyama / geodesic-random-walk step */
+int fd_igso3_tables(const double* sigma, const double* omega, int ns, int no, int L, double* pdf, double* cdf,
+                    double* score_norms, void* stream);
+int fd_sample_ref(const double* z_axis, const double* u, const double* z_trans, const double* cdf_row,
+                  const double* omega, int no, double coord_scale, float* out, long n, void* stream);
+int fd_forward_marginal(const float* rig0, const double* z_axis, const double* u, const double* z_trans,
+                        const double* cdf_row, const double* omega, int no, double sigma, double beta,
+                        double coord_scale, int L, const float* mask, float* rig_t, double* rot_score,
+                        double* trans_score, long n, void* stream);
+int fd_se3_reverse_step(const float* rig_t, const double* rot_score, const double* trans_score,
+                        const double* z_rot, const double* z_trans, const float* mask, int B, int N, double g_rot,
+                        double b_t, double dt, double noise_scale, double coord_scale, int center, int diffuse_rot,
+                        int diffuse_trans, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

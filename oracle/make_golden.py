@@ -218,6 +218,49 @@ def main():
     print("backbone_atoms", report["backbone_atoms"], flush=True)
     np.savez_compressed(os.path.join(GOLD, "diffuser.npz"), **d)
 
+    # ---------------- short reverse-diffusion trajectory (the loop of Experiment.inference_fn,
+    # train_se3_diffusion.py:746-781, driven with the reference model + reference diffuser) ----------------
+    import copy
+    tconf = rl.base_conf(CACHE, num_blocks=2).model
+    torch.manual_seed(0)
+    tmodel = score_network.ScoreNetwork(tconf, diff)
+    tmodel.load_state_dict(fo.synth_params(seed=21, conf=dict(fo.CONF, num_blocks=2)), strict=True)
+    tmodel.eval()
+    Bt, Nt, num_t, min_t, ns_ = 2, 10, 6, 0.01, 0.1
+    np.random.seed(2024)
+    zr = np.random.randn(Bt * Nt, 3); ur = np.random.rand(Bt * Nt); zt = np.random.normal(size=(Bt * Nt, 3))
+    np.random.seed(2024)
+    rig_init = diff.sample_ref(n_samples=Bt * Nt, as_tensor_7=True)["rigids_t"].reshape(Bt, Nt, 7)
+    feats_t = dict(res_mask=torch.ones(Bt, Nt), fixed_mask=torch.zeros(Bt, Nt),
+                   seq_idx=torch.arange(1, Nt + 1)[None].repeat(Bt, 1), torsion_angles_sin_cos=torch.zeros(Bt, Nt, 7, 2),
+                   sc_ca_t=torch.zeros(Bt, Nt, 3), rigids_t=rig_init.clone(), t=torch.ones(Bt))
+    steps = np.linspace(min_t, 1.0, num_t)[::-1]
+    noises = []
+    with torch.no_grad():
+        feats_t["t"] = steps[0] * torch.ones(Bt)
+        feats_t["sc_ca_t"] = tmodel(feats_t)["rigids"][..., 4:]
+        for t_ in steps:
+            if t_ > min_t:
+                feats_t["t"] = t_ * torch.ones(Bt)
+                mo = tmodel(feats_t)
+                feats_t["sc_ca_t"] = mo["rigids"][..., 4:]
+                st = np.random.get_state()
+                z1 = np.random.normal(size=(Bt, Nt, 3)); z2 = np.random.normal(size=(Bt, Nt, 3))
+                np.random.set_state(st)
+                noises.append((z1, z2))
+                rg = diff.reverse(rigid_t=ru.Rigid.from_tensor_7(feats_t["rigids_t"]), rot_score=du.move_to_np(mo["rot_score"]),
+                                  trans_score=du.move_to_np(mo["trans_score"]), diffuse_mask=np.ones((Bt, Nt)), t=t_, dt=1 / num_t,
+                                  center=True, noise_scale=ns_)
+            else:
+                mo = tmodel(feats_t)
+                rg = ru.Rigid.from_tensor_7(mo["rigids"])
+            feats_t["rigids_t"] = rg.to_tensor_7()
+    np.savez_compressed(os.path.join(GOLD, "traj.npz"), B=Bt, N=Nt, num_t=num_t, min_t=min_t, noise_scale=ns_, seed=21,
+                        blocks=2, init_randn=zr, init_rand=ur, init_normal=zt, rig_init=rig_init.numpy(),
+                        z_rot=np.stack([n[0] for n in noises]), z_trans=np.stack([n[1] for n in noises]),
+                        final_rigids=feats_t["rigids_t"].numpy(), final_psi=mo["psi"].numpy())
+    print("trajectory golden written", flush=True)
+
     with open(os.path.join(GOLD, "PINNING_REPORT.txt"), "w") as f:
         f.write("oracle/framediff_oracle.py vs the unmodified reference (max |a-b| / max |b|)\n")
         f.write(f"torch {torch.__version__} numpy {np.__version__}\n")

@@ -92,9 +92,13 @@ _SIGS = {
     "fd_heads_fwd": "pppp" + "pl" + "ppp" + "pi" + "S" + "pppppp" + "iis",
     "fd_heads_bwd": "ppppp" + "ppp" + "pi" + "S" + "ppppp" + "ppp" + "iis",
     "fd_backbone_atoms": "ppSppls",
+    "fd_igso3_tables": "ppiiippps",
+    "fd_sample_ref": "pppppidpls",
+    "fd_forward_marginal": "ppppppidddipppp" + "ls",
+    "fd_se3_reverse_step": "ppppppiidddddiiips",
 }
 # exact argument lists, kept next to the header for the symbol-export test
-_CT = {"p": c_void_p, "i": c_int, "l": c_long, "f": c_float, "S": c_void_p, "s": c_void_p}
+_CT = {"p": c_void_p, "i": c_int, "l": c_long, "f": c_float, "d": c_double, "S": c_void_p, "s": c_void_p}
 
 
 class FdLib:
@@ -151,7 +155,7 @@ class FdLib:
                 conv.append(_ptr(a))
             elif code == "S":
                 conv.append(ctypes.addressof(a))
-            elif code == "f":
+            elif code in "fd":
                 conv.append(float(a))
             else:
                 conv.append(int(a))

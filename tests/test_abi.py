@@ -1,0 +1,52 @@
+"""C-ABI surface: include/fd_hip.h <-> ctypes binding <-> the built gfx950 library.
+No compute calls (works without a GPU)."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from se3_diffusion_amd import hip  # noqa: E402
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "fd_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_binding_covers_header():
+    assert header_symbols() == hip.exported_symbols()
+
+
+def test_product_library_exports_every_symbol():
+    if not os.path.exists(hip.LIB_PATH):
+        from se3_diffusion_amd import build
+        build.build(verbose=False)
+    lib = hip.FdLib(hip.LIB_PATH)            # binds every symbol; AttributeError if one is missing
+    assert lib.backend == "gfx950"
+    assert lib.cdll.fd_abi_version() == 1
+    for s in header_symbols():
+        assert hasattr(lib.cdll, s)
+
+
+def test_no_cpu_fallback(emu_lib, tmp_path):
+    import torch
+    # a CPU tensor handed to the gfx950 build is an error, not a silent fallback
+    lib = hip.FdLib(hip.LIB_PATH)
+    with pytest.raises(hip.FdError):
+        lib.call("fd_axpby", torch.zeros(4), torch.zeros(4), 1.0, 1.0, 4)
+    # a missing library is an error
+    with pytest.raises(hip.FdError):
+        hip.FdLib(str(tmp_path / "nope.so"))
+    # the product loader only accepts the gfx950 backend
+    assert emu_lib.backend == "emu" and not emu_lib.is_device
+
+
+def test_error_reporting(emu_lib):
+    import torch
+    with pytest.raises(hip.FdError, match="multiple of 64"):
+        emu_lib.call("fd_layernorm_fwd", torch.zeros(2, 100), 100, torch.ones(100), torch.zeros(100), None,
+                     torch.zeros(2, 100), 100, None, None, 2, 100, 1e-5)

@@ -1,0 +1,205 @@
+"""SE(3) diffuser parity against tests/golden/diffuser.npz (outputs of the UNMODIFIED reference with
+its own numpy RNG stream, written by oracle/make_golden.py).
+
+Frames are compared as rotation matrices / quaternions up to sign.  Tolerances: fp64 arithmetic stored
+as fp32 frames -> 2e-6 absolute on unit quaternions / rotation matrices, 2e-5 A on translations;
+scores 1e-9 relative (float64 series) except where the reference evaluates in float32."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from se3_diffusion_amd.data import se3_diffuser, utils as du  # noqa: E402
+from se3_diffusion_amd.openfold.utils import rigid_utils as ru  # noqa: E402
+
+G = np.load(os.path.join(ROOT, "tests", "golden", "diffuser.npz"))
+CACHE = os.environ.get("FD_TEST_IGSO3_CACHE", "/tmp/fd_test_igso3_cache")
+
+
+def conf(cache=CACHE):
+    ns = SimpleNamespace
+    return ns(diffuse_trans=True, diffuse_rot=True, r3=ns(min_b=0.1, max_b=20.0, coordinate_scaling=0.1),
+              so3=ns(num_omega=1000, num_sigma=1000, min_sigma=0.1, max_sigma=1.5, schedule="logarithmic",
+                     cache_dir=cache, use_cached_score=False))
+
+
+@pytest.fixture(scope="module")
+def diff():
+    return se3_diffuser.SE3Diffuser(conf())
+
+
+def rotmats(t7):
+    return du.quat_wxyz_to_matrix(np.asarray(t7[..., :4], dtype=np.float64))
+
+
+def test_schedules_and_tables(diff):
+    so3, r3 = diff._so3_diffuser, diff._r3_diffuser
+    ts = G["ts"]
+    assert np.allclose([so3.sigma(t) for t in ts], G["sigma"], rtol=1e-14)
+    assert np.array_equal([so3.t_to_idx(t) for t in ts], G["t_to_idx"])
+    assert np.allclose([so3.diffusion_coef(t) for t in ts], G["g_rot"], rtol=1e-13)
+    assert np.allclose([r3.b_t(t) for t in ts], G["b_t"]) and np.allclose([r3.marginal_b_t(t) for t in ts], G["marginal_b_t"])
+    assert np.allclose([r3.score_scaling(t) for t in ts], G["trans_score_scaling"], rtol=1e-13)
+    rows, cols = G["tab_rows"], G["tab_cols"]
+    assert np.allclose(so3._pdf[np.ix_(rows, cols)], G["pdf_sample"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(so3._cdf[np.ix_(rows, cols)], G["cdf_sample"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(so3._score_norms[np.ix_(rows, cols)], G["score_norms_sample"], rtol=1e-8, atol=2e-7)
+    assert np.allclose(so3._cdf[499], G["cdf_row_499"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(so3._score_scaling[[0, 9, 499, 999]], G["score_scaling_table_sample"], rtol=1e-8)
+    assert np.allclose([so3.score_scaling(t) for t in ts], G["rot_score_scaling"], rtol=1e-8)
+    with pytest.raises(ValueError):
+        so3.sigma(np.array(1.5))
+    with pytest.raises(ValueError):
+        r3.b_t(np.array(-0.1))
+
+
+def test_torch_score_host(diff):
+    so3 = diff._so3_diffuser
+    sc = so3.torch_score(torch.tensor(G["ts_vec"]), torch.tensor(G["ts"], dtype=torch.float32)).numpy()
+    ref = G["ts_score"]
+    # the reference evaluates sin/cos((l+1/2) w) in float32: compare away from w -> 0 where that noise explodes
+    # ... and where the density is not negligible: for omega >> sigma the true f is ~0 and the reference's
+    # f'/(f + 1e-4) is float32 round-off of O(1) (a float64 evaluation gives ~0) -- see DESIGN.md "numerics".
+    from se3_diffusion_amd.data.so3_diffuser import _series
+    om = np.linalg.norm(G["ts_vec"], axis=-1)
+    sg = so3.discrete_sigma[so3.t_to_idx(G["ts"].astype(np.float32).astype(np.float64))][:, None]
+    f, _ = _series(om + 1e-6, sg)
+    ok = (om > 0.05) & (f > 1e-2)
+    assert ok.sum() >= 20
+    assert (np.abs(sc - ref)[ok] < 5e-4 * np.abs(ref)[ok].max(-1, keepdims=True) + 1e-6).all()
+    # calc_rot_score through Rotation objects (quaternion algebra in fp32)
+    out = diff.calc_rot_score(ru.Rotation(quats=torch.tensor(G["crs_qt"]), normalize_quats=False),
+                              ru.Rotation(quats=torch.tensor(G["crs_q0"]), normalize_quats=False),
+                              torch.tensor(G["ts"], dtype=torch.float32)).numpy()
+    # rows t >= 0.2 only: at t = 0.01 / 0.05 random relative rotations sit in the negligible-density regime above
+    assert np.abs(out - G["crs_out"])[2:].max() < 5e-4 * np.abs(G["crs_out"])[2:].max()
+    ts_out = diff.calc_trans_score(torch.tensor(G["cts_xt"]), torch.tensor(G["cts_x0"]),
+                                   torch.tensor(G["ts"], dtype=torch.float32)[:, None, None], use_torch=True).numpy()
+    assert np.allclose(ts_out, G["cts_out"], rtol=1e-5, atol=1e-6)
+
+
+def _check_reverse(out7, tag):
+    assert np.abs(rotmats(out7) - G[f"rev_{tag}_out_rotmats"]).max() < 3e-6
+    assert np.abs(np.asarray(out7[..., 4:]) - G[f"rev_{tag}_out_trans"]).max() < 3e-5
+
+
+def test_reverse_host_numpy_stream(diff):
+    """Same numpy seed as the reference -> same frames (rotation noise drawn first, then translation)."""
+    for tag in ("a", "b"):
+        np.random.seed(123)
+        out = diff.reverse(rigid_t=ru.Rigid.from_tensor_7(torch.tensor(G["rev_rigids"])), rot_score=G["rev_rot_score"],
+                           trans_score=G["rev_trans_score"], t=float(G[f"rev_{tag}_t"]), dt=1 / 100,
+                           diffuse_mask=G["rev_dmask"], center=True, noise_scale=float(G[f"rev_{tag}_ns"]))
+        _check_reverse(out.to_tensor_7().numpy(), tag)
+    with pytest.raises(ValueError):
+        diff.reverse(rigid_t=ru.Rigid.from_tensor_7(torch.tensor(G["rev_rigids"])), rot_score=G["rev_rot_score"],
+                     trans_score=G["rev_trans_score"], t=np.array([0.5, 0.5]), dt=0.01)
+
+
+def _reverse_kernel(diff, dev):
+    for tag in ("a", "b"):
+        out = diff.reverse_device(torch.tensor(G["rev_rigids"]).to(dev), G["rev_rot_score"], G["rev_trans_score"],
+                                  float(G[f"rev_{tag}_t"]), 1 / 100, diffuse_mask=G["rev_dmask"], center=True,
+                                  noise_scale=float(G[f"rev_{tag}_ns"]), noise=(G[f"rev_{tag}_zrot"], G[f"rev_{tag}_ztrans"]))
+        _check_reverse(out.cpu().numpy(), tag)
+
+
+def test_reverse_kernel_emu(diff, use_emu):
+    _reverse_kernel(diff, "cpu")
+
+
+def _check_sample_ref(t7):
+    ref = G["sr_out_t7"]
+    assert np.abs(rotmats(t7) - rotmats(ref)).max() < 3e-6
+    assert np.abs(np.asarray(t7[..., 4:]) - ref[..., 4:]).max() < 3e-5
+
+
+def test_sample_ref_host(diff):
+    np.random.seed(321)
+    _check_sample_ref(diff.sample_ref(n_samples=11, as_tensor_7=True)["rigids_t"].numpy())
+    with pytest.raises(ValueError):
+        diff.sample_ref(n_samples=4, diffuse_mask=np.ones(4))
+
+
+def test_sample_ref_kernel_emu(diff, use_emu):
+    t7 = diff.sample_ref_device(11, "cpu", noise=(G["sr_randn"], G["sr_rand"], G["sr_normal"]))
+    _check_sample_ref(t7.numpy())
+
+
+def _check_fm(out):
+    t7 = out["rigids_t"].cpu().numpy() if torch.is_tensor(out["rigids_t"]) else out["rigids_t"]
+    assert np.abs(rotmats(t7) - rotmats(G["fm_rigids_t"])).max() < 3e-6
+    assert np.abs(t7[..., 4:] - G["fm_rigids_t"][..., 4:]).max() < 3e-5
+    assert np.allclose(out["trans_score"], G["fm_trans_score"], rtol=1e-9, atol=1e-10)
+    assert np.allclose(out["rot_score"], G["fm_rot_score"], rtol=1e-7, atol=1e-9)
+    assert np.allclose(out["trans_score_scaling"], G["fm_trans_score_scaling"]) and np.allclose(out["rot_score_scaling"], G["fm_rot_score_scaling"], rtol=1e-8)
+
+
+def test_forward_marginal_host(diff):
+    np.random.seed(55)
+    _check_fm(diff.forward_marginal(ru.Rigid.from_tensor_7(torch.tensor(G["fm_rigids0"])), float(G["fm_t"])))
+
+
+def _fm_kernel(diff, dev):
+    from se3_diffusion_amd import hip
+    so3, r3 = diff._so3_diffuser, diff._r3_diffuser
+    t = float(G["fm_t"])
+    n = 10
+    cdf, omega = so3.device_tables(dev)
+    idx = int(so3.t_to_idx(t))
+    r0 = torch.tensor(G["fm_rigids0"]).to(dev)
+    rt = torch.empty_like(r0)
+    rs = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    ts = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    f64 = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
+    hip.get_lib().call("fd_forward_marginal", r0, f64(G["fm_randn"]), f64(G["fm_rand"]), f64(G["fm_normal"]),
+                       (cdf, idx * cdf.shape[1]), omega, omega.numel(), float(so3.discrete_sigma[idx]),
+                       float(r3.marginal_b_t(t)), 0.1, 1000, None, rt, rs, ts, n)
+    _check_fm(dict(rigids_t=rt, trans_score=ts.cpu().numpy(), rot_score=rs.cpu().numpy(),
+                   trans_score_scaling=r3.score_scaling(t), rot_score_scaling=so3.score_scaling(t)))
+
+
+def test_forward_marginal_kernel_emu(diff, use_emu):
+    _fm_kernel(diff, "cpu")
+
+
+def test_igso3_tables_kernel_emu(diff, use_emu):
+    """fd_igso3_tables on a sub-grid vs the cached full tables."""
+    from se3_diffusion_amd import hip
+    so3 = diff._so3_diffuser
+    rows = np.array([0, 9, 499, 999])
+    sg = torch.tensor(so3.discrete_sigma[rows], dtype=torch.float64)
+    om = torch.tensor(so3.discrete_omega[:64], dtype=torch.float64)
+    pdf = torch.empty((4, 64), dtype=torch.float64); cdf = torch.empty_like(pdf); sn = torch.empty_like(pdf)
+    hip.get_lib().call("fd_igso3_tables", sg, om, 4, 64, 1000, pdf, cdf, sn)
+    assert np.allclose(pdf.numpy(), so3._pdf[rows][:, :64], rtol=1e-9, atol=1e-13)
+    assert np.allclose(sn.numpy(), so3._score_norms[rows][:, :64], rtol=1e-8, atol=2e-7)
+    assert np.allclose(cdf.numpy() * 64 / 1000, so3._cdf[rows][:, :64], rtol=1e-9, atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_diffuser_kernels_gpu(hip_lib, tmp_path):
+    d = se3_diffuser.SE3Diffuser(conf(str(tmp_path)))      # builds the tables with fd_igso3_tables on the GPU
+    test_schedules_and_tables(d)
+    _reverse_kernel(d, "cuda")
+    _check_sample_ref(d.sample_ref_device(11, "cuda", noise=(G["sr_randn"], G["sr_rand"], G["sr_normal"])).cpu().numpy())
+    _fm_kernel(d, "cuda")
+    np.random.seed(55)
+    _check_fm(d.forward_marginal(ru.Rigid.from_tensor_7(torch.tensor(G["fm_rigids0"]).cuda()), float(G["fm_t"])))
+    np.random.seed(123)
+    out = d.reverse(rigid_t=ru.Rigid.from_tensor_7(torch.tensor(G["rev_rigids"]).cuda()), rot_score=G["rev_rot_score"],
+                    trans_score=G["rev_trans_score"], t=float(G["rev_a_t"]), dt=1 / 100, diffuse_mask=G["rev_dmask"],
+                    center=True, noise_scale=float(G["rev_a_ns"]))
+    _check_reverse(out.to_tensor_7().cpu().numpy(), "a")
+    # differentiable calc_rot_score on the GPU vs the float64 host series
+    qt, q0 = torch.tensor(G["crs_qt"]).cuda(), torch.tensor(G["crs_q0"]).cuda().requires_grad_(True)
+    tt = torch.tensor(G["ts"], dtype=torch.float32).cuda()
+    sc = d.calc_rot_score(ru.Rotation(quats=qt, normalize_quats=False), ru.Rotation(quats=q0, normalize_quats=False), tt)
+    assert np.abs(sc.detach().cpu().numpy() - G["crs_out"])[2:].max() < 5e-4 * np.abs(G["crs_out"])[2:].max()
+    sc.sum().backward()
+    assert torch.isfinite(q0.grad).all()

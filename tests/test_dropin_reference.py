@@ -1,0 +1,79 @@
+"""The reference's OWN experiment code, unmodified, running on this repo's hot path.
+
+Needs the reference checkout (build container only: /root/reference; skipped elsewhere).  Runs in a
+subprocess because the reference's top-level module names (model, data, openfold, experiments) are
+generic.  Inside: oracle/ref_loader stubs the reference's missing non-arithmetic imports (hydra, wandb,
+...), se3_diffusion_amd.dropin.install() binds model.score_network / data.se3_diffuser / ... to the HIP
+implementations (SIMT-interpreter build on this GPU-less box), then experiments.train_se3_diffusion.
+Experiment is constructed and its loss_fn / update_fn / inference_fn are driven directly."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("FD_REFERENCE_ROOT", "/root/reference")
+
+SCRIPT = r'''
+import os, sys, types, copy
+import numpy as np, torch
+ROOT, REF = sys.argv[1], sys.argv[2]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+from oracle import ref_loader as rl
+rl.install()
+import build_emu
+from se3_diffusion_amd import hip, dropin
+hip._TEST_OVERRIDE = hip.FdLib(build_emu.build(verbose=False))     # GPU-less box: interpreter build
+bound = dropin.install(REF)
+from hydra.core.hydra_config import HydraConfig
+HydraConfig.initialized = lambda: False
+from experiments import train_se3_diffusion as tr
+import model.score_network as sn, data.se3_diffuser as sd
+assert sn.__name__.startswith("se3_diffusion_amd") and sd.__name__.startswith("se3_diffusion_amd"), (sn.__name__, sd.__name__)
+base = rl.base_conf(os.environ.get("FD_TEST_IGSO3_CACHE", "/tmp/fd_test_igso3_cache"), num_blocks=1)
+ns = rl.ns
+conf = ns(dict(
+    data=dict(min_t=0.01, num_t=4, samples_per_eval_length=1, num_eval_lengths=1),
+    experiment=dict(name="t", run_id=None, use_ddp=False, use_wandb=False, warm_start=None, use_warm_start_conf=False,
+                    ckpt_dir=None, eval_dir=None, learning_rate=1e-4, num_parameters=None, batch_size=2,
+                    trans_loss_weight=1.0, rot_loss_weight=0.5, rot_loss_t_threshold=0.2, separate_rot_loss=True,
+                    trans_x0_threshold=1.0, coordinate_scaling=0.1, bb_atom_loss_weight=1.0, bb_atom_loss_t_filter=0.25,
+                    dist_mat_loss_weight=1.0, dist_mat_loss_t_filter=0.25, aux_loss_weight=0.25, noise_scale=1.0)))
+conf.diffuser, conf.model = base.diffuser, base.model
+exp = tr.Experiment(conf=conf)
+assert type(exp.model).__module__.startswith("se3_diffusion_amd")
+from se3_diffusion_amd import train_step as ts
+ts.perturb_final_layers(exp.model, seed=1)
+torch.manual_seed(0); np.random.seed(0)
+B, N = 2, 8
+batch = ts.synthetic_batch(B, N, "cpu", seed=3)
+batch["t"][0] = 0.1
+import random; random.seed(1)       # loss_fn draws random.random() for self-conditioning
+exp.model.train()
+loss, aux = exp.loss_fn(dict(batch))
+assert torch.isfinite(loss), loss
+l2, _ = exp.update_fn(dict(batch))     # fwd + loss + bwd + Adam through the reference's code
+assert torch.isfinite(l2)
+g = [p.grad for p in exp.model.parameters() if p.grad is not None]
+assert len(g) > 70 and all(torch.isfinite(x).all() for x in g)
+# reverse diffusion through the reference's inference_fn (diffuser.reverse on CPU-resident frames)
+exp.model.eval()
+init = exp.diffuser.sample_ref(n_samples=N, as_tensor_7=True)
+feats = dict(res_mask=torch.ones(N), fixed_mask=torch.zeros(N), seq_idx=torch.arange(1, N + 1),
+             torsion_angles_sin_cos=torch.zeros(N, 7, 2), sc_ca_t=torch.zeros(N, 3), rigids_t=init["rigids_t"])
+feats = {k: v[None] for k, v in feats.items()}
+out = exp.inference_fn(feats, num_t=3, min_t=0.01, aux_traj=True, noise_scale=0.1)
+assert out["prot_traj"].shape == (3, 1, N, 37, 3) and np.isfinite(out["prot_traj"]).all()
+print("DROPIN_OK", float(loss), float(l2), bound)
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "experiments")), reason="reference checkout not present")
+def test_reference_experiment_runs_on_dropin(tmp_path):
+    p = tmp_path / "drive.py"
+    p.write_text(SCRIPT)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, str(p), ROOT, REF], capture_output=True, text=True, cwd=str(tmp_path), env=env,
+                       timeout=1500)
+    assert "DROPIN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
