@@ -60,6 +60,7 @@ typedef struct FdGemmDesc {
   int tile;              /* 0 = auto; 1: 128x128, 2: 64x64, 3: 128x32 */
   int ksplit;            /* >1: split K over blocks, C += alpha*A*B atomically
                             (weight gradients: tiny MxN, huge K); epilogue-free */
+  int mtiles;            /* 0 = auto; >0: consecutive M tiles pipelined per block (un-batched, ksplit 1) */
 } FdGemmDesc;
 
 int fd_gemm(const FdGemmDesc* desc, void* stream);

@@ -14,8 +14,12 @@
 // row-major ([rows][32+4]) and read back with ds_read_b128 using a permuted
 // k order (MFMA step (q,t) of lane-half h consumes k = 8q+4h+t), so one
 // 16-byte LDS read feeds four MFMAs; strided operands are staged [k][rows+4]
-// and read with ds_read_b32 in the same k order.  Global->register prefetch of
-// tile kt+1 is issued before the MFMAs of tile kt (write-late staging).
+// and read with ds_read_b32 in the same k order.  LDS is double-buffered (one
+// barrier per k-tile); the next tile travels global -> registers -> LDS under
+// the MFMAs of the current one.  The FAST instantiation (16-byte-aligned
+// operands) keeps per-thread pointers and row predicates in registers so the
+// staging code between MFMA groups is a handful of instructions; the generic
+// instantiation handles any stride / alignment / tail element-wise.
 // 1-D grid with an XCD-aware remap so that the column blocks that share an A
 // row panel run on one XCD and hit its L2.
 #include "fd_common.h"
@@ -29,67 +33,111 @@ constexpr int KPAD = 4;
 struct GemmArgs {
   FdGemmDesc d;
   int nblk_m, nblk_n;
-  int vecA, vecB;
   int ksplit;
+  int mtiles;   // consecutive M tiles pipelined by one block
 };
 
-template <int ROWS, bool KC>
+// Stages a ROWS x BK operand tile: global -> registers (load) -> LDS (store).
+//   KC : global k-contiguous  -> LDS [ROWS][BK+KPAD]
+//   !KC: global row-contiguous -> LDS [BK][ROWS+KPAD]
+// `rs` = stride of the row index, `cs` = stride of k.
+template <int ROWS, bool KC, bool FAST>
 struct Stager {
-  // ROWS x BK tile; KC: global k-contiguous -> LDS [ROWS][BK+KPAD]
-  //                !KC: global row-contiguous -> LDS [BK][ROWS+KPAD]
   static constexpr int NV = ROWS / 32;  // float4 per thread (256 threads)
-  float4 r[NV];
+  const float* p[NV];   // FAST: per-thread source pointer of the current tile
+  bool ok[NV];          // FAST: row (KC) / row-quad (!KC) in range
+  int koff[NV];         // FAST: k offset of this thread's element inside the tile
+  long kstep;           // FAST: BK * cs
+  // generic path state
+  const float* base;
+  long rs, cs;
+  int row0, nrows;
 
-  __device__ __forceinline__ void load(const float* __restrict__ base, long rs, long cs,
-                                       int row0, int k0, int nrows, int K, int vec, int tid) {
+  __device__ __forceinline__ void init(const float* __restrict__ b, long rs_, long cs_, int row0_, int nrows_,
+                                       int k0, int tid) {
+    base = b; rs = rs_; cs = cs_; row0 = row0_; nrows = nrows_;
+    if (FAST) {
+      kstep = (long)BK * cs_;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int f = tid + 256 * i;
+        if (KC) {
+          const int row = f >> 3, kq = f & 7;
+          koff[i] = 4 * kq;
+          ok[i] = (row0_ + row) < nrows_;
+          p[i] = b + (long)(row0_ + row) * rs_ + (long)(k0 + 4 * kq);
+        } else {
+          constexpr int RQ = ROWS / 4;
+          const int k = f / RQ, rq = f % RQ;
+          koff[i] = k;
+          ok[i] = (row0_ + 4 * rq) < nrows_;
+          p[i] = b + (long)(row0_ + 4 * rq) + (long)(k0 + k) * cs_;
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void load(float4 (&r)[NV], int k0, int K, int tid) {
+    if (FAST) {
+      if (k0 + BK <= K) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok[i]) v = *reinterpret_cast<const float4*>(p[i]);
+          r[i] = v;
+          p[i] += kstep;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok[i] && k0 + koff[i] < K) v = *reinterpret_cast<const float4*>(p[i]);
+          r[i] = v;
+          p[i] += kstep;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      int f = tid + 256 * i;
+      const int f = tid + 256 * i;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (KC) {
-        int row = f >> 3, kq = f & 7;
-        int gr = row0 + row, gk = k0 + 4 * kq;
+        const int row = f >> 3, kq = f & 7;
+        const int gr = row0 + row, gk = k0 + 4 * kq;
         if (gr < nrows) {
-          const float* p = base + (long)gr * rs + (long)gk * cs;
-          if (vec) {
-            if (gk < K) v = *reinterpret_cast<const float4*>(p);
-          } else {
-            if (gk + 0 < K) v.x = p[0];
-            if (gk + 1 < K) v.y = p[cs];
-            if (gk + 2 < K) v.z = p[2 * cs];
-            if (gk + 3 < K) v.w = p[3 * cs];
-          }
+          const float* q = base + (long)gr * rs + (long)gk * cs;
+          if (gk + 0 < K) v.x = q[0];
+          if (gk + 1 < K) v.y = q[cs];
+          if (gk + 2 < K) v.z = q[2 * cs];
+          if (gk + 3 < K) v.w = q[3 * cs];
         }
       } else {
         constexpr int RQ = ROWS / 4;
-        int k = f / RQ, rq = f % RQ;
-        int gr = row0 + 4 * rq, gk = k0 + k;
+        const int k = f / RQ, rq = f % RQ;
+        const int gr = row0 + 4 * rq, gk = k0 + k;
         if (gk < K) {
-          const float* p = base + (long)gr * rs + (long)gk * cs;
-          if (vec) {
-            if (gr < nrows) v = *reinterpret_cast<const float4*>(p);
-          } else {
-            if (gr + 0 < nrows) v.x = p[0];
-            if (gr + 1 < nrows) v.y = p[rs];
-            if (gr + 2 < nrows) v.z = p[2 * rs];
-            if (gr + 3 < nrows) v.w = p[3 * rs];
-          }
+          const float* q = base + (long)gr * rs + (long)gk * cs;
+          if (gr + 0 < nrows) v.x = q[0];
+          if (gr + 1 < nrows) v.y = q[rs];
+          if (gr + 2 < nrows) v.z = q[2 * rs];
+          if (gr + 3 < nrows) v.w = q[3 * rs];
         }
       }
       r[i] = v;
     }
   }
 
-  __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
+  __device__ __forceinline__ void store(const float4 (&r)[NV], float* __restrict__ lds, int tid) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      int f = tid + 256 * i;
+      const int f = tid + 256 * i;
       if (KC) {
-        int row = f >> 3, kq = f & 7;
+        const int row = f >> 3, kq = f & 7;
         *reinterpret_cast<float4*>(&lds[row * (BK + KPAD) + 4 * kq]) = r[i];
       } else {
         constexpr int RQ = ROWS / 4;
-        int k = f / RQ, rq = f % RQ;
+        const int k = f / RQ, rq = f % RQ;
         *reinterpret_cast<float4*>(&lds[k * (ROWS + KPAD) + 4 * rq]) = r[i];
       }
     }
@@ -108,99 +156,21 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  constexpr int TM = BM / WGM / 32;
-  constexpr int TN = BN / WGN / 32;
-  static_assert(WGM * WGN == 4, "4 waves");
-  constexpr int A_LDS = A_KC ? BM * (BK + KPAD) : BK * (BM + KPAD);
-  constexpr int B_LDS = B_KC ? BN * (BK + KPAD) : BK * (BN + KPAD);
-  __shared__ __attribute__((aligned(16))) float lds[A_LDS + B_LDS];
-  float* As = lds;
-  float* Bs = lds + A_LDS;
-
-  const FdGemmDesc& d = g.d;
-  const int tid = (int)threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int wm = wave / WGN, wn = wave % WGN;
-
-  const int nblk = g.nblk_m * g.nblk_n;
-  const int lid = fd_xcd_swizzle((int)blockIdx.x, nblk);
-  const int bm = lid / g.nblk_n, bn = lid % g.nblk_n;
-  const int m0 = bm * BM, n0 = bn * BN;
-
-  const int z = (int)blockIdx.y;
-  const int zo = z / d.bdiv, zi = z % d.bdiv;
-  const float* __restrict__ A = d.A + zo * d.a_so + zi * d.a_si;
-  const float* __restrict__ B = d.B + zo * d.b_so + zi * d.b_si;
-  float* __restrict__ C = d.C + zo * d.c_so + zi * d.c_si;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  Stager<BM, A_KC> sa;
-  Stager<BN, B_KC> sb;
-  // split-K: blockIdx.z owns k-tiles [kt0, nkt)
-  const int nkt_all = (d.K + BK - 1) / BK;
-  const int per = (nkt_all + g.ksplit - 1) / g.ksplit;
-  const int kt0 = (int)blockIdx.z * per;
-  const int nkt = (kt0 + per < nkt_all) ? kt0 + per : nkt_all;
-
-  sa.load(A, d.a_rs, d.a_cs, m0, kt0 * BK, d.M, d.K, g.vecA, tid);
-  // B(k,n): "row" index of the staged tile is n -> row stride b_cs, k stride b_rs
-  sb.load(B, d.b_cs, d.b_rs, n0, kt0 * BK, d.N, d.K, g.vecB, tid);
-  sa.store(As, tid);
-  sb.store(Bs, tid);
-  __syncthreads();
-
-  for (int kt = kt0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) {
-      sa.load(A, d.a_rs, d.a_cs, m0, (kt + 1) * BK, d.M, d.K, g.vecA, tid);
-      sb.load(B, d.b_cs, d.b_rs, n0, (kt + 1) * BK, d.N, d.K, g.vecB, tid);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float a[TM][4], b[TN][4];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        read_frag<BM, A_KC>(As, (wm * TM + i) * 32 + l31, q, h, a[i]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + l31, q, h, b[j]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = fd::mfma_32x32x2(a[i][t], b[j][t], acc[i][j]);
-    }
-    __syncthreads();
-    if (kt + 1 < nkt) {
-      sa.store(As, tid);
-      sb.store(Bs, tid);
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue ----
-  if (g.ksplit > 1) {
+// epilogue of one BM x BN output tile held in the MFMA accumulators
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile(const FdGemmDesc& d, float* __restrict__ C, f32x16 (&acc)[TM][TN],
+                                           int m_base, int n_base, int h, int l31, bool splitk) {
+  if (splitk) {
     // split-K partial: C += alpha * partial (atomic; C holds the running sum)
-    if (kt0 >= nkt) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m >= d.M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int n = n0 + (wn * TN + j) * 32 + l31;
+          const int n = n_base + j * 32 + l31;
           if (n < d.N) atomicAdd(C + (long)m * d.ldc + n, d.alpha * acc[i][j][r]);
         }
       }
@@ -211,7 +181,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (m >= d.M) continue;
       long prow = 0, qrow = 0;
       if (d.pair_p) {
@@ -221,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       const float rs = d.rowscale ? d.rowscale[m] : 1.f;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + l31;
+        const int n = n_base + j * 32 + l31;
         if (n >= d.N) continue;
         float v = d.alpha * acc[i][j][r];
         if (d.bias) v += d.bias[n];
@@ -238,7 +208,164 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC, bool FAST>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+  constexpr int TM = BM / WGM / 32;
+  constexpr int TN = BN / WGN / 32;
+  static_assert(WGM * WGN == 4, "4 waves");
+  constexpr int A_LDS = A_KC ? BM * (BK + KPAD) : BK * (BM + KPAD);
+  constexpr int B_LDS = B_KC ? BN * (BK + KPAD) : BK * (BN + KPAD);
+  constexpr int LDS_STAGE = A_LDS + B_LDS;
+  __shared__ __attribute__((aligned(16))) float lds[2 * LDS_STAGE];
+  float* As = lds;
+  float* Bs = lds + A_LDS;
+
+  const FdGemmDesc& d = g.d;
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // A block owns `mtiles` consecutive M tiles of one N column block and runs them as ONE software pipeline
+  // (the first loads of tile i+1 are in flight while tile i finishes and stores), so short-K GEMMs do not pay
+  // a load-latency bubble per output tile.
+  const int T = g.mtiles;
+  const int nblk_mg = (g.nblk_m + T - 1) / T;
+  const int nblk = nblk_mg * g.nblk_n;
+  const int lid = fd_xcd_swizzle((int)blockIdx.x, nblk);
+  const int bmg = lid / g.nblk_n, bn = lid % g.nblk_n;
+  const int mt0 = bmg * T;
+  const int ntile = (g.nblk_m - mt0 < T) ? g.nblk_m - mt0 : T;
+  const int n0 = bn * BN;
+
+  const int z = (int)blockIdx.y;
+  const int zo = z / d.bdiv, zi = z % d.bdiv;
+  const float* __restrict__ A = d.A + zo * d.a_so + zi * d.a_si;
+  const float* __restrict__ B = d.B + zo * d.b_so + zi * d.b_si;
+  float* __restrict__ C = d.C + zo * d.c_so + zi * d.c_si;
+
+  // split-K: blockIdx.z owns k-tiles [kt0, nkt)
+  const int nkt_all = (d.K + BK - 1) / BK;
+  const int per = (nkt_all + g.ksplit - 1) / g.ksplit;
+  const int kt0 = (int)blockIdx.z * per;
+  const int nkt = (kt0 + per < nkt_all) ? kt0 + per : nkt_all;
+  const int nk = nkt - kt0;
+  if (nk <= 0 || ntile <= 0) return;
+  const int total = ntile * nk;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Stager<BM, A_KC, FAST> sa;
+  Stager<BN, B_KC, FAST> sb;
+  // two register sets: tile it+1 and tile it+2 are both in flight while tile it is multiplied (prefetch
+  // distance ~1.75 k-tiles: cold HBM reads of a streamed A operand need more than one k-tile of cover)
+  float4 ra[2][Stager<BM, A_KC, FAST>::NV], rb[2][Stager<BN, B_KC, FAST>::NV];
+  int l_t = 0, l_k = 0;   // (tile, k-tile) of the next global load
+  auto issue_load = [&](float4 (&xa)[Stager<BM, A_KC, FAST>::NV], float4 (&xb)[Stager<BN, B_KC, FAST>::NV]) {
+    if (l_k == 0) {
+      sa.init(A, d.a_rs, d.a_cs, (mt0 + l_t) * BM, d.M, kt0 * BK, tid);
+      // B(k,n): the "row" index of the staged tile is n -> row stride b_cs, k stride b_rs
+      sb.init(B, d.b_cs, d.b_rs, n0, d.N, kt0 * BK, tid);
+    }
+    sa.load(xa, (kt0 + l_k) * BK, d.K, tid);
+    sb.load(xb, (kt0 + l_k) * BK, d.K, tid);
+    if (++l_k == nk) { l_k = 0; ++l_t; }
+  };
+
+  // Software pipeline, one barrier per k-tile.  While tile `it` is multiplied out of LDS[cur]:
+  //   after MFMA group 0: tile it+1 (registers, set (it+1)&1) -> LDS[cur^1]
+  //   after MFMA group 1: global loads of tile it+3 -> the register set just freed
+  // so LDS writes and global loads hide under the 64-cycle fp32 MFMAs of the SAME wave.  MFMA operand fragments
+  // are double-buffered in registers (group q+1 is fetched before group q issues).
+  issue_load(ra[0], rb[0]);
+  sa.store(ra[0], As, tid);
+  sb.store(rb[0], Bs, tid);
+  if (total > 1) issue_load(ra[1], rb[1]);
+  if (total > 2) issue_load(ra[0], rb[0]);
+  __syncthreads();
+
+  float a[2][TM][4], b[2][TN][4];
+  int cur = 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) read_frag<BM, A_KC>(As, (wm * TM + i) * 32 + l31, 0, h, a[0][i]);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + l31, 0, h, b[0][j]);
+
+  int c_t = 0, c_k = 0;   // (tile, k-tile) being multiplied
+  auto body = [&](int it, float4 (&xa)[Stager<BM, A_KC, FAST>::NV], float4 (&xb)[Stager<BN, B_KC, FAST>::NV]) {
+    // xa/xb: the register set holding tile it+1 (stored here, then refilled with tile it+3)
+    const float* Ac = As + cur * LDS_STAGE;
+    const float* Bc = Bs + cur * LDS_STAGE;
+    float* An = As + (cur ^ 1) * LDS_STAGE;
+    float* Bn = Bs + (cur ^ 1) * LDS_STAGE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) read_frag<BM, A_KC>(Ac, (wm * TM + i) * 32 + l31, q + 1, h, a[(q + 1) & 1][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) read_frag<BN, B_KC>(Bc, (wn * TN + j) * 32 + l31, q + 1, h, b[(q + 1) & 1][j]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = fd::mfma_32x32x2(a[q & 1][i][t], b[q & 1][j][t], acc[i][j]);
+      if (q == 0 && it + 1 < total) {
+        sa.store(xa, An, tid);
+        sb.store(xb, Bn, tid);
+      }
+      if (q == 1 && it + 3 < total) issue_load(xa, xb);
+    }
+    if (++c_k == nk) {
+      store_tile<TM, TN>(d, C, acc, (mt0 + c_t) * BM + wm * TM * 32, n0 + wn * TN * 32, h, l31, g.ksplit > 1);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      c_k = 0;
+      ++c_t;
+    }
+    __syncthreads();
+    cur ^= 1;
+    if (it + 1 < total) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) read_frag<BM, A_KC>(An, (wm * TM + i) * 32 + l31, 0, h, a[0][i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) read_frag<BN, B_KC>(Bn, (wn * TN + j) * 32 + l31, 0, h, b[0][j]);
+    }
+  };
+  for (int it = 0; it < total; it += 2) {
+    body(it, ra[1], rb[1]);
+    if (it + 1 < total) body(it + 1, ra[0], rb[0]);
+  }
+}
+
+// 16-byte staging is legal when the contiguous index is a multiple of 4 everywhere the kernel can touch it
+bool operands_vectorisable(const FdGemmDesc& d) {
+  auto al4 = [](long x) { return (x & 3) == 0; };
+  bool va, vb;
+  if (d.a_cs == 1)
+    va = fd_aligned16(d.A) && al4(d.a_rs) && al4(d.K) && al4(d.a_so) && al4(d.a_si);
+  else
+    va = (d.a_rs == 1) && fd_aligned16(d.A) && al4(d.a_cs) && al4(d.M) && al4(d.a_so) && al4(d.a_si);
+  if (d.b_rs == 1)
+    vb = fd_aligned16(d.B) && al4(d.b_cs) && al4(d.K) && al4(d.b_so) && al4(d.b_si);
+  else
+    vb = (d.b_cs == 1) && fd_aligned16(d.B) && al4(d.b_rs) && al4(d.N) && al4(d.b_so) && al4(d.b_si);
+  return va && vb;
+}
+
+template <int BM, int BN, int WGM, int WGN, bool FAST>
 int launch_cfg(const FdGemmDesc& d, hipStream_t stream) {
   GemmArgs g;
   g.d = d;
@@ -247,31 +374,29 @@ int launch_cfg(const FdGemmDesc& d, hipStream_t stream) {
   const bool a_kc = (d.a_cs == 1);
   const bool b_kc = (d.b_rs == 1);
   const int nb = d.batch > 0 ? d.batch : 1;
-  auto al4 = [](long x) { return (x & 3) == 0; };
-  // vector (16 B) staging is legal when the contiguous index is a multiple of 4
-  // everywhere the kernel can touch it.
-  if (a_kc)
-    g.vecA = fd_aligned16(d.A) && al4(d.a_rs) && al4(d.K) && al4(d.a_so) && al4(d.a_si);
-  else
-    g.vecA = (d.a_rs == 1) && fd_aligned16(d.A) && al4(d.a_cs) && al4(d.M) && al4(d.a_so) && al4(d.a_si);
-  if (b_kc)
-    g.vecB = fd_aligned16(d.B) && al4(d.b_cs) && al4(d.K) && al4(d.b_so) && al4(d.b_si);
-  else
-    g.vecB = (d.b_cs == 1) && fd_aligned16(d.B) && al4(d.b_rs) && al4(d.N) && al4(d.b_so) && al4(d.b_si);
   g.ksplit = d.ksplit > 1 ? d.ksplit : 1;
   {
     const int nkt_all = fd_cdiv(d.K, BK);
     if (g.ksplit > nkt_all) g.ksplit = nkt_all > 0 ? nkt_all : 1;
   }
-  dim3 grid(g.nblk_m * g.nblk_n, nb, g.ksplit), block(256, 1, 1);
+  // persistent M-tile pipelining for the large un-batched GEMMs (pair-level tensors): keep >= ~2300 blocks
+  g.mtiles = 1;
+  if (g.ksplit == 1 && nb == 1) {
+    const long blocks = (long)g.nblk_m * g.nblk_n;
+    long t = blocks / 2304;
+    g.mtiles = (int)(t < 1 ? 1 : (t > 16 ? 16 : t));
+    if (d.mtiles > 0) g.mtiles = d.mtiles;
+  }
+  const int nblk_mg = (g.nblk_m + g.mtiles - 1) / g.mtiles;
+  dim3 grid(nblk_mg * g.nblk_n, nb, g.ksplit), block(256, 1, 1);
   if (a_kc && b_kc)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, true, true, FAST>), grid, block, 0, stream, g);
   else if (a_kc && !b_kc)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, true, false, FAST>), grid, block, 0, stream, g);
   else if (!a_kc && b_kc)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, false, true, FAST>), grid, block, 0, stream, g);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, false, false>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, false, false, FAST>), grid, block, 0, stream, g);
   FD_CHECK_LAUNCH("fd_gemm");
   return FD_OK;
 }
@@ -301,10 +426,12 @@ extern "C" int fd_gemm(const FdGemmDesc* desc, void* stream_) {
     else if (blocks128 >= 512 && d.N >= 96) cfg = 1;
     else cfg = 2;
   }
+  const bool fast = operands_vectorisable(d);
+  if (!fast && cfg == 1) cfg = 2;   // the element-wise staging path is only instantiated for the small tiles
   switch (cfg) {
-    case 1: return launch_cfg<128, 128, 2, 2>(d, stream);
-    case 2: return launch_cfg<64, 64, 2, 2>(d, stream);
-    case 3: return launch_cfg<128, 32, 4, 1>(d, stream);
+    case 1: return launch_cfg<128, 128, 2, 2, true>(d, stream);
+    case 2: return fast ? launch_cfg<64, 64, 2, 2, true>(d, stream) : launch_cfg<64, 64, 2, 2, false>(d, stream);
+    case 3: return fast ? launch_cfg<128, 32, 4, 1, true>(d, stream) : launch_cfg<128, 32, 4, 1, false>(d, stream);
     default: fd_set_error("fd_gemm: bad tile config %d", cfg); return FD_ERR_ARG;
   }
 }

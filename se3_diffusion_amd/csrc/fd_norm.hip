@@ -171,6 +171,51 @@ __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__
   }
 }
 
+// vectorised variant (ld % 4 == 0, ncols % 4 == 0, 16-byte aligned): lanes span 256 columns with float4 loads,
+// four independent row streams per wave keep loads in flight
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ X, long ld, long rows, int ncols,
+                                                       float* __restrict__ out) {
+  __shared__ float4 red[4][64];
+  const int lane = fd::lane_id(), wave = fd::wave_id();
+  const long wg = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
+  for (int c0 = 0; c0 < ncols; c0 += 256) {
+    const int c = c0 + lane * 4;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    if (c < ncols) {
+      long r = wg;
+      for (; r + 3 * nw < rows; r += 4 * nw) {
+        const float4 v0 = *reinterpret_cast<const float4*>(X + r * ld + c);
+        const float4 v1 = *reinterpret_cast<const float4*>(X + (r + nw) * ld + c);
+        const float4 v2 = *reinterpret_cast<const float4*>(X + (r + 2 * nw) * ld + c);
+        const float4 v3 = *reinterpret_cast<const float4*>(X + (r + 3 * nw) * ld + c);
+        acc0.x += v0.x; acc0.y += v0.y; acc0.z += v0.z; acc0.w += v0.w;
+        acc1.x += v1.x; acc1.y += v1.y; acc1.z += v1.z; acc1.w += v1.w;
+        acc2.x += v2.x; acc2.y += v2.y; acc2.z += v2.z; acc2.w += v2.w;
+        acc3.x += v3.x; acc3.y += v3.y; acc3.z += v3.z; acc3.w += v3.w;
+      }
+      for (; r < rows; r += nw) {
+        const float4 v0 = *reinterpret_cast<const float4*>(X + r * ld + c);
+        acc0.x += v0.x; acc0.y += v0.y; acc0.z += v0.z; acc0.w += v0.w;
+      }
+    }
+    float4 s;
+    s.x = (acc0.x + acc1.x) + (acc2.x + acc3.x);
+    s.y = (acc0.y + acc1.y) + (acc2.y + acc3.y);
+    s.z = (acc0.z + acc1.z) + (acc2.z + acc3.z);
+    s.w = (acc0.w + acc1.w) + (acc2.w + acc3.w);
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < ncols) {
+      const float4 a = red[0][lane], b = red[1][lane], e = red[2][lane], f = red[3][lane];
+      atomicAdd(&out[c + 0], (a.x + b.x) + (e.x + f.x));
+      atomicAdd(&out[c + 1], (a.y + b.y) + (e.y + f.y));
+      atomicAdd(&out[c + 2], (a.z + b.z) + (e.z + f.z));
+      atomicAdd(&out[c + 3], (a.w + b.w) + (e.w + f.w));
+    }
+    __syncthreads();
+  }
+}
+
 // dst[r*ldd + c] += a * src[r*lds + c]   (gradient accumulation into column blocks / views)
 __global__ __launch_bounds__(256) void add2d_kernel(float* __restrict__ dst, long ldd, const float* __restrict__ src,
                                                     long lds, long rows, int cols, float a) {
@@ -216,8 +261,13 @@ extern "C" int fd_layernorm_bwd(const float* dy, long lddy, const float* x, long
 
 extern "C" int fd_colsum_acc(const float* X, long ld, long rows, int ncols, float* out, void* stream) {
   if (rows == 0 || ncols == 0) return FD_OK;
-  long g = (rows + 3) / 4;
+  long g = (rows + 15) / 16;
   int grid = (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
+  if ((ld & 3) == 0 && (ncols & 3) == 0 && fd_aligned16(X)) {
+    hipLaunchKernelGGL(colsum4_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ld, rows, ncols, out);
+    FD_CHECK_LAUNCH("fd_colsum_acc");
+    return FD_OK;
+  }
   hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, ld, rows, ncols, out);
   FD_CHECK_LAUNCH("fd_colsum_acc");
   return FD_OK;

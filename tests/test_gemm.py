@@ -108,6 +108,28 @@ def test_gemm_gpu(hip_lib):
     assert _run(hip_lib, "cuda", 4096, 384, 384, True, True, 0) < 2e-6
 
 
+def _mtiles(lib, dev):
+    """several M tiles pipelined by one block (persistent loop), with an epilogue and ragged last tile"""
+    g = torch.Generator().manual_seed(5)
+    for (M, N, K, tile, mt) in [(300, 72, 96, 2, 3), (700, 130, 40, 1, 2), (333, 40, 64, 3, 4)]:
+        A = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g)
+        bias = torch.randn(N, generator=g)
+        C = torch.zeros(M, N).to(dev)
+        lib.gemm(A.to(dev), W.to(dev), C, M, N, K, (K, 1), (1, K), N, bias=bias.to(dev), relu=True, tile=tile, mtiles=mt)
+        ref = torch.clamp(A.double() @ W.double().t() + bias.double(), min=0)
+        assert (C.cpu().double() - ref).abs().max() < 1e-4, (M, N, K)
+
+
+def test_gemm_mtiles_emu(emu_lib):
+    _mtiles(emu_lib, "cpu")
+
+
+@pytest.mark.gpu
+def test_gemm_mtiles_gpu(hip_lib):
+    _mtiles(hip_lib, "cuda")
+
+
 def _splitk(lib, dev):
     g = torch.Generator().manual_seed(3)
     M, N, K = 40, 72, 1000   # dW-like: reduction over many rows, operands row-contiguous (TN)

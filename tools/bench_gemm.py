@@ -1,10 +1,14 @@
-"""Micro-benchmark fd_gemm on the shapes that dominate the FrameDiff step (MI355X)."""
+"""Micro-benchmark fd_gemm on the shapes that dominate the FrameDiff step (MI355X).
+   python tools/bench_gemm.py [--only substr] [--iters n] [--warm n]"""
+import argparse
 import json
-import sys
 import os
+import sys
+
 import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from se3_diffusion_amd import hip
+from se3_diffusion_amd import hip  # noqa: E402
 
 
 def timeit(fn, iters=10, warm=3):
@@ -20,35 +24,48 @@ def timeit(fn, iters=10, warm=3):
     return s.elapsed_time(e) / iters
 
 
+P = 30 * 128 * 128
+SHAPES = [
+    # name, M, N, K, a_kc, b_kc, tile, ksplit
+    ("edge_fwd_W2 NT", P, 384, 384, True, True, 1, 1),
+    ("edge_fwd_W1z NT", P, 384, 128, True, True, 1, 1),
+    ("edge_fwd_Wf NT", P, 128, 384, True, True, 1, 1),
+    ("edge_bwd_dX NN", P, 384, 384, True, False, 1, 1),
+    ("edge_bwd_dW TN", 384, 384, P, False, False, 1, 256),
+    ("edge_bwd_dW TN t2", 384, 384, P, False, False, 2, 128),
+    ("ipa_proj NT", 3840, 6816, 256, True, True, 1, 1),
+    ("ipa_proj NT t2", 3840, 6816, 256, True, True, 2, 1),
+    ("ipa_out NT", 3840, 256, 2688, True, True, 2, 1),
+    ("z_to_40 NT", P, 40, 128, True, True, 3, 1),
+    ("sample N=128 proj", 128, 6816, 256, True, True, 2, 1),
+    ("sample edge W2 N=128", 16384, 384, 384, True, True, 1, 1),
+    ("sample edge W2 N=128 t2", 16384, 384, 384, True, True, 2, 1),
+    ("square 4096 NT", 4096, 4096, 4096, True, True, 1, 1),
+    ("probe shortK bigN", 32768, 4096, 384, True, True, 1, 1),
+    ("probe longK N384", 122880, 384, 1536, True, True, 1, 1),
+    ("probe K384 N384 M64k", 65536, 384, 384, True, True, 1, 1),
+]
+
+
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--warm", type=int, default=3)
+    a = ap.parse_args()
     lib = hip.get_lib()
     dev = "cuda"
-    P = 30 * 128 * 128
     out = []
-    shapes = [
-        # name, M, N, K, layout(a_kc,b_kc), tile, ksplit
-        ("edge_fwd_W2 NT", P, 384, 384, True, True, 1, 1),
-        ("edge_fwd_W1z NT", P, 384, 128, True, True, 1, 1),
-        ("edge_fwd_Wf NT", P, 128, 384, True, True, 1, 1),
-        ("edge_bwd_dX NN", P, 384, 384, True, False, 1, 1),
-        ("edge_bwd_dW TN", 384, 384, P, False, False, 1, 256),
-        ("edge_bwd_dW TN t2", 384, 384, P, False, False, 2, 128),
-        ("ipa_proj NT", 3840, 6816, 256, True, True, 1, 1),
-        ("ipa_proj NT t2", 3840, 6816, 256, True, True, 2, 1),
-        ("ipa_out NT", 3840, 256, 2688, True, True, 2, 1),
-        ("z_to_40 NT", P, 40, 128, True, True, 3, 1),
-        ("sample N=128 proj", 128, 6816, 256, True, True, 2, 1),
-        ("sample edge W2 N=128", 16384, 384, 384, True, True, 1, 1),
-        ("sample edge W2 N=128 t2", 16384, 384, 384, True, True, 2, 1),
-    ]
-    for name, M, N, K, akc, bkc, tile, ks in shapes:
+    for name, M, N, K, akc, bkc, tile, ks in SHAPES:
+        if a.only and a.only not in name:
+            continue
         A = torch.randn(M, K, device=dev) if akc else torch.randn(K, M, device=dev)
         B = torch.randn(N, K, device=dev) if bkc else torch.randn(K, N, device=dev)
         C = torch.zeros(M, N, device=dev)
         a_str = (K, 1) if akc else (1, M)
         b_str = (1, K) if bkc else (N, 1)
-        fn = lambda: lib.gemm(A, B, C, M, N, K, a_str, b_str, N, tile=tile, ksplit=ks)
-        ms = timeit(fn)
+        fn = lambda: lib.gemm(A, B, C, M, N, K, a_str, b_str, N, tile=tile, ksplit=ks)  # noqa: E731
+        ms = timeit(fn, a.iters, a.warm)
         tf = 2.0 * M * N * K / ms / 1e9
         out.append(dict(name=name, M=M, N=N, K=K, tile=tile, ksplit=ks, ms=round(ms, 4), tflops=round(tf, 2)))
         print(f"{name:28s} M={M:7d} N={N:5d} K={K:7d} tile={tile} ks={ks:3d}  {ms:8.3f} ms  {tf:7.2f} TF/s", flush=True)
