@@ -164,8 +164,9 @@ int fd_forward_marginal(const float* rig0, const double* z_axis, const double* u
                         double* trans_score, long n, void* stream);
 int fd_se3_reverse_step(const float* rig_t, const double* rot_score, const double* trans_score,
                         const double* z_rot, const double* z_trans, const float* mask, int B, int N, double g_rot,
-                        double b_t, double dt, double noise_scale, double coord_scale, int center, int diffuse_rot,
-                        int diffuse_trans, float* out, void* stream);
+                        double b_t, const double* tparams /* optional device {g_rot, b_t}: overrides the scalars,
+                        lets one captured hipGraph serve every t */, double dt, double noise_scale,
+                        double coord_scale, int center, int diffuse_rot, int diffuse_trans, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -168,12 +168,13 @@ __global__ __launch_bounds__(256) void forward_marginal_kernel(
 __global__ __launch_bounds__(256) void reverse_step_kernel(
     const float* __restrict__ rig_t, const double* __restrict__ rot_score, const double* __restrict__ trans_score,
     const double* __restrict__ z_rot, const double* __restrict__ z_trans, const float* __restrict__ mask, int N,
-    double g_rot, double b_t, double dt, double noise_scale, double cs, int center, int diffuse_rot,
-    int diffuse_trans, float* __restrict__ out) {
+    double g_rot, double b_t, const double* __restrict__ tparams, double dt, double noise_scale, double cs, int center,
+    int diffuse_rot, int diffuse_trans, float* __restrict__ out) {
   __shared__ double red[4][3];
   __shared__ double com[3];
   const int b = (int)blockIdx.x;
   const int tid = (int)threadIdx.x;
+  if (tparams) { g_rot = tparams[0]; b_t = tparams[1]; }   // time-dependent scalars from HBM (graph replay)
   const double sdt = sqrt(dt), gb = sqrt(b_t);
   double acc[3] = {0.0, 0.0, 0.0};
   // pass 1: translations (stored temporarily in out[4:7] as fp64-rounded-to-fp32 is NOT acceptable for the
@@ -264,11 +265,12 @@ extern "C" int fd_forward_marginal(const float* rig0, const double* z_axis, cons
 
 extern "C" int fd_se3_reverse_step(const float* rig_t, const double* rot_score, const double* trans_score,
                                    const double* z_rot, const double* z_trans, const float* mask, int B, int N,
-                                   double g_rot, double b_t, double dt, double noise_scale, double coord_scale,
-                                   int center, int diffuse_rot, int diffuse_trans, float* out, void* stream) {
+                                   double g_rot, double b_t, const double* tparams, double dt, double noise_scale,
+                                   double coord_scale, int center, int diffuse_rot, int diffuse_trans, float* out,
+                                   void* stream) {
   if (B == 0 || N == 0) return FD_OK;
   hipLaunchKernelGGL(reverse_step_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, rig_t, rot_score,
-                     trans_score, z_rot, z_trans, mask, N, g_rot, b_t, dt, noise_scale, coord_scale, center,
+                     trans_score, z_rot, z_trans, mask, N, g_rot, b_t, tparams, dt, noise_scale, coord_scale, center,
                      diffuse_rot, diffuse_trans, out);
   FD_CHECK_LAUNCH("fd_se3_reverse_step");
   return FD_OK;

@@ -167,9 +167,10 @@ class SE3Diffuser:
         return _assemble_rigid(rot_t_1, trans_t_1, device=rigid_t.device)
 
     def reverse_device(self, rigids_t7, rot_score, trans_score, t, dt, diffuse_mask=None, center=True,
-                       noise_scale=1.0, noise=None, generator=None):
+                       noise_scale=1.0, noise=None, generator=None, tparams=None, out=None):
         """Device-resident reverse step on [B, N, 7] frames (fd_se3_reverse_step).  noise=None draws
-        z_rot then z_trans from `generator` (torch, on device)."""
+        z_rot then z_trans from `generator` (torch, on device).  tparams: optional device float64 [2] =
+        (g_rot(t), b(t)) read by the kernel instead of the scalars (one captured hipGraph serves every t)."""
         from .. import hip
         dev = rigids_t7.device
         B, N = rigids_t7.shape[0], rigids_t7.shape[1]
@@ -180,10 +181,11 @@ class SE3Diffuser:
             z_rot, z_trans = _f64(noise[0], dev), _f64(noise[1], dev)
         mask = None if diffuse_mask is None else torch.as_tensor(
             diffuse_mask.detach() if torch.is_tensor(diffuse_mask) else np.asarray(diffuse_mask)).to(device=dev, dtype=torch.float32).contiguous()
-        out = torch.empty((B, N, 7), dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty((B, N, 7), dtype=torch.float32, device=dev)
         hip.get_lib().call("fd_se3_reverse_step", rigids_t7.to(torch.float32).contiguous(), _f64(rot_score, dev),
                            _f64(trans_score, dev), z_rot, z_trans, mask, B, N, float(self._so3_diffuser.diffusion_coef(t)),
-                           float(self._r3_diffuser.b_t(t)), float(dt), float(noise_scale),
+                           float(self._r3_diffuser.b_t(t)), tparams, float(dt), float(noise_scale),
                            float(self._r3_diffuser._r3_conf.coordinate_scaling), int(center), int(self._diffuse_rot),
                            int(self._diffuse_trans), out)
         return out

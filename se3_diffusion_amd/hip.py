@@ -95,7 +95,7 @@ _SIGS = {
     "fd_igso3_tables": "ppiiippps",
     "fd_sample_ref": "pppppidpls",
     "fd_forward_marginal": "ppppppidddipppp" + "ls",
-    "fd_se3_reverse_step": "ppppppiidddddiiips",
+    "fd_se3_reverse_step": "ppppppiiddpdddiiips",
 }
 # exact argument lists, kept next to the header for the symbol-export test
 _CT = {"p": c_void_p, "i": c_int, "l": c_long, "f": c_float, "d": c_double, "S": c_void_p, "s": c_void_p}

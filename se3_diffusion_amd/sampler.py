@@ -5,13 +5,17 @@ num_t steps -- no device->numpy->scipy->eigh->device round trip per step
 
 Per step: ScoreNetwork forward (HIP trunk) -> self-conditioning CA update -> fd_se3_reverse_step.
 The last step (t == min_t) takes the model's predicted frames directly (:778-780).
+
+use_graph=True captures ONE step (~230 kernel launches) into a hipGraph and replays it for every t:
+the time-dependent scalars live in HBM (feats['t'], tparams = (g_rot(t), b(t))) and the noise is drawn
+into static buffers before each replay, so small-N sampling is no longer launch-bound.
 """
 from __future__ import annotations
 
 import numpy as np
 import torch
 
-from .openfold.utils import rigid_utils as ru
+from . import hip
 
 
 def init_feats(diffuser, B, N, device, generator=None, noise=None):
@@ -25,44 +29,107 @@ def init_feats(diffuser, B, N, device, generator=None, noise=None):
         rigids_t=rig, t=torch.ones(B, device=dev))
 
 
+def _f64(x, dev):
+    return torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x).to(device=dev, dtype=torch.float64)
+
+
 @torch.no_grad()
 def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_condition=True, center=True,
-           generator=None, noise_fn=None, return_traj=False):
+           generator=None, noise_fn=None, return_traj=False, use_graph=False):
     """Run the reverse process on `feats` (from init_feats).  noise_fn(step, shape) -> (z_rot, z_trans) injects
     draws (e.g. the numpy stream, for trajectory parity); default draws on the device.
     Returns dict(rigids [B,N,7], atom37 [B,N,37,3], psi, (rigid_traj list))."""
-    feats = dict(feats)
+    dev = feats["rigids_t"].device
     B, N = feats["res_mask"].shape
     steps = np.linspace(min_t, 1.0, num_t)[::-1]
     dt = 1.0 / num_t
     was_training = model.training
     model.eval()
+    lib = hip.get_lib()
+    saved_prof, lib.gemm_profile = lib.gemm_profile, (None if use_graph else lib.gemm_profile)
+    # static state (updated in place so a captured graph sees it)
+    st = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in feats.items()}
+    st["rigids_t"] = st["rigids_t"].to(torch.float32).contiguous()
+    st["t"] = torch.ones(B, device=dev)
+    diffuse_mask = ((1 - st["fixed_mask"]) * st["res_mask"]).contiguous()
+    z_rot = torch.zeros((B, N, 3), dtype=torch.float64, device=dev)
+    z_trans = torch.zeros((B, N, 3), dtype=torch.float64, device=dev)
+    tparams = torch.zeros(2, dtype=torch.float64, device=dev)
+    new_rig = torch.empty((B, N, 7), dtype=torch.float32, device=dev)
+    psi = torch.zeros((B, N, 2), device=dev)
+    so3, r3 = diffuser._so3_diffuser, diffuser._r3_diffuser
+
+    # per-step scalars (g_rot(t), b(t)) uploaded once; each step copies its row device-to-device
+    all_tp = torch.tensor(np.stack([[float(so3.diffusion_coef(t)), float(r3.b_t(t))] for t in steps]),
+                          dtype=torch.float64).to(dev)
+    step_of = {float(t): i for i, t in enumerate(steps)}
+
+    def set_t(t):
+        st["t"].fill_(float(t))
+        tparams.copy_(all_tp[step_of[float(t)]])
+
+    def draw(i):
+        if noise_fn is None:
+            z_rot.normal_(generator=generator)
+            z_trans.normal_(generator=generator)
+        else:
+            zr, zt = noise_fn(i, (B, N, 3))
+            z_rot.copy_(_f64(zr, dev))
+            z_trans.copy_(_f64(zt, dev))
+
+    def step_body():
+        out = model(st)
+        if self_condition:
+            st["sc_ca_t"].copy_(out["rigids"][..., 4:])
+        psi.copy_(out["psi"])
+        diffuser.reverse_device(st["rigids_t"], out["rot_score"], out["trans_score"], 0.5, dt, diffuse_mask=diffuse_mask,
+                                center=center, noise_scale=noise_scale, noise=(z_rot, z_trans), tparams=tparams,
+                                out=new_rig)
+        st["rigids_t"].copy_(new_rig)
+
     traj = []
-    diffuse_mask = (1 - feats["fixed_mask"]) * feats["res_mask"]
     if self_condition:
-        feats["t"] = torch.full((B,), float(steps[0]), device=feats["rigids_t"].device)
-        feats["sc_ca_t"] = model(feats)["rigids"][..., 4:]
+        set_t(steps[0])
+        st["sc_ca_t"].copy_(model(st)["rigids"][..., 4:])
+    graph = None
+    n_rev = int(np.sum(steps > min_t))
+    if use_graph and lib.is_device and n_rev > 3:
+        # warm up on a side stream (allocator, lazily-built constant tables), then capture one step
+        saved = {k: st[k].clone() for k in ("rigids_t", "sc_ca_t")}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            set_t(steps[0])
+            for _ in range(2):
+                step_body()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step_body()
+        for k, v in saved.items():
+            st[k].copy_(v)
     out = None
     for i, t in enumerate(steps):
         if t > min_t:
-            feats["t"] = torch.full((B,), float(t), device=feats["rigids_t"].device)
-            out = model(feats)
-            if self_condition:
-                feats["sc_ca_t"] = out["rigids"][..., 4:]
-            noise = None if noise_fn is None else noise_fn(i, (B, N, 3))
-            feats["rigids_t"] = diffuser.reverse_device(feats["rigids_t"], out["rot_score"], out["trans_score"], float(t), dt,
-                                                        diffuse_mask=diffuse_mask, center=center, noise_scale=noise_scale,
-                                                        noise=noise, generator=generator)
+            set_t(t)
+            draw(i)
+            if graph is not None:
+                graph.replay()
+            else:
+                step_body()
         else:
-            out = model(feats)
-            feats["rigids_t"] = out["rigids"]
+            # reference quirk kept: the final forward still carries the previous step's t (train_se3_diffusion.py:778-779)
+            out = model(st)
+            st["rigids_t"].copy_(out["rigids"])
+            psi.copy_(out["psi"])
         if return_traj:
-            traj.append(feats["rigids_t"].clone())
+            traj.append(st["rigids_t"].clone())
     if was_training:
         model.train()
+    lib.gemm_profile = saved_prof
     from . import train_step as ts
-    atom37, _ = ts.backbone_atoms(feats["rigids_t"], out["psi"])
-    res = dict(rigids=feats["rigids_t"], atom37=atom37, psi=out["psi"])
+    atom37, _ = ts.backbone_atoms(st["rigids_t"], psi)
+    res = dict(rigids=st["rigids_t"], atom37=atom37, psi=psi)
     if return_traj:
         res["rigid_traj"] = traj
     return res
