@@ -61,6 +61,8 @@ typedef struct FdGemmDesc {
   int ksplit;            /* >1: split K over blocks, C += alpha*A*B atomically
                             (weight gradients: tiny MxN, huge K); epilogue-free */
   int mtiles;            /* 0 = auto; >0: consecutive M tiles pipelined per block (un-batched, ksplit 1) */
+  float* a_rowsum;       /* optional [M]: += alpha * sum_k A(m,k), accumulated atomically (fused bias gradient
+                            of dW = dY^T X: A = dY^T, so this is sum over rows of dY) */
 } FdGemmDesc;
 
 int fd_gemm(const FdGemmDesc* desc, void* stream);

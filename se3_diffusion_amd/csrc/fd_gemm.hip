@@ -176,39 +176,65 @@ __device__ __forceinline__ void store_tile(const FdGemmDesc& d, float* __restric
       }
     return;
   }
-  const long nn = (long)d.nres * d.nres;
+  // per-column constants hoisted; the pair (b,i,j) decode of a row is one division per 32-row block, then carries
+  bool nok[TN];
+  float bj[TN];
+  int ncol[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    ncol[j] = n_base + j * 32 + l31;
+    nok[j] = ncol[j] < d.N;
+    bj[j] = (d.bias && nok[j]) ? d.bias[ncol[j]] : 0.f;
+  }
+  const int nres = d.nres;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    const int mi = m_base + i * 32;
+    int rr0 = 0, ii0 = 0, bb0 = 0;
+    if (d.pair_p) {
+      const int q0 = mi / nres;
+      rr0 = mi - q0 * nres;
+      bb0 = q0 / nres;
+      ii0 = q0 - bb0 * nres;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int m = mi + o;
       if (m >= d.M) continue;
-      long prow = 0, qrow = 0;
+      const float* pp = nullptr;
+      const float* pq = nullptr;
       if (d.pair_p) {
-        prow = m / d.nres;
-        qrow = (m / nn) * d.nres + (m % d.nres);
+        int rr = rr0 + o, ii = ii0, bb = bb0;
+        while (rr >= nres) {
+          rr -= nres;
+          if (++ii == nres) { ii = 0; ++bb; }
+        }
+        pp = d.pair_p + ((long)bb * nres + ii) * d.ld_pair;   // row m / nres
+        pq = d.pair_q + ((long)bb * nres + rr) * d.ld_pair;   // row (m / nres^2) * nres + m % nres
       }
       const float rs = d.rowscale ? d.rowscale[m] : 1.f;
+      float* crow = C + (long)m * d.ldc;
+      const float* grow = d.gate ? d.gate + (long)m * d.ld_gate : nullptr;
+      const float* rrow = d.resid ? d.resid + (long)m * d.ld_resid : nullptr;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int n = n_base + j * 32 + l31;
-        if (n >= d.N) continue;
-        float v = d.alpha * acc[i][j][r];
-        if (d.bias) v += d.bias[n];
-        if (d.pair_p) v += d.pair_p[prow * d.ld_pair + n] + d.pair_q[qrow * d.ld_pair + n];
+        if (!nok[j]) continue;
+        const int n = ncol[j];
+        float v = d.alpha * acc[i][j][r] + bj[j];
+        if (pp) v += pp[n] + pq[n];
         if (d.relu) v = v > 0.f ? v : 0.f;
-        if (d.gate) v = d.gate[(long)m * d.ld_gate + n] > 0.f ? v : 0.f;
+        if (grow) v = grow[n] > 0.f ? v : 0.f;
         v *= rs;
-        if (d.resid) v += d.resid[(long)m * d.ld_resid + n];
-        float* cp = C + (long)m * d.ldc + n;
-        if (d.beta) v += *cp;
-        *cp = v;
+        if (rrow) v += rrow[n];
+        if (d.beta) v += crow[n];
+        crow[n] = v;
       }
     }
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC, bool FAST>
+template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC, bool FAST, bool ROWSUM = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   constexpr int TM = BM / WGM / 32;
   constexpr int TN = BN / WGN / 32;
@@ -298,6 +324,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   for (int j = 0; j < TN; ++j) read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + l31, 0, h, b[0][j]);
 
   int c_t = 0, c_k = 0;   // (tile, k-tile) being multiplied
+  const bool do_rowsum = ROWSUM && (d.a_rowsum != nullptr) && bn == 0 && wn == 0 && z == 0;
+  float rsum[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rsum[i] = 0.f;
   auto body = [&](int it, float4 (&xa)[Stager<BM, A_KC, FAST>::NV], float4 (&xb)[Stager<BN, B_KC, FAST>::NV]) {
     // xa/xb: the register set holding tile it+1 (stored here, then refilled with tile it+3)
     const float* Ac = As + cur * LDS_STAGE;
@@ -323,9 +353,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         sb.store(xb, Bn, tid);
       }
       if (q == 1 && it + 3 < total) issue_load(xa, xb);
+      if (ROWSUM && do_rowsum) {
+        // fused bias gradient: row sums of A over k (A = dY^T in dW = dY^T X), from the fragments already in registers
+#pragma unroll
+        for (int i = 0; i < TM; ++i) rsum[i] += (a[q & 1][i][0] + a[q & 1][i][1]) + (a[q & 1][i][2] + a[q & 1][i][3]);
+      }
     }
     if (++c_k == nk) {
       store_tile<TM, TN>(d, C, acc, (mt0 + c_t) * BM + wm * TM * 32, n0 + wn * TN * 32, h, l31, g.ksplit > 1);
+      if (ROWSUM && do_rowsum) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float tot = rsum[i] + __shfl_xor(rsum[i], 32);   // the two lane halves hold disjoint k subsets
+          const int m = (mt0 + c_t) * BM + (wm * TM + i) * 32 + l31;
+          if (h == 0 && m < d.M) atomicAdd(d.a_rowsum + m, d.alpha * tot);
+          rsum[i] = 0.f;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -389,6 +433,13 @@ int launch_cfg(const FdGemmDesc& d, hipStream_t stream) {
   }
   const int nblk_mg = (g.nblk_m + g.mtiles - 1) / g.mtiles;
   dim3 grid(nblk_mg * g.nblk_n, nb, g.ksplit), block(256, 1, 1);
+  if constexpr (BM == 64 && BN == 64 && FAST) {
+    if (d.a_rowsum && !a_kc && !b_kc) {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, false, false, true, true>), grid, block, 0, stream, g);
+      FD_CHECK_LAUNCH("fd_gemm");
+      return FD_OK;
+    }
+  }
   if (a_kc && b_kc)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, true, true, FAST>), grid, block, 0, stream, g);
   else if (a_kc && !b_kc)
@@ -428,6 +479,14 @@ extern "C" int fd_gemm(const FdGemmDesc* desc, void* stream_) {
   }
   const bool fast = operands_vectorisable(d);
   if (!fast && cfg == 1) cfg = 2;   // the element-wise staging path is only instantiated for the small tiles
+  if (d.a_rowsum && !(cfg == 2 && fast && d.a_cs != 1 && d.b_rs != 1)) {
+    // the fused row-sum lives in one instantiation (64x64, both operands row-contiguous = the dW = dY^T X case);
+    // anything else takes the stand-alone column-sum kernel
+    FD_CHECK_ARG(d.a_rs == 1 && d.alpha == 1.0f && (d.batch <= 1), "fd_gemm: a_rowsum needs a row-contiguous A, alpha 1, no batch");
+    int rc = fd_colsum_acc(d.A, d.a_cs, d.K, d.M, d.a_rowsum, stream_);
+    if (rc != FD_OK) return rc;
+    d.a_rowsum = nullptr;
+  }
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, true>(d, stream);
     case 2: return fast ? launch_cfg<64, 64, 2, 2, true>(d, stream) : launch_cfg<64, 64, 2, 2, false>(d, stream);

@@ -42,6 +42,7 @@ class FdGemmDesc(Structure):
         ("gate", c_void_p), ("ld_gate", c_long),
         ("rowscale", c_void_p),
         ("relu", c_int), ("tile", c_int), ("ksplit", c_int), ("mtiles", c_int),
+        ("a_rowsum", c_void_p),
     ]
 
 
@@ -166,7 +167,7 @@ class FdLib:
     def gemm(self, A, B, C, M, N, K, a_str, b_str, ldc, *, a_off=0, b_off=0, c_off=0,
              batch=1, bdiv=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), alpha=1.0, beta=False,
              bias=None, pair=None, resid=None, ld_resid=0, gate=None, ld_gate=0,
-             rowscale=None, relu=False, tile=0, ksplit=1, mtiles=0):
+             rowscale=None, relu=False, tile=0, ksplit=1, mtiles=0, a_rowsum=None):
         d = FdGemmDesc()
         d.A, d.B, d.C = _ptr(A, a_off), _ptr(B, b_off), _ptr(C, c_off)
         d.M, d.N, d.K = int(M), int(N), int(K)
@@ -188,6 +189,7 @@ class FdLib:
         d.gate, d.ld_gate = _ptr(gate), ld_gate
         d.rowscale = _ptr(rowscale)
         d.relu, d.tile, d.ksplit, d.mtiles = int(bool(relu)), int(tile), int(ksplit), int(mtiles)
+        d.a_rowsum = _ptr(a_rowsum)
         for x in (bias, resid, gate, rowscale):
             if x is not None:
                 tens.append(x[0] if isinstance(x, tuple) else x)

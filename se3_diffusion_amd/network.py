@@ -53,11 +53,12 @@ def check_conf(conf):
 def _lin_grads(G, wname, bname, dy, x, M, N, K, w_off=0, w_ld=None):
     if G is None:
         return
+    db = G[bname] if (bname is not None and bname in G) else None
     if wname in G:
         W = G[wname]
-        ops.linear_dw(dy, x, (W, w_off, w_ld if w_ld is not None else W.shape[1]), M, N, K)
-    if bname is not None and bname in G:
-        ops.bias_grad(dy, G[bname], M, N)
+        ops.linear_dw(dy, x, (W, w_off, w_ld if w_ld is not None else W.shape[1]), M, N, K, db=db)
+    elif db is not None:
+        ops.bias_grad(dy, db, M, N)
 
 
 # --------------------------------------------------------------------------- embedder

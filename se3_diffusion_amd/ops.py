@@ -65,15 +65,16 @@ def _ksplit(mn_blocks, K):
     return ks
 
 
-def linear_dw(dy, x, dW, M, N, K):
-    """dW[N,K] += dy[M,N]^T @ x[M,K]  (reduction over the M rows; split-K)."""
+def linear_dw(dy, x, dW, M, N, K, db=None):
+    """dW[N,K] += dy[M,N]^T @ x[M,K]  (reduction over the M rows; split-K); db[N] += sum_m dy[m,:] fused
+    into the same kernel (row sums of the A = dy^T operand)."""
     dt, do, dl = dy
     xt, xo, xl = x
     wt, wo, wl = dW
     blocks = ((N + 63) // 64) * ((K + 63) // 64)
     ks = _ksplit(blocks, M)
     lib().gemm(dt, xt, wt, N, K, M, (1, dl), (xl, 1), wl, a_off=do, b_off=xo, c_off=wo,
-               beta=(ks == 1), ksplit=ks, tile=2)
+               beta=(ks == 1), ksplit=ks, tile=2, a_rowsum=db)
 
 
 def add_view(dst, src, rows, cols, alpha=1.0):
