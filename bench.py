@@ -211,8 +211,17 @@ def main():
     if rank != 0:
         return
     # dominant kernel: gemm_kernel<128,128,2,2,*,*> (tile 1)
+    if os.environ.get("FD_BENCH_GEMM_DETAIL"):
+        shapes = {}
+        for p in prof:
+            s = shapes.setdefault((p[0], p[1], p[2]) + p[6], [0.0, 0.0, 0])
+            s[0] += p[3]; s[1] += p[4].elapsed_time(p[5]) * 1e-3; s[2] += 1
+        rows = sorted(shapes.items(), key=lambda kv: -kv[1][1])
+        sys.stderr.write("tile akc bkc (M,N,K,batch,gate,beta,pair,ksplit)  calls/step  ms/step  TF/s\n")
+        for k, v in rows[:40]:
+            sys.stderr.write(f"{k}  {v[2] / a.steps:.1f}  {v[1] / a.steps * 1e3:.3f}  {v[0] / v[1] / 1e12:.1f}\n")
     by = {}
-    for tile, akc, bkc, flops, e0, e1 in prof:
+    for tile, akc, bkc, flops, e0, e1, _shape in prof:
         k = (tile, akc, bkc)
         s = by.setdefault(k, [0.0, 0.0, 0])
         s[0] += flops

@@ -176,22 +176,28 @@ __device__ __forceinline__ void store_tile(const FdGemmDesc& d, float* __restric
       }
     return;
   }
-  // per-column constants hoisted; the pair (b,i,j) decode of a row is one division per 32-row block, then carries
+  // Branch-free operand fetch: row / column indices are CLAMPED into range for every epilogue load (gate, pair,
+  // residual, old C) and only the final store is predicated, so the compiler can hoist and batch all loads of the
+  // unrolled (row, column) loop instead of one exec-masked load-use pair at a time.  The pair (b,i,j) decode of a
+  // row is one division per 32-row block, then carries.
   bool nok[TN];
   float bj[TN];
   int ncol[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    ncol[j] = n_base + j * 32 + l31;
-    nok[j] = ncol[j] < d.N;
-    bj[j] = (d.bias && nok[j]) ? d.bias[ncol[j]] : 0.f;
+    const int n = n_base + j * 32 + l31;
+    nok[j] = n < d.N;
+    ncol[j] = nok[j] ? n : d.N - 1;
+    bj[j] = d.bias ? d.bias[ncol[j]] : 0.f;
   }
   const int nres = d.nres;
+  const bool has_pair = d.pair_p != nullptr, has_gate = d.gate != nullptr, has_res = d.resid != nullptr;
+  const bool has_rs = d.rowscale != nullptr, has_beta = d.beta != 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int mi = m_base + i * 32;
     int rr0 = 0, ii0 = 0, bb0 = 0;
-    if (d.pair_p) {
+    if (has_pair) {
       const int q0 = mi / nres;
       rr0 = mi - q0 * nres;
       bb0 = q0 / nres;
@@ -200,35 +206,35 @@ __device__ __forceinline__ void store_tile(const FdGemmDesc& d, float* __restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int m = mi + o;
-      if (m >= d.M) continue;
-      const float* pp = nullptr;
-      const float* pq = nullptr;
-      if (d.pair_p) {
+      const bool mok = mi + o < d.M;
+      const int m = mok ? mi + o : d.M - 1;
+      const float* pp = C;
+      const float* pq = C;
+      if (has_pair) {
         int rr = rr0 + o, ii = ii0, bb = bb0;
         while (rr >= nres) {
           rr -= nres;
           if (++ii == nres) { ii = 0; ++bb; }
         }
+        if (!mok) { rr = 0; ii = 0; bb = 0; }
         pp = d.pair_p + ((long)bb * nres + ii) * d.ld_pair;   // row m / nres
         pq = d.pair_q + ((long)bb * nres + rr) * d.ld_pair;   // row (m / nres^2) * nres + m % nres
       }
-      const float rs = d.rowscale ? d.rowscale[m] : 1.f;
+      const float rs = has_rs ? d.rowscale[m] : 1.f;
       float* crow = C + (long)m * d.ldc;
-      const float* grow = d.gate ? d.gate + (long)m * d.ld_gate : nullptr;
-      const float* rrow = d.resid ? d.resid + (long)m * d.ld_resid : nullptr;
+      const float* grow = has_gate ? d.gate + (long)m * d.ld_gate : C;
+      const float* rrow = has_res ? d.resid + (long)m * d.ld_resid : C;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if (!nok[j]) continue;
         const int n = ncol[j];
         float v = d.alpha * acc[i][j][r] + bj[j];
-        if (pp) v += pp[n] + pq[n];
+        if (has_pair) v += pp[n] + pq[n];
         if (d.relu) v = v > 0.f ? v : 0.f;
-        if (grow) v = grow[n] > 0.f ? v : 0.f;
+        if (has_gate) v = grow[n] > 0.f ? v : 0.f;
         v *= rs;
-        if (rrow) v += rrow[n];
-        if (d.beta) v += crow[n];
-        crow[n] = v;
+        if (has_res) v += rrow[n];
+        if (has_beta) v += crow[n];
+        if (mok && nok[j]) crow[n] = v;
       }
     }
   }

@@ -203,7 +203,8 @@ class FdLib:
             e0.record()
             self._check(self.cdll.fd_gemm(ctypes.byref(d), stream), "fd_gemm")
             e1.record()
-            prof.append((d.tile, d.a_cs == 1, d.b_rs == 1, 2.0 * d.M * d.N * d.K * max(1, batch), e0, e1))
+            prof.append((d.tile, d.a_cs == 1, d.b_rs == 1, 2.0 * d.M * d.N * d.K * max(1, batch), e0, e1,
+                         (d.M, d.N, d.K, max(1, batch), int(bool(d.gate)), d.beta, int(bool(d.pair_p)), d.ksplit)))
             return
         self._check(self.cdll.fd_gemm(ctypes.byref(d), stream), "fd_gemm")
 

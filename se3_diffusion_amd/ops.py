@@ -71,10 +71,12 @@ def linear_dw(dy, x, dW, M, N, K, db=None):
     dt, do, dl = dy
     xt, xo, xl = x
     wt, wo, wl = dW
-    blocks = ((N + 63) // 64) * ((K + 63) // 64)
-    ks = _ksplit(blocks, M)
+    # output is tiny (N x K weights), the reduction (M rows) is huge: split K so that ~2300 blocks exist
+    tile, t = (1, 128) if (N >= 256 and K >= 256 and db is None) else (2, 64)
+    blocks = ((N + t - 1) // t) * ((K + t - 1) // t)
+    ks = max(1, min(2304 // max(1, blocks), M // 256))
     lib().gemm(dt, xt, wt, N, K, M, (1, dl), (xl, 1), wl, a_off=do, b_off=xo, c_off=wo,
-               beta=(ks == 1), ksplit=ks, tile=2, a_rowsum=db)
+               beta=(ks == 1), ksplit=ks, tile=tile, a_rowsum=db)
 
 
 def add_view(dst, src, rows, cols, alpha=1.0):
