@@ -35,6 +35,7 @@ struct GemmArgs {
   int nblk_m, nblk_n;
   int ksplit;
   int mtiles;   // consecutive M tiles pipelined by one block
+  int epi_vec;  // 16-byte epilogue through LDS (needs mtiles == 1 and 4-element aligned C / gate / resid / pair)
 };
 
 // Stages a ROWS x BK operand tile: global -> registers (load) -> LDS (store).
@@ -240,6 +241,75 @@ __device__ __forceinline__ void store_tile(const FdGemmDesc& d, float* __restric
   }
 }
 
+// Vector epilogue: the accumulator tile is transposed through LDS so that every thread owns 4 consecutive columns
+// of a row -- C, gate, residual and pair operands then move as 16-byte accesses (4x fewer memory instructions than
+// the fragment-shaped scalar epilogue, which is what bounds the short-K GEMMs of the backward pass).
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void store_tile_vec(const FdGemmDesc& d, float* __restrict__ C, f32x16 (&acc)[TM][TN],
+                                               float* __restrict__ lds, int m0, int n0, int wm, int wn, int h, int l31,
+                                               int tid) {
+  constexpr int PITCH = BN + 4;
+  __syncthreads();   // every wave is done reading operand fragments from LDS
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        lds[row * PITCH + (wn * TN + j) * 32 + l31] = acc[i][j][r];
+      }
+  __syncthreads();
+  constexpr int C4 = BN / 4;          // float4 columns per row
+  constexpr int RPP = 256 / C4;       // rows per pass
+  const int c4 = tid % C4, r0 = tid / C4;
+  const int n = n0 + 4 * c4;
+  const bool nok = n < d.N;            // N % 4 == 0: the whole float4 is in or out
+  const int nc = nok ? n : 0;
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (d.bias) b4 = *reinterpret_cast<const float4*>(d.bias + nc);
+  const bool has_pair = d.pair_p != nullptr, has_gate = d.gate != nullptr, has_res = d.resid != nullptr;
+  const bool has_rs = d.rowscale != nullptr, has_beta = d.beta != 0;
+  const int nres = d.nres;
+#pragma unroll 4
+  for (int p = 0; p < BM / RPP; ++p) {
+    const int row = p * RPP + r0;
+    const bool mok = m0 + row < d.M;
+    const int m = mok ? m0 + row : d.M - 1;
+    const float4 a4 = *reinterpret_cast<const float4*>(&lds[row * PITCH + 4 * c4]);
+    float4 v = make_float4(d.alpha * a4.x + b4.x, d.alpha * a4.y + b4.y, d.alpha * a4.z + b4.z, d.alpha * a4.w + b4.w);
+    if (has_pair) {
+      const int q = m / nres;
+      const int jj = m - q * nres;
+      const int bb = q / nres;
+      const float4 pp = *reinterpret_cast<const float4*>(d.pair_p + (long)q * d.ld_pair + nc);
+      const float4 pq = *reinterpret_cast<const float4*>(d.pair_q + ((long)bb * nres + jj) * d.ld_pair + nc);
+      v.x += pp.x + pq.x; v.y += pp.y + pq.y; v.z += pp.z + pq.z; v.w += pp.w + pq.w;
+    }
+    if (d.relu) {
+      v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+    }
+    if (has_gate) {
+      const float4 g4 = *reinterpret_cast<const float4*>(d.gate + (long)m * d.ld_gate + nc);
+      v.x = g4.x > 0.f ? v.x : 0.f; v.y = g4.y > 0.f ? v.y : 0.f; v.z = g4.z > 0.f ? v.z : 0.f; v.w = g4.w > 0.f ? v.w : 0.f;
+    }
+    if (has_rs) {
+      const float rs = d.rowscale[m];
+      v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
+    }
+    if (has_res) {
+      const float4 r4 = *reinterpret_cast<const float4*>(d.resid + (long)m * d.ld_resid + nc);
+      v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+    }
+    float* cp = C + (long)m * d.ldc + nc;
+    if (has_beta) {
+      const float4 c4v = *reinterpret_cast<const float4*>(cp);
+      v.x += c4v.x; v.y += c4v.y; v.z += c4v.z; v.w += c4v.w;
+    }
+    if (mok && nok) *reinterpret_cast<float4*>(cp) = v;
+  }
+}
+
 template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC, bool FAST, bool ROWSUM = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   constexpr int TM = BM / WGM / 32;
@@ -366,7 +436,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       }
     }
     if (++c_k == nk) {
-      store_tile<TM, TN>(d, C, acc, (mt0 + c_t) * BM + wm * TM * 32, n0 + wn * TN * 32, h, l31, g.ksplit > 1);
+      if (g.epi_vec)
+        store_tile_vec<BM, BN, TM, TN>(d, C, acc, lds, (mt0 + c_t) * BM, n0, wm, wn, h, l31, tid);
+      else
+        store_tile<TM, TN>(d, C, acc, (mt0 + c_t) * BM + wm * TM * 32, n0 + wn * TN * 32, h, l31, g.ksplit > 1);
       if (ROWSUM && do_rowsum) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -436,6 +509,16 @@ int launch_cfg(const FdGemmDesc& d, hipStream_t stream) {
     long t = blocks / 2304;
     g.mtiles = (int)(t < 1 ? 1 : (t > 16 ? 16 : t));
     if (d.mtiles > 0) g.mtiles = d.mtiles;
+  }
+  {
+    auto al4 = [](long x) { return (x & 3) == 0; };
+    bool ok = g.ksplit == 1 && al4(d.N) && al4(d.ldc) && fd_aligned16(d.C) && al4(d.c_so) && al4(d.c_si);
+    if (d.bias) ok = ok && fd_aligned16(d.bias);
+    if (d.gate) ok = ok && fd_aligned16(d.gate) && al4(d.ld_gate);
+    if (d.resid) ok = ok && fd_aligned16(d.resid) && al4(d.ld_resid);
+    if (d.pair_p) ok = ok && fd_aligned16(d.pair_p) && fd_aligned16(d.pair_q) && al4(d.ld_pair);
+    g.epi_vec = ok && (d.mtiles <= 1);
+    if (g.epi_vec) g.mtiles = 1;
   }
   const int nblk_mg = (g.nblk_m + g.mtiles - 1) / g.mtiles;
   dim3 grid(nblk_mg * g.nblk_n, nb, g.ksplit), block(256, 1, 1);
