@@ -17,10 +17,8 @@ Stage list per trunk block b (A3 of SURVEY.md):
 """
 from __future__ import annotations
 
-import ctypes
 import math
 
-import numpy as np
 import torch
 
 from . import hip, ops
