@@ -173,6 +173,7 @@ def main():
     batch = ts.synthetic_batch(B, N, dev, seed=100 + rank)
     gt37, _ = ts.backbone_atoms(batch["rigids_0"], batch["torsion_angles_sin_cos"][..., 2, :])
     grads = fdist.FlatGrads(model.parameters())
+    model.accumulate_into_grad = True      # backward kernels accumulate straight into the flat all-reduce buffer
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
 
     def step():

@@ -74,7 +74,7 @@ class _ScoreNetFn(torch.autograd.Function):
         bool_mask = (not module.training) and not need_grad       # nn.TransformerEncoder fast-path semantics
         out, sv = trunk.forward(P, feats, module._num_blocks, module._dconf, tfmr_bool_mask=bool_mask,
                                 save=need_grad)
-        ctx.sv, ctx.P, ctx.names = sv, P, names
+        ctx.sv, ctx.P, ctx.names, ctx.module = sv, P, names, module
         res = tuple(out[k] for k in _OUT_KEYS)
         ctx.mark_non_differentiable(res[5])
         return res
@@ -82,8 +82,16 @@ class _ScoreNetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_psi, d_rot, d_ts, d_rig, d_a37, d_a14):
         P, names = ctx.P, ctx.names
-        G = {k: torch.zeros_like(v) for k, v in P.items()}
         d_out = dict(psi=d_psi, rot_score=d_rot, trans_score=d_ts, rigids=d_rig, atom37=d_a37)
+        if ctx.module.accumulate_into_grad and all(p.grad is not None for p in P.values()):
+            # every kernel of the backward ACCUMULATES (+=) its parameter gradient, so when the caller pre-allocates
+            # .grad (e.g. dist.FlatGrads: one flat buffer for the single RCCL all-reduce) the gradients are written
+            # in place -- no 282 zero-fills + 282 autograd accumulation kernels per step
+            G = {k: v.grad for k, v in P.items()}
+            trunk.backward(P, G, ctx.sv, d_out)
+            ctx.sv = None
+            return (None, None, None, None) + tuple(None for _ in names)
+        G = {k: torch.zeros_like(v) for k, v in P.items()}
         trunk.backward(P, G, ctx.sv, d_out)
         ctx.sv = None
         return (None, None, None, None) + tuple(G[n] for n in names)
@@ -99,6 +107,9 @@ class ScoreNetwork(nn.Module):
         self.diffuser = diffuser
         self.score_model = ipa_pytorch.IpaScore(model_conf, diffuser)
         self._num_blocks = model_conf.ipa.num_blocks
+        # opt-in (bench.py / dist.FlatGrads): write parameter gradients straight into pre-allocated .grad tensors.
+        # Leave False under torch DDP, whose reducer hooks the autograd accumulation.
+        self.accumulate_into_grad = False
         self._dconf = _diffuser_consts(model_conf, diffuser)
 
     def _apply_mask(self, aatype_diff, aatype_0, diff_mask):

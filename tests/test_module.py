@@ -57,6 +57,29 @@ def test_train_step_emu(use_emu):
     _train_step("cpu", B=2, N=8, blocks=1)
 
 
+def test_inplace_grad_accumulation_emu(use_emu):
+    """accumulate_into_grad=True (bench.py / dist.FlatGrads) gives the same gradients as the autograd path."""
+    from se3_diffusion_amd import dist as fdist
+    conf = dict(fo.CONF, num_blocks=1)
+    P = fo.synth_params(seed=12, conf=conf)
+    batch = ts.synthetic_batch(1, 8, "cpu", seed=6)
+    gt37, _ = fo.backbone_atoms(batch["rigids_0"][..., :4], batch["rigids_0"][..., 4:], batch["torsion_angles_sin_cos"][..., 2, :])
+    grads = []
+    for inplace in (False, True):
+        m = ScoreNetwork(ts.base_model_conf(1), diffuser=None)
+        m.load_state_dict(P, strict=True)
+        m.train()
+        if inplace:
+            flat = fdist.FlatGrads(m.parameters())
+            m.accumulate_into_grad = True
+        ts.dsm_loss(batch, m(batch), gt37).backward()
+        grads.append({n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters()})
+        if inplace:
+            assert float(flat.flat.abs().sum()) > 0
+    for n in grads[0]:
+        assert torch.allclose(grads[0][n], grads[1][n], rtol=1e-4, atol=1e-6), n
+
+
 def test_backbone_atoms_emu(use_emu):
     f = fo.synth_feats(2, 7, seed=3)
     psi = f["torsion_angles_sin_cos"][..., 2, :]
