@@ -57,7 +57,10 @@ typedef struct FdGemmDesc {
   long ld_gate;
   const float* rowscale; /* [M] */
   int relu;
-  int tile;              /* 0 = auto; 1: 128x128, 2: 64x64, 3: 128x32 */
+  int tile;              /* 0 = auto; fp32 MFMA (bitwise an fmaf chain over k): 1: 128x128, 2: 64x64, 3: 128x32;
+                            4: 256x128 split-bf16 (each fp32 operand = 3 exact bf16 terms, 6 bf16-MFMA products,
+                            fp32 accumulate: fp32 accuracy, not bitwise the fmaf chain).  Auto picks 4 for the
+                            large pair-level GEMMs unless FD_GEMM_EXACT_F32=1 is set in the environment. */
   int ksplit;            /* >1: split K over blocks, C += alpha*A*B atomically
                             (weight gradients: tiny MxN, huge K); epilogue-free */
   int mtiles;            /* 0 = auto; >0: consecutive M tiles pipelined per block (un-batched, ksplit 1) */
@@ -66,6 +69,8 @@ typedef struct FdGemmDesc {
 } FdGemmDesc;
 
 int fd_gemm(const FdGemmDesc* desc, void* stream);
+/* the tile code (1..4) fd_gemm would run this descriptor with; no launch */
+int fd_gemm_plan(const FdGemmDesc* desc);
 
 /* ---- LayerNorm / reductions (HBM-bound) -------------------------------
  * torch.nn.LayerNorm (eps 1e-5, biased variance) at score_network.py:73,85,

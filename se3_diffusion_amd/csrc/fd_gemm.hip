@@ -244,7 +244,7 @@ __device__ __forceinline__ void store_tile(const FdGemmDesc& d, float* __restric
 // Vector epilogue: the accumulator tile is transposed through LDS so that every thread owns 4 consecutive columns
 // of a row -- C, gate, residual and pair operands then move as 16-byte accesses (4x fewer memory instructions than
 // the fragment-shaped scalar epilogue, which is what bounds the short-K GEMMs of the backward pass).
-template <int BM, int BN, int TM, int TN>
+template <int BM, int BN, int TM, int TN, int NTHR = 256>
 __device__ __forceinline__ void store_tile_vec(const FdGemmDesc& d, float* __restrict__ C, f32x16 (&acc)[TM][TN],
                                                float* __restrict__ lds, int m0, int n0, int wm, int wn, int h, int l31,
                                                int tid) {
@@ -261,7 +261,7 @@ __device__ __forceinline__ void store_tile_vec(const FdGemmDesc& d, float* __res
       }
   __syncthreads();
   constexpr int C4 = BN / 4;          // float4 columns per row
-  constexpr int RPP = 256 / C4;       // rows per pass
+  constexpr int RPP = NTHR / C4;      // rows per pass
   const int c4 = tid % C4, r0 = tid / C4;
   const int n = n0 + 4 * c4;
   const bool nok = n < d.N;            // N % 4 == 0: the whole float4 is in or out
@@ -473,6 +473,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   }
 }
 
+#include "fd_gemm_split.h"   // gemm_bx3_kernel: tile code 4
+
 // 16-byte staging is legal when the contiguous index is a multiple of 4 everywhere the kernel can touch it
 bool operands_vectorisable(const FdGemmDesc& d) {
   auto al4 = [](long x) { return (x & 3) == 0; };
@@ -486,6 +488,71 @@ bool operands_vectorisable(const FdGemmDesc& d) {
   else
     vb = (d.b_cs == 1) && fd_aligned16(d.B) && al4(d.b_rs) && al4(d.N) && al4(d.b_so) && al4(d.b_si);
   return va && vb;
+}
+
+// the LDS-transposed float4 epilogue needs 4-element aligned C / bias / gate / residual / pair operands
+bool epilogue_vectorisable(const FdGemmDesc& d, int ksplit) {
+  auto al4 = [](long x) { return (x & 3) == 0; };
+  bool ok = ksplit == 1 && al4(d.N) && al4(d.ldc) && fd_aligned16(d.C) && al4(d.c_so) && al4(d.c_si);
+  if (d.bias) ok = ok && fd_aligned16(d.bias);
+  if (d.gate) ok = ok && fd_aligned16(d.gate) && al4(d.ld_gate);
+  if (d.resid) ok = ok && fd_aligned16(d.resid) && al4(d.ld_resid);
+  if (d.pair_p) ok = ok && fd_aligned16(d.pair_p) && fd_aligned16(d.pair_q) && al4(d.ld_pair);
+  return ok;
+}
+
+// split-bf16 kernel: instantiated for A k-contiguous (activations [rows, features]) with either B layout
+// (y = x W^T and dx = dy W) and for both operands row-contiguous (dW = dY^T X)
+bool bx3_layout_ok(const FdGemmDesc& d) {
+  const bool a_kc = (d.a_cs == 1), b_kc = (d.b_rs == 1);
+  return a_kc || (!a_kc && !b_kc);
+}
+
+int launch_bx3(const FdGemmDesc& d, hipStream_t stream) {
+  GemmArgs g;
+  g.d = d;
+  g.nblk_m = fd_cdiv(d.M, XBM);
+  g.nblk_n = fd_cdiv(d.N, XBN);
+  const int nb = d.batch > 0 ? d.batch : 1;
+  g.ksplit = d.ksplit > 1 ? d.ksplit : 1;
+  const int nkt_all = fd_cdiv(d.K, XBK);
+  if (g.ksplit > nkt_all) g.ksplit = nkt_all > 0 ? nkt_all : 1;
+  g.mtiles = 1;
+  g.epi_vec = epilogue_vectorisable(d, g.ksplit);
+  const bool a_kc = (d.a_cs == 1), b_kc = (d.b_rs == 1);
+  dim3 grid(g.nblk_m * g.nblk_n, nb, g.ksplit), block(XTHR, 1, 1);
+  if (a_kc && b_kc)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<true, true>), grid, block, 0, stream, g);
+  else if (a_kc && !b_kc)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<true, false>), grid, block, 0, stream, g);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<false, false>), grid, block, 0, stream, g);
+  FD_CHECK_LAUNCH("fd_gemm(split-bf16)");
+  return FD_OK;
+}
+
+// FD_GEMM_EXACT_F32=1 keeps every GEMM on the fp32-MFMA (fmaf-chain) kernels
+bool split_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("FD_GEMM_EXACT_F32");
+    return !(e && e[0] && e[0] != '0');
+  }();
+  return on;
+}
+
+// tile selection: 1 = 128x128, 2 = 64x64, 3 = 128x32 (fp32 MFMA); 4 = 256x128 split-bf16.
+// Wide tiles when the problem fills the chip, narrow otherwise.
+int plan_tile(const FdGemmDesc& d, bool fast) {
+  int cfg = d.tile;
+  if (cfg == 0) {
+    const long blocks128 = (long)fd_cdiv(d.M, 128) * fd_cdiv(d.N, 128) * (d.batch > 0 ? d.batch : 1);
+    if (d.N <= 48) cfg = 3;
+    else if (blocks128 >= 512 && d.N >= 96) cfg = 1;
+    else cfg = 2;
+    if (cfg == 1 && fast && d.K >= 64 && bx3_layout_ok(d) && split_enabled()) cfg = 4;
+  }
+  if (!fast && cfg == 1) cfg = 2;   // the element-wise staging path is only instantiated for the small tiles
+  return cfg;
 }
 
 template <int BM, int BN, int WGM, int WGN, bool FAST>
@@ -510,16 +577,8 @@ int launch_cfg(const FdGemmDesc& d, hipStream_t stream) {
     g.mtiles = (int)(t < 1 ? 1 : (t > 16 ? 16 : t));
     if (d.mtiles > 0) g.mtiles = d.mtiles;
   }
-  {
-    auto al4 = [](long x) { return (x & 3) == 0; };
-    bool ok = g.ksplit == 1 && al4(d.N) && al4(d.ldc) && fd_aligned16(d.C) && al4(d.c_so) && al4(d.c_si);
-    if (d.bias) ok = ok && fd_aligned16(d.bias);
-    if (d.gate) ok = ok && fd_aligned16(d.gate) && al4(d.ld_gate);
-    if (d.resid) ok = ok && fd_aligned16(d.resid) && al4(d.ld_resid);
-    if (d.pair_p) ok = ok && fd_aligned16(d.pair_p) && fd_aligned16(d.pair_q) && al4(d.ld_pair);
-    g.epi_vec = ok && (d.mtiles <= 1);
-    if (g.epi_vec) g.mtiles = 1;
-  }
+  g.epi_vec = epilogue_vectorisable(d, g.ksplit) && (d.mtiles <= 1);
+  if (g.epi_vec) g.mtiles = 1;
   const int nblk_mg = (g.nblk_m + g.mtiles - 1) / g.mtiles;
   dim3 grid(nblk_mg * g.nblk_n, nb, g.ksplit), block(256, 1, 1);
   if constexpr (BM == 64 && BN == 64 && FAST) {
@@ -543,6 +602,11 @@ int launch_cfg(const FdGemmDesc& d, hipStream_t stream) {
 
 }  // namespace
 
+extern "C" int fd_gemm_plan(const FdGemmDesc* desc) {
+  FD_CHECK_ARG(desc != nullptr, "fd_gemm_plan: null descriptor");
+  return plan_tile(*desc, operands_vectorisable(*desc));
+}
+
 extern "C" int fd_gemm(const FdGemmDesc* desc, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   FD_CHECK_ARG(desc != nullptr, "fd_gemm: null descriptor");
@@ -558,19 +622,14 @@ extern "C" int fd_gemm(const FdGemmDesc* desc, void* stream_) {
     FD_CHECK_ARG(!d.bias && !d.pair_p && !d.resid && !d.gate && !d.rowscale && !d.relu,
                  "fd_gemm: split-K accumulates alpha*A*B into C; no other epilogue allowed");
   }
-  // tile selection: wide tiles when the problem fills the chip, narrow otherwise
-  const long blocks128 = (long)fd_cdiv(d.M, 128) * fd_cdiv(d.N, 128) * (d.batch > 0 ? d.batch : 1);
-  int cfg = d.tile;
-  if (cfg == 0) {
-    if (d.N <= 48) cfg = 3;
-    else if (blocks128 >= 512 && d.N >= 96) cfg = 1;
-    else cfg = 2;
-  }
   const bool fast = operands_vectorisable(d);
-  if (!fast && cfg == 1) cfg = 2;   // the element-wise staging path is only instantiated for the small tiles
-  if (d.a_rowsum && !(cfg == 2 && fast && d.a_cs != 1 && d.b_rs != 1)) {
-    // the fused row-sum lives in one instantiation (64x64, both operands row-contiguous = the dW = dY^T X case);
-    // anything else takes the stand-alone column-sum kernel
+  const int cfg = plan_tile(d, fast);
+  if (cfg == 4)
+    FD_CHECK_ARG(fast && bx3_layout_ok(d), "fd_gemm: tile 4 (split-bf16) needs 16-byte aligned operands and a k-contiguous A "
+                                           "or both operands row-contiguous");
+  if (d.a_rowsum && !((cfg == 2 || cfg == 4) && fast && d.a_cs != 1 && d.b_rs != 1 && d.batch <= 1)) {
+    // the fused row-sum lives in the instantiations with both operands row-contiguous (the dW = dY^T X case) of
+    // the 64x64 fp32 kernel and the split-bf16 kernel; anything else takes the stand-alone column-sum kernel
     FD_CHECK_ARG(d.a_rs == 1 && d.alpha == 1.0f && (d.batch <= 1), "fd_gemm: a_rowsum needs a row-contiguous A, alpha 1, no batch");
     int rc = fd_colsum_acc(d.A, d.a_cs, d.K, d.M, d.a_rowsum, stream_);
     if (rc != FD_OK) return rc;
@@ -580,6 +639,7 @@ extern "C" int fd_gemm(const FdGemmDesc* desc, void* stream_) {
     case 1: return launch_cfg<128, 128, 2, 2, true>(d, stream);
     case 2: return fast ? launch_cfg<64, 64, 2, 2, true>(d, stream) : launch_cfg<64, 64, 2, 2, false>(d, stream);
     case 3: return fast ? launch_cfg<128, 32, 4, 1, true>(d, stream) : launch_cfg<128, 32, 4, 1, false>(d, stream);
+    case 4: return launch_bx3(d, stream);
     default: fd_set_error("fd_gemm: bad tile config %d", cfg); return FD_ERR_ARG;
   }
 }

@@ -1,0 +1,290 @@
+// Split-bf16 GEMM kernel (fd_gemm tile code 4) for the pair-level GEMMs.  Included by fd_gemm.hip inside its
+// anonymous namespace (uses GemmArgs, store_tile, store_tile_vec, fd_xcd_swizzle).
+//
+// gfx950 runs the bf16 MFMA at 16x the fp32-MFMA rate.  An fp32 value splits EXACTLY into three bf16 terms
+// x = x0 + x1 + x2 (round-to-nearest at every stage: 3 x (8 bits + sign of the next residual) covers the 24-bit
+// significand), so  a*b = sum_{i,j} a_i*b_j  with every term an exact bf16 product.  The six terms with i+j <= 2
+// are accumulated in fp32 by v_mfma_f32_32x32x16_bf16; the three dropped terms are <= 2^-26 |a*b|, below the fp32
+// rounding of the product itself.  The result is an fp32-accurate GEMM (same error class as the fmaf-chain kernel;
+// tests/test_gemm.py measures both against fp64) at up to 16/6 = 2.7x its peak rate.
+//
+// Operands stay fp32 in HBM; the split happens in registers on the way global -> LDS (11 VALU ops per element
+// pair).  The block is wave-specialised so that this VALU work never sits in the instruction stream of a wave that
+// feeds the matrix pipe:
+//   * 8 consumer waves (4 x 2; wave tile 64 x 64 of the 256 x 128 block tile) issue only ds_read_b128 + MFMA;
+//   * 4 producer waves (one per SIMD) load later stages from global memory, split them and write them to LDS.
+// A stage is 16 k (one MFMA step) of every row: three 32-byte bf16 planes + 16 B pad = 112 B per row (7 x 16 B:
+// conflict-free ds_read_b128; the producer's row order makes every 8-lane ds_write_b128 group tile one 128-byte
+// bank window).  LDS holds a RING OF THREE stages: while the consumers multiply stage s out of registers they
+// prefetch the fragments of stage s+1 (complete since the previous barrier) and the producers fill stage s+2, so
+// the single barrier per stage never has an LDS read or a global load waiting behind it.
+constexpr int XBK = 16;
+constexpr int XROWB = 3 * XBK * 2 + 16;   // bytes per staged row
+constexpr int XCONS = 512;                // consumer (MFMA) threads: waves 0..7
+constexpr int XPROD = 256;                // producer (load + split + LDS store) threads: waves 8..11
+constexpr int XTHR = XCONS + XPROD;
+constexpr int XBM = 256, XBN = 128;
+constexpr int XSTAGE = (XBM + XBN) * XROWB;
+constexpr int XRING = 3;
+constexpr int XEPI = XBM * (XBN + 4) * 4;   // the vector epilogue transposes the C tile through LDS
+constexpr int XLDS = XRING * XSTAGE > XEPI ? XRING * XSTAGE : XEPI;
+static_assert(XLDS <= 160 * 1024, "LDS");
+static_assert(XBM == XPROD, "the fused row sum relies on producer thread t staging row t of a row-contiguous A");
+
+__device__ __forceinline__ void split8(const float (&x)[8], uint4& s0, uint4& s1, uint4& s2) {
+  unsigned t0[4], t1[4], t2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float u = x[2 * j], v = x[2 * j + 1];
+    const unsigned h = fd::pack_bf16(u, v);
+    const float ru = u - fd::bf16lo_f32(h), rv = v - fd::bf16hi_f32(h);
+    const unsigned m = fd::pack_bf16(ru, rv);
+    const float qu = ru - fd::bf16lo_f32(m), qv = rv - fd::bf16hi_f32(m);
+    t0[j] = h;
+    t1[j] = m;
+    t2[j] = fd::pack_bf16(qu, qv);
+  }
+  s0 = make_uint4(t0[0], t0[1], t0[2], t0[3]);
+  s1 = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+  s2 = make_uint4(t2[0], t2[1], t2[2], t2[3]);
+}
+
+// Stages a ROWS x 16 operand tile.  A slot = (row, group of 8 consecutive k).
+//   KC : k contiguous in memory   -> 2 x float4 per slot, 2 lanes per row
+//   !KC: row contiguous in memory -> 8 dword loads per slot (coalesced across the lanes = rows)
+template <int ROWS, bool KC>
+struct SplitStager {
+  static constexpr int NS = ROWS * 2 / XPROD;
+  const float* p[NS];
+  int kofs[NS];   // first k of the slot inside the stage
+  int lofs[NS];   // LDS byte offset of the slot (plane 0)
+  long kstep, cs;
+
+  __device__ __forceinline__ void init(const float* __restrict__ b, long rs_, long cs_, int row0, int nrows, int k0,
+                                       int tid) {
+    cs = cs_;
+    kstep = (long)XBK * cs_;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int f = tid + XPROD * i;   // tid = producer thread index
+      // KC: two lanes cover the 64 contiguous bytes a row contributes to a stage; the four rows of an 8-lane
+      // ds_write_b128 group are taken 2 apart (2 * 112 B = 96 mod 128: the group tiles one 32-bank window)
+      const int q = f >> 1;
+      const int row = KC ? ((q & ~7) | ((q & 3) << 1) | ((q & 7) >> 2)) : (f % ROWS);
+      const int kg = KC ? (f & 1) : (f / ROWS);
+      kofs[i] = 8 * kg;
+      lofs[i] = row * XROWB + kg * 16;
+      // rows past the end are CLAMPED, not zero-filled: an output row/column depends only on its own operand
+      // row, and the epilogue never stores rows >= M or columns >= N
+      const int grow = (row0 + row < nrows) ? row0 + row : nrows - 1;
+      p[i] = b + (long)grow * rs_ + (long)(k0 + 8 * kg) * cs_;
+    }
+  }
+
+  __device__ __forceinline__ void load(float (&r)[NS][8], int k0, int K) {
+    if (k0 + XBK <= K) {   // (uniform) whole stage inside the k range: unconditional loads
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        if (KC) {
+          const float4 v = *reinterpret_cast<const float4*>(p[i]);
+          const float4 w = *reinterpret_cast<const float4*>(p[i] + 4);
+          r[i][0] = v.x; r[i][1] = v.y; r[i][2] = v.z; r[i][3] = v.w;
+          r[i][4] = w.x; r[i][5] = w.y; r[i][6] = w.z; r[i][7] = w.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r[i][e] = p[i][e * cs];
+        }
+        p[i] += kstep;
+      }
+      return;
+    }
+    // k tail: zeros beyond K
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[i][e] = 0.f;
+      if (KC) {
+        // K % 4 == 0 (operands_vectorisable): a float4 is entirely inside or outside the k range
+        if (k0 + kofs[i] < K) {
+          const float4 v = *reinterpret_cast<const float4*>(p[i]);
+          r[i][0] = v.x; r[i][1] = v.y; r[i][2] = v.z; r[i][3] = v.w;
+        }
+        if (k0 + kofs[i] + 4 < K) {
+          const float4 v = *reinterpret_cast<const float4*>(p[i] + 4);
+          r[i][4] = v.x; r[i][5] = v.y; r[i][6] = v.z; r[i][7] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (k0 + kofs[i] + e < K) r[i][e] = p[i][e * cs];
+      }
+      p[i] += kstep;
+    }
+  }
+
+  __device__ __forceinline__ void store(const float (&r)[NS][8], char* __restrict__ lds) const {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      uint4 s0, s1, s2;
+      split8(r[i], s0, s1, s2);
+      *reinterpret_cast<uint4*>(lds + lofs[i]) = s0;
+      *reinterpret_cast<uint4*>(lds + lofs[i] + 2 * XBK) = s1;
+      *reinterpret_cast<uint4*>(lds + lofs[i] + 4 * XBK) = s2;
+    }
+  }
+};
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(XTHR, 1) void gemm_bx3_kernel(GemmArgs g) {
+  constexpr int BM = XBM, BN = XBN, TM = 2, TN = 2;
+  constexpr int A_BYTES = BM * XROWB;
+  __shared__ __attribute__((aligned(16))) char lds[XLDS];
+
+  const FdGemmDesc& d = g.d;
+  const int tid = (int)threadIdx.x;
+
+  const int nblk = g.nblk_m * g.nblk_n;
+  const int lid = fd_xcd_swizzle((int)blockIdx.x, nblk);
+  const int bm = lid / g.nblk_n, bn = lid % g.nblk_n;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const int z = (int)blockIdx.y;
+  const int zo = z / d.bdiv, zi = z % d.bdiv;
+
+  // split-K: blockIdx.z owns stages [kt0, kt0 + nk)
+  const int nkt_all = (d.K + XBK - 1) / XBK;
+  const int per = (nkt_all + g.ksplit - 1) / g.ksplit;
+  const int kt0 = (int)blockIdx.z * per;
+  const int nkt = (kt0 + per < nkt_all) ? kt0 + per : nkt_all;
+  const int nk = nkt - kt0;
+  if (nk <= 0) return;
+
+  if (tid >= XCONS) {
+    // ---- producer waves: global -> registers -> (split) -> LDS ring; two register sets = two stages in flight ----
+    const int ptid = tid - XCONS;
+    fd::raise_wave_priority();   // the producer's instruction stream must never wait for an issue slot
+    const float* __restrict__ A = d.A + zo * d.a_so + zi * d.a_si;
+    const float* __restrict__ B = d.B + zo * d.b_so + zi * d.b_si;
+    SplitStager<BM, A_KC> sa;
+    SplitStager<BN, B_KC> sb;
+    constexpr int NSA = SplitStager<BM, A_KC>::NS, NSB = SplitStager<BN, B_KC>::NS;
+    float ra[2][NSA][8], rb[2][NSB][8];
+    sa.init(A, d.a_rs, d.a_cs, m0, d.M, kt0 * XBK, ptid);
+    sb.init(B, d.b_cs, d.b_rs, n0, d.N, kt0 * XBK, ptid);   // the staged "row" of B is n
+    int lk = kt0;   // stage of the next global load
+    auto issue = [&](float (&xa)[NSA][8], float (&xb)[NSB][8]) {
+      sa.load(xa, lk * XBK, d.K);
+      sb.load(xb, lk * XBK, d.K);
+      ++lk;
+    };
+    // fused bias gradient of dW = dY^T X (A = dY^T row-contiguous: producer thread t stages row m0 + t in all of
+    // its slots): row sums of A over k, taken from the registers on their way to LDS
+    const bool do_rowsum = !A_KC && d.a_rowsum != nullptr && bn == 0 && z == 0;
+    float rsum = 0.f;
+    int wbuf = 0;   // ring slot of the next LDS store
+    auto put = [&](float (&xa)[NSA][8], float (&xb)[NSB][8]) {
+      if (!A_KC && do_rowsum) {
+#pragma unroll
+        for (int i = 0; i < NSA; ++i)
+          rsum += ((xa[i][0] + xa[i][1]) + (xa[i][2] + xa[i][3])) + ((xa[i][4] + xa[i][5]) + (xa[i][6] + xa[i][7]));
+      }
+      char* dst = lds + wbuf * XSTAGE;
+      sa.store(xa, dst);
+      sb.store(xb, dst + A_BYTES);
+      wbuf = (wbuf == XRING - 1) ? 0 : wbuf + 1;
+    };
+    issue(ra[0], rb[0]);
+    if (nk > 1) issue(ra[1], rb[1]);
+    put(ra[0], rb[0]);
+    if (nk > 2) issue(ra[0], rb[0]);
+    if (nk > 1) {
+      put(ra[1], rb[1]);
+      if (nk > 3) issue(ra[1], rb[1]);
+    }
+    __syncthreads();   // stages 0 and 1 are in the ring
+    // during stage `it`: stage it+2 goes registers -> ring slot (it+2) % 3 (last read, as stage it-1, two barriers
+    // ago) and the loads of stage it+4 refill the register set
+    auto step = [&](int it, float (&xa)[NSA][8], float (&xb)[NSB][8]) {
+      if (it + 2 < nk) {
+        put(xa, xb);
+        if (it + 4 < nk) issue(xa, xb);
+      }
+      __syncthreads();
+    };
+    for (int it = 0; it < nk; it += 2) {
+      step(it, ra[0], rb[0]);
+      if (it + 1 < nk) step(it + 1, ra[1], rb[1]);
+    }
+    if (!A_KC && do_rowsum && m0 + ptid < d.M) atomicAdd(d.a_rowsum + m0 + ptid, d.alpha * rsum);
+    if (g.epi_vec) {   // the two barriers of the consumers' LDS-transposed epilogue
+      __syncthreads();
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---- consumer waves: LDS -> registers -> MFMA ----
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* __restrict__ C = d.C + zo * d.c_so + zi * d.c_si;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-lane fragment base: row (l31); lane-half h takes k 8h..8h+7 of the 16-k MFMA step
+  const int a_frag = ((wm * TM) * 32 + l31) * XROWB + h * 16;
+  const int b_frag = A_BYTES + ((wn * TN) * 32 + l31) * XROWB + h * 16;
+  uint4 fa[2][TM][3], fb[2][TN][3];
+  int rbuf = 0;   // ring slot of the next fragment read
+  auto read_frags = [&](uint4 (&xa)[TM][3], uint4 (&xb)[TN][3]) {
+    const char* st = lds + rbuf * XSTAGE;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        xa[i][s] = *reinterpret_cast<const uint4*>(st + a_frag + i * 32 * XROWB + s * 2 * XBK);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        xb[j][s] = *reinterpret_cast<const uint4*>(st + b_frag + j * 32 * XROWB + s * 2 * XBK);
+    }
+    rbuf = (rbuf == XRING - 1) ? 0 : rbuf + 1;
+  };
+  // term pairs (i, j) with i + j <= 2, smallest first; the four accumulators are interleaved so that dependent
+  // MFMAs are four issues apart
+  auto mfmas = [&](uint4 (&xa)[TM][3], uint4 (&xb)[TN][3]) {
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+      constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = fd::mfma_32x32x16_bf16(xa[i][PA[p]], xb[j][PB[p]], acc[i][j]);
+    }
+  };
+  // stage it is multiplied out of registers while the fragments of stage it+1 (complete in the ring since the last
+  // barrier) are fetched; the barrier itself carries no LDS wait on this side
+  auto step = [&](int it, uint4 (&ca)[TM][3], uint4 (&cb)[TN][3], uint4 (&na)[TM][3], uint4 (&nb)[TN][3]) {
+    if (it + 1 < nk) read_frags(na, nb);
+    mfmas(ca, cb);
+    fd::block_barrier_nofence();
+  };
+
+  __syncthreads();   // stages 0 and 1 are in the ring
+  read_frags(fa[0], fb[0]);
+  for (int it = 0; it < nk; it += 2) {
+    step(it, fa[0], fb[0], fa[1], fb[1]);
+    if (it + 1 < nk) step(it + 1, fa[1], fb[1], fa[0], fb[0]);
+  }
+
+  if (g.epi_vec)
+    store_tile_vec<BM, BN, TM, TN, XCONS>(d, C, acc, reinterpret_cast<float*>(lds), m0, n0, wm, wn, h, l31, tid);
+  else
+    store_tile<TM, TN>(d, C, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, h, l31, g.ksplit > 1);
+}

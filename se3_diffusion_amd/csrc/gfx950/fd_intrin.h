@@ -19,6 +19,30 @@ __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31], e = 0..7 packed two per dword
+// (low half first); exact bf16 products, f32 accumulate; D as 32x32x2.  32 cycles / SIMD.
+typedef __bf16 fd_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 fd_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(fd_bf16x8, a), __builtin_bit_cast(fd_bf16x8, b), c, 0, 0, 0);
+}
+// two f32 -> one dword of two bf16, round-to-nearest-even (v_cvt_pk_bf16_f32): lo in bits 0..15
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  // (asm rather than two __bf16 casts: the compiler otherwise re-derives each half with its own conversion when
+  // the packed word is unpacked again by the split code)
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ float bf16lo_f32(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16hi_f32(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// s_setprio 3: this wave wins instruction arbitration on its SIMD
+__device__ __forceinline__ void raise_wave_priority() { __builtin_amdgcn_s_setprio(3); }
+
+// s_barrier without the LDS/memory fence of __syncthreads(): for a wave that has nothing to publish at the barrier
+__device__ __forceinline__ void block_barrier_nofence() { __builtin_amdgcn_s_barrier(); }
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 

@@ -69,6 +69,7 @@ def _ptr(t, off=0):
 # f = float, S = pointer to a ctypes struct, s = stream (supplied by the binding).
 _SIGS = {
     "fd_gemm": "Ss",
+    "fd_gemm_plan": "S",
     "fd_layernorm_fwd": "plpppplpplifs",
     "fd_layernorm_bwd": "plplpppppl" + "ipplis",
     "fd_colsum_acc": "pllips",
@@ -193,11 +194,10 @@ class FdLib:
         for x in (bias, resid, gate, rowscale):
             if x is not None:
                 tens.append(x[0] if isinstance(x, tuple) else x)
-        if d.tile == 0:
-            d.tile = auto_tile(d.M, d.N, max(1, batch))
         stream = self._stream(tens)
         prof = self.gemm_profile
         if prof is not None and self.is_device:
+            d.tile = self.cdll.fd_gemm_plan(ctypes.byref(d))
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -209,14 +209,6 @@ class FdLib:
         self._check(self.cdll.fd_gemm(ctypes.byref(d), stream), "fd_gemm")
 
     gemm_profile = None  # set to a list to record (tile, a_kc, b_kc, flops, ev0, ev1) per fd_gemm launch
-
-
-def auto_tile(M, N, batch):
-    """Same selection rule as fd_gemm (csrc/fd_gemm.hip): 1 = 128x128, 2 = 64x64, 3 = 128x32."""
-    if N <= 48:
-        return 3
-    blocks128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
-    return 1 if (blocks128 >= 512 and N >= 96) else 2
 
 
 _PRODUCT: FdLib | None = None

@@ -72,8 +72,15 @@ def linear_dw(dy, x, dW, M, N, K, db=None):
     xt, xo, xl = x
     wt, wo, wl = dW
     # output is tiny (N x K weights), the reduction (M rows) is huge: split K so that ~2300 blocks exist
-    tile, t = (1, 128) if (N >= 256 and K >= 256 and db is None) else (2, 64)
-    blocks = ((N + t - 1) // t) * ((K + t - 1) // t)
+    al16 = all((t.data_ptr() + 4 * o) % 16 == 0 and ld % 4 == 0 for t, o, ld in (dy, x))
+    if N >= 384 and K >= 256 and M >= 65536 and N % 4 == 0 and K % 4 == 0 and al16:
+        # large pair-level weight gradients (>= 75 % of the 256 x 128 tiles used, enough tiles that the split-K
+        # atomics stay cheap): split-bf16 kernel with the fused row sum
+        tile = 4
+        blocks = ((N + 255) // 256) * ((K + 127) // 128)
+    else:
+        tile, t = (1, 128) if (N >= 256 and K >= 256 and db is None) else (2, 64)
+        blocks = ((N + t - 1) // t) * ((K + t - 1) // t)
     ks = max(1, min(2304 // max(1, blocks), M // 256))
     lib().gemm(dt, xt, wt, N, K, M, (1, dl), (xl, 1), wl, a_off=do, b_off=xo, c_off=wo,
                beta=(ks == 1), ksplit=ks, tile=tile, a_rowsum=db)

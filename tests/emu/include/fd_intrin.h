@@ -64,6 +64,43 @@ static inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
   return d;
 }
 
+static inline float bf16lo_f32(unsigned w) { unsigned u = w << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline float bf16hi_f32(unsigned w) { unsigned u = w & 0xffff0000u; float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned bf16_rne(float x) {
+  unsigned u; memcpy(&u, &x, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+static inline unsigned pack_bf16(float lo, float hi) { return (bf16_rne(lo) & 0xffffu) | (bf16_rne(hi) << 16); }
+
+// 32x32x16 bf16: A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31]; exact products, f32 accumulate (k-ordered here)
+static inline f32x16 mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) {
+  struct AB { unsigned a[4], b[4]; } ab{{a.x, a.y, a.z, a.w}, {b.x, b.y, b.z, b.w}};
+  auto tab = hipemu::wave_exchange(&ab, sizeof(ab));
+  int l = hipemu::g_cur->lane;
+  int col = l & 31, hi = l >> 5;
+  f32x16 d;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int kh = 0; kh < 2; ++kh) {
+      AB x, y;
+      memcpy(&x, tab[row + 32 * kh], sizeof(AB));
+      memcpy(&y, tab[col + 32 * kh], sizeof(AB));
+      for (int e = 0; e < 4; ++e) {
+        acc = fmaf(bf16lo_f32(x.a[e]), bf16lo_f32(y.b[e]), acc);
+        acc = fmaf(bf16hi_f32(x.a[e]), bf16hi_f32(y.b[e]), acc);
+      }
+    }
+    d[r] = acc;
+  }
+  return d;
+}
+
+static inline void raise_wave_priority() {}
+
+static inline void block_barrier_nofence() { hipemu::barrier(); }
+
 static inline int lane_id() { return hipemu::g_cur->lane; }
 static inline int wave_id() { return hipemu::g_cur->wave; }
 

@@ -149,3 +149,102 @@ def test_gemm_splitk_emu(emu_lib):
 @pytest.mark.gpu
 def test_gemm_splitk_gpu(hip_lib):
     _splitk(hip_lib, "cuda")
+
+
+# ---- tile 4: split-bf16 (three exact bf16 terms per fp32 operand, six bf16-MFMA products, fp32 accumulate) ----
+SPLIT_LAYOUTS = [(True, True), (True, False), (False, False)]
+SPLIT_CASES = [(64, 64, 32), (128, 128, 64), (100, 72, 40), (260, 136, 100), (256, 384, 96)]
+
+
+@pytest.mark.parametrize("layout", SPLIT_LAYOUTS)
+def test_gemm_split_layouts_emu(emu_lib, layout):
+    for (M, N, K) in SPLIT_CASES[:4]:
+        assert _run(emu_lib, "cpu", M, N, K, layout[0], layout[1], 4) < 2e-6, (M, N, K)
+
+
+def test_gemm_split_epilogue_emu(emu_lib):
+    assert _run(emu_lib, "cpu", 100, 72, 40, True, True, 4, epi=True) < 2e-6
+    assert _run(emu_lib, "cpu", 300, 132, 72, True, False, 4, epi=True) < 2e-6
+
+
+def _split_accuracy(lib, dev, M, N, K):
+    """the split path carries fp32 accuracy: its error against fp64 is of the size of the fmaf-chain kernel's"""
+    g = torch.Generator().manual_seed(9)
+    A = (torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, K, generator=g)))   # wide dynamic range
+    W = torch.randn(N, K, generator=g)
+    ref = A.double() @ W.double().t()
+    mag = A.double().abs() @ W.double().abs().t()      # error scale of a K-term fp32 dot product
+    errs = {}
+    for tile in (1, 4):
+        C = torch.zeros(M, N).to(dev)
+        lib.gemm(A.to(dev), W.to(dev), C, M, N, K, (K, 1), (1, K), N, tile=tile)
+        errs[tile] = float(((C.cpu().double() - ref).abs() / mag).max())
+    assert errs[1] < 2e-6 and errs[4] < 2e-6, errs
+    assert errs[4] < 3 * errs[1] + 2e-7, errs
+    return errs
+
+
+def test_gemm_split_accuracy_emu(emu_lib):
+    _split_accuracy(emu_lib, "cpu", 64, 32, 512)
+
+
+def test_gemm_split_unsupported_layout_raises(emu_lib):
+    from se3_diffusion_amd.hip import FdError
+    with pytest.raises(FdError):
+        _run(emu_lib, "cpu", 64, 64, 32, False, True, 4)       # A row-contiguous with B k-contiguous: not built
+    with pytest.raises(FdError):
+        _run(emu_lib, "cpu", 33, 6, 65, True, True, 4)         # unaligned operands
+
+
+def _splitk4(lib, dev, M=136, N=72, K=1000, ks=5):
+    g = torch.Generator().manual_seed(4)
+    dY = torch.randn(K, M, generator=g)
+    X = torch.randn(K, N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    C = C0.clone().to(dev)
+    lib.gemm(dY.to(dev), X.to(dev), C, M, N, K, (1, M), (N, 1), N, ksplit=ks, tile=4)
+    ref = C0.double() + dY.double().t() @ X.double()
+    assert (C.cpu().double() - ref).abs().max() < 2e-6 * ref.abs().max()
+
+
+def test_gemm_split_splitk_emu(emu_lib):
+    _splitk4(emu_lib, "cpu")
+
+
+@pytest.mark.gpu
+def test_gemm_split_gpu(hip_lib):
+    for (a_kc, b_kc) in SPLIT_LAYOUTS:
+        for (M, N, K) in SPLIT_CASES:
+            assert _run(hip_lib, "cuda", M, N, K, a_kc, b_kc, 4) < 2e-6, (a_kc, b_kc, M, N, K)
+        assert _run(hip_lib, "cuda", 300, 132, 72, a_kc, b_kc, 4, epi=True) < 2e-6
+    _splitk4(hip_lib, "cuda")
+    _splitk4(hip_lib, "cuda", M=384, N=384, K=40000, ks=64)
+    errs = _split_accuracy(hip_lib, "cuda", 1024, 384, 384)
+    print("split-bf16 vs fp32-MFMA max error / (|A||B|):", errs)
+    # the automatic plan takes the split path for the pair-level shapes (and only when operands allow)
+    assert _run(hip_lib, "cuda", 65536, 128, 128, True, True, 0) < 2e-6
+
+
+def _splitk4_rowsum(lib, dev, M=384, N=136, K=3000, ks=6):
+    """dW = dY^T X on the split-bf16 kernel with the bias gradient (column sums of dY) fused into the producers"""
+    g = torch.Generator().manual_seed(8)
+    dY = torch.randn(K, M, generator=g)
+    X = torch.randn(K, N, generator=g)
+    C = torch.zeros(M, N).to(dev)
+    db0 = torch.randn(M, generator=g)
+    db = db0.clone().to(dev)
+    lib.gemm(dY.to(dev), X.to(dev), C, M, N, K, (1, M), (N, 1), N, ksplit=ks, tile=4, a_rowsum=db)
+    ref = dY.double().t() @ X.double()
+    assert (C.cpu().double() - ref).abs().max() < 2e-6 * ref.abs().max()
+    rs = db0.double() + dY.double().sum(0)
+    assert (db.cpu().double() - rs).abs().max() < 1e-5 * rs.abs().max()
+
+
+def test_gemm_split_rowsum_emu(emu_lib):
+    _splitk4_rowsum(emu_lib, "cpu", M=300, N=72, K=200, ks=3)
+
+
+@pytest.mark.gpu
+def test_gemm_split_rowsum_gpu(hip_lib):
+    _splitk4_rowsum(hip_lib, "cuda")
+    _splitk4_rowsum(hip_lib, "cuda", M=384, N=384, K=65536, ks=64)

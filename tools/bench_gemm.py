@@ -44,6 +44,19 @@ SHAPES = [
     ("probe shortK bigN", 32768, 4096, 384, True, True, 1, 1),
     ("probe longK N384", 122880, 384, 1536, True, True, 1, 1),
     ("probe K384 N384 M64k", 65536, 384, 384, True, True, 1, 1),
+    # split-bf16 (tile 4) on the same pair-level shapes
+    ("x3 edge_fwd_W2 NT", P, 384, 384, True, True, 4, 1),
+    ("x3 edge_fwd_W1z NT", P, 384, 128, True, True, 4, 1),
+    ("x3 edge_fwd_Wf NT", P, 128, 384, True, True, 4, 1),
+    ("x3 edge_fwd_Wfz NT", P, 128, 128, True, True, 4, 1),
+    ("x3 edge_bwd_dX NN", P, 384, 384, True, False, 4, 1),
+    ("x3 edge_bwd_dX NN N128", P, 128, 384, True, False, 4, 1),
+    ("x3 edge_bwd_dW TN", 384, 384, P, False, False, 4, 384),
+    ("x3 edge_bwd_dW TN 128", 128, 384, P, False, False, 4, 768),
+    ("x3 sample edge W2 N=128", 16384, 384, 384, True, True, 4, 1),
+    ("x3 sample edge W2 N=256", 65536, 384, 384, True, True, 4, 1),
+    ("x3 square 4096 NT", 4096, 4096, 4096, True, True, 4, 1),
+    ("x3 probe longK N384", 122880, 384, 1536, True, True, 4, 1),
 ]
 
 
@@ -52,6 +65,8 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--warm", type=int, default=3)
+    ap.add_argument("--mtiles", type=int, default=0)
+    ap.add_argument("--fill", default="randn", help="randn | ones | zeros (data-dependent power check)")
     a = ap.parse_args()
     lib = hip.get_lib()
     dev = "cuda"
@@ -61,10 +76,13 @@ def main():
             continue
         A = torch.randn(M, K, device=dev) if akc else torch.randn(K, M, device=dev)
         B = torch.randn(N, K, device=dev) if bkc else torch.randn(K, N, device=dev)
+        if a.fill != "randn":
+            A.fill_(1.0 if a.fill == "ones" else 0.0)
+            B.fill_(1.0 if a.fill == "ones" else 0.0)
         C = torch.zeros(M, N, device=dev)
         a_str = (K, 1) if akc else (1, M)
         b_str = (1, K) if bkc else (N, 1)
-        fn = lambda: lib.gemm(A, B, C, M, N, K, a_str, b_str, N, tile=tile, ksplit=ks)  # noqa: E731
+        fn = lambda: lib.gemm(A, B, C, M, N, K, a_str, b_str, N, tile=tile, ksplit=ks, mtiles=a.mtiles)  # noqa: E731
         ms = timeit(fn, a.iters, a.warm)
         tf = 2.0 * M * N * K / ms / 1e9
         out.append(dict(name=name, M=M, N=N, K=K, tile=tile, ksplit=ks, ms=round(ms, 4), tflops=round(tf, 2)))
