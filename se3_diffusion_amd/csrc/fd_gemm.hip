@@ -549,7 +549,12 @@ int plan_tile(const FdGemmDesc& d, bool fast) {
     if (d.N <= 48) cfg = 3;
     else if (blocks128 >= 512 && d.N >= 96) cfg = 1;
     else cfg = 2;
-    if (cfg == 1 && fast && d.K >= 64 && bx3_layout_ok(d) && split_enabled()) cfg = 4;
+    // the split-bf16 kernel wherever the wide fp32 tile would run, and for mid-size problems (single-backbone
+    // sampling: 16k..64k pair rows) as soon as its 256x128 tiles cover ~40 % of the CUs
+    const long blocks_x3 = (long)fd_cdiv(d.M, XBM) * fd_cdiv(d.N, XBN) * (d.batch > 0 ? d.batch : 1);
+    if ((cfg == 1 || (d.N >= 96 && d.M >= 1024 && blocks_x3 >= 96)) && fast && d.K >= 64 && bx3_layout_ok(d) &&
+        split_enabled())
+      cfg = 4;
   }
   if (!fast && cfg == 1) cfg = 2;   // the element-wise staging path is only instantiated for the small tiles
   return cfg;
