@@ -110,8 +110,10 @@ int fd_ipa_points_bwd(const float* proj, const float* quat, const float* dqp, co
                       void* stream);
 int fd_ipa_softmax_fwd(float* S, const float* zb, const float* qp, const float* kp, const float* head_w,
                        const float* mask, int B, int N, void* stream);
+/* hw_part: [B*N, 8] scratch (per-query-row partials of the head-weight gradient, column-summed into dhead_w) */
 int fd_ipa_softmax_bwd(const float* A, float* dA, const float* qp, const float* kp, const float* head_w,
-                       float* dzb, float* dqp, float* dkp, float* dhead_w, int B, int N, void* stream);
+                       float* dzb, float* dqp, float* dkp, float* dhead_w, float* hw_part, int B, int N,
+                       void* stream);
 int fd_ipa_opt_fwd(const float* optg, const float* quat, const float* trans, float* feats, long R, void* stream);
 int fd_ipa_opt_bwd(const float* dfeats, const float* feats, const float* quat, float* doptg, float* dframe,
                    long R, void* stream);

@@ -82,7 +82,7 @@ _SIGS = {
     "fd_ipa_points_fwd": "ppppppliiiis",
     "fd_ipa_points_bwd": "pppppppliiiis",
     "fd_ipa_softmax_fwd": "ppppppiis",
-    "fd_ipa_softmax_bwd": "pppppppppiis",
+    "fd_ipa_softmax_bwd": "ppppppppppiis",
     "fd_ipa_opt_fwd": "ppppls",
     "fd_ipa_opt_bwd": "pppppls",
     "fd_ipa_opair_fwd": "pppiis",

@@ -193,7 +193,8 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe):
     # softmax (dA becomes dLogits) + point/bias/head-weight grads
     dqp = empty((R, H, PQ * 3), dev); dkp = empty((R, H, PQ * 3), dev)
     dhw = G[f"{pre}.head_weights"] if G is not None else zeros((H,), dev)
-    L.call("fd_ipa_softmax_bwd", A, dA, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, B, N)
+    hw_part = empty((R, H), dev)
+    L.call("fd_ipa_softmax_bwd", A, dA, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, hw_part, B, N)
     sc = math.sqrt(1.0 / (3 * C))
     # dQ = sc * dL K ; dK = sc * dL^T Q
     L.gemm(dA, proj, dproj, N, C, N, (N, 1), (LDP, 1), LDP, b_off=2048, batch=B * H, bdiv=H,

@@ -81,7 +81,9 @@ def linear_dw(dy, x, dW, M, N, K, db=None):
     else:
         tile, t = (1, 128) if (N >= 256 and K >= 256 and db is None) else (2, 64)
         blocks = ((N + t - 1) // t) * ((K + t - 1) // t)
-    ks = max(1, min(2304 // max(1, blocks), M // 256))
+    # ~9 blocks per CU for the 64/128 tiles; the 256x128 split-bf16 tile runs one block per CU, and every extra split
+    # costs a full tile of L2 atomics: 3 per CU
+    ks = max(1, min((768 if tile == 4 else 2304) // max(1, blocks), M // 256))
     lib().gemm(dt, xt, wt, N, K, M, (1, dl), (xl, 1), wl, a_off=do, b_off=xo, c_off=wo,
                beta=(ks == 1), ksplit=ks, tile=tile, a_rowsum=db)
 

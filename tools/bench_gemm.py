@@ -53,6 +53,16 @@ SHAPES = [
     ("x3 edge_bwd_dX NN N128", P, 128, 384, True, False, 4, 1),
     ("x3 edge_bwd_dW TN", 384, 384, P, False, False, 4, 384),
     ("x3 edge_bwd_dW TN 128", 128, 384, P, False, False, 4, 768),
+    ("x3 dWks 64", 384, 384, P, False, False, 4, 64),
+    ("x3 dWks 96", 384, 384, P, False, False, 4, 96),
+    ("x3 dWks 128", 384, 384, P, False, False, 4, 128),
+    ("x3 dWks 192", 384, 384, P, False, False, 4, 192),
+    ("t2 dWks 48 (128x384)", 128, 384, P, False, False, 2, 48),
+    ("t2 dWks 96 (128x384)", 128, 384, P, False, False, 2, 96),
+    ("t2 dWks 192 (128x384)", 128, 384, P, False, False, 2, 192),
+    ("t2 dWks 144 (128x128)", 128, 128, P, False, False, 2, 144),
+    ("t2 dWks 288 (128x128)", 128, 128, P, False, False, 2, 288),
+    ("t2 dWks 576 (128x128)", 128, 128, P, False, False, 2, 576),
     ("x3 sample edge W2 N=128", 16384, 384, 384, True, True, 4, 1),
     ("x3 sample edge W2 N=256", 65536, 384, 384, True, True, 4, 1),
     ("x3 square 4096 NT", 4096, 4096, 4096, True, True, 4, 1),
