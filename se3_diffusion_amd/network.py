@@ -52,11 +52,13 @@ def _lin_grads(G, wname, bname, dy, x, M, N, K, w_off=0, w_ld=None):
     if G is None:
         return
     db = G[bname] if (bname is not None and bname in G) else None
+    # node-level calls run on the gradient side stream (ops.side): dy / x must not be written again by the caller
     if wname in G:
         W = G[wname]
-        ops.linear_dw(dy, x, (W, w_off, w_ld if w_ld is not None else W.shape[1]), M, N, K, db=db)
+        ops.side(lambda: ops.linear_dw(dy, x, (W, w_off, w_ld if w_ld is not None else W.shape[1]), M, N, K, db=db),
+                 (dy[0], x[0]), M)
     elif db is not None:
-        ops.bias_grad(dy, db, M, N)
+        ops.side(lambda: ops.bias_grad(dy, db, M, N), (dy[0],), M)
 
 
 # --------------------------------------------------------------------------- embedder
@@ -82,7 +84,7 @@ def mlp3_ln_bwd(P, G, pre, sv, dy):
     dh2 = empty((M, Cc), dev)
     ops.linear_dx(mv(dh3), mv(P[f"{pre}.4.weight"]), mv(dh2), M, Cc, Cc, gate=mv(sv["h2"]))
     _lin_grads(G, f"{pre}.2.weight", f"{pre}.2.bias", mv(dh2), mv(sv["h1"]), M, Cc, Cc)
-    dh1 = dh3  # reuse
+    dh1 = empty((M, Cc), dev)   # (dh3 is still being read by its weight gradient on the side stream)
     ops.linear_dx(mv(dh2), mv(P[f"{pre}.2.weight"]), mv(dh1), M, Cc, Cc, gate=mv(sv["h1"]))
     _lin_grads(G, f"{pre}.0.weight", f"{pre}.0.bias", mv(dh1), sv["x"], M, Cc, K0)
 
@@ -278,13 +280,13 @@ def tfmr_layer_bwd(P, G, pre, sv, dy2):
     df = empty((R, TD), dev)
     ops.linear_dx(mv(dt2), mv(P[f"{pre}.linear2.weight"]), mv(df), R, TD, TD, gate=mv(sv["f"]))
     _lin_grads(G, f"{pre}.linear1.weight", f"{pre}.linear1.bias", mv(df), mv(sv["y1"]), R, TD, TD)
-    dy1 = dt2  # dy1 = dt2 (residual) + df W1
-    ops.linear_dx(mv(df), mv(P[f"{pre}.linear1.weight"]), mv(dy1), R, TD, TD, beta=True)
+    dy1 = empty((R, TD), dev)  # dy1 = dt2 (residual) + df W1 (operands of side-stream gradients stay read-only)
+    ops.linear_dx(mv(df), mv(P[f"{pre}.linear1.weight"]), mv(dy1), R, TD, TD, resid=mv(dt2))
     dt1 = empty((R, TD), dev)
     ops.layernorm_bwd(mv(dy1), mv(sv["t1"]), P[f"{pre}.norm1.weight"], sv["m1"], sv["r1"], mv(dt1), R, TD,
                       dgamma=G[f"{pre}.norm1.weight"], dbeta=G[f"{pre}.norm1.bias"])
     _lin_grads(G, f"{pre}.self_attn.out_proj.weight", f"{pre}.self_attn.out_proj.bias", mv(dt1), mv(sv["o"]), R, TD, TD)
-    do = df  # reuse
+    do = empty((R, TD), dev)
     ops.linear_dx(mv(dt1), mv(P[f"{pre}.self_attn.out_proj.weight"]), mv(do), R, TD, TD)
     qkv, A = sv["qkv"], sv["A"]
     dqkv = empty((R, 3 * TD), dev)
@@ -301,8 +303,8 @@ def tfmr_layer_bwd(P, G, pre, sv, dy2):
     L.gemm(dA, qkv, dqkv, N, THD, N, (1, N), (3 * TD, 1), 3 * TD, c_off=TD, batch=B * TH, bdiv=TH,
            a_bs=(TH * N * N, N * N), b_bs=(N * 3 * TD, THD), c_bs=(N * 3 * TD, THD), alpha=sc)
     _lin_grads(G, f"{pre}.self_attn.in_proj_weight", f"{pre}.self_attn.in_proj_bias", mv(dqkv), mv(sv["x"]), R, 3 * TD, TD)
-    dx = dt1  # dx = dt1 (residual) + dqkv W_in
-    ops.linear_dx(mv(dqkv), mv(P[f"{pre}.self_attn.in_proj_weight"]), mv(dx), R, 3 * TD, TD, beta=True)
+    dx = empty((R, TD), dev)  # dx = dt1 (residual) + dqkv W_in
+    ops.linear_dx(mv(dqkv), mv(P[f"{pre}.self_attn.in_proj_weight"]), mv(dx), R, 3 * TD, TD, resid=mv(dt1))
     return dx
 
 
@@ -339,8 +341,8 @@ def post_node_bwd(P, G, b, sv, dn3, du0):
     dh1 = empty((R, CS), dev)
     ops.linear_dx(mv(dh2), mv(P[f"{nt}.linear_2.weight"]), mv(dh1), R, CS, CS, gate=mv(sv["h1"]))
     _lin_grads(G, f"{nt}.linear_1.weight", f"{nt}.linear_1.bias", mv(dh1), mv(sv["n2"]), R, CS, CS)
-    dn2 = dt  # dn2 = dt (residual) + dh1 W1
-    ops.linear_dx(mv(dh1), mv(P[f"{nt}.linear_1.weight"]), mv(dn2), R, CS, CS, beta=True)
+    dn2 = empty((R, CS), dev)  # dn2 = dt (residual) + dh1 W1
+    ops.linear_dx(mv(dh1), mv(P[f"{nt}.linear_1.weight"]), mv(dn2), R, CS, CS, resid=mv(dt))
     _lin_grads(G, f"{pre}.post_tfmr_{b}.weight", f"{pre}.post_tfmr_{b}.bias", mv(dn2), mv(sv["u2"]), R, CS, TD)
     du2 = empty((R, TD), dev)
     ops.linear_dx(mv(dn2), mv(P[f"{pre}.post_tfmr_{b}.weight"]), mv(du2), R, CS, TD)

@@ -35,8 +35,10 @@ def bb_update_bwd(P, G, b, sv, dq2, dt2, dframe, dn3):
     lib().call("fd_bb_update_bwd", dq2, dt2, dframe, sv["dmask"], sv["upd"], sv["quat"], dq, dt, dupd, dupd_s, R)
     # upd = W6 (n3 * d) + b6
     if G is not None:
-        ops.linear_dw(mv(dupd_s), mv(sv["n3"]), mv(G[f"{pre}.weight"]), R, 6, CS)
-        ops.bias_grad(mv(dupd), G[f"{pre}.bias"], R, 6)
+        def _grads():
+            ops.linear_dw(mv(dupd_s), mv(sv["n3"]), mv(G[f"{pre}.weight"]), R, 6, CS)
+            ops.bias_grad(mv(dupd), G[f"{pre}.bias"], R, 6)
+        ops.side(_grads, (dupd_s, dupd, sv["n3"]), R)
     ops.linear_dx(mv(dupd_s), mv(P[f"{pre}.weight"]), mv(dn3), R, 6, CS, beta=True)
     return dq, dt
 
@@ -84,13 +86,17 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
                       rowscale=sv["emask"], dgamma=G[f"{pre}.layer_norm.weight"], dbeta=G[f"{pre}.layer_norm.bias"])
     # y = Wf h2 + Wf[:, :128] z + Pf_i + Qf_j (+bf inside Qf)
     gWf = G[f"{pre}.final_layer.weight"]
-    ops.linear_dw(mv(dy), mv(h2), mv(gWf), Pn, CZ, EH)
-    ops.linear_dw(mv(dy), mv(z), (gWf, 0, EH), Pn, CZ, CZ)
+    def _grads_y():
+        ops.linear_dw(mv(dy), mv(h2), mv(gWf), Pn, CZ, EH)
+        ops.linear_dw(mv(dy), mv(z), (gWf, 0, EH), Pn, CZ, CZ)
+    ops.side(_grads_y, (dy, h2, z), Pn)
     dPf = zeros((R, CZ), dev); dQf = zeros((R, CZ), dev)
     L.call("fd_pair_reduce_acc", dy, B, N, CZ, dPf, dQf, CZ)
-    ops.linear_dw(mv(dPf), mv(e), (gWf, CZ, EH), R, CZ, CE)
-    ops.linear_dw(mv(dQf), mv(e), (gWf, CZ + CE, EH), R, CZ, CE)
-    ops.bias_grad(mv(dQf), G[f"{pre}.final_layer.bias"], R, CZ)
+    def _grads_f():
+        ops.linear_dw(mv(dPf), mv(e), (gWf, CZ, EH), R, CZ, CE)
+        ops.linear_dw(mv(dQf), mv(e), (gWf, CZ + CE, EH), R, CZ, CE)
+        ops.bias_grad(mv(dQf), G[f"{pre}.final_layer.bias"], R, CZ)
+    ops.side(_grads_f, (dPf, dQf, e), R)
     de = empty((R, CE), dev)
     ops.linear_dx(mv(dPf), (Wf, CZ, EH), mv(de), R, CZ, CE)
     ops.linear_dx(mv(dQf), (Wf, CZ + CE, EH), mv(de), R, CZ, CE, beta=True)
@@ -102,12 +108,14 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
     ops.linear_dx(mv(dh2), mv(W2), mv(dh1), Pn, EH, EH, gate=mv(h1))
     del dh2
     gW1 = G[f"{pre}.trunk.0.weight"]
-    ops.linear_dw(mv(dh1), mv(z), (gW1, 0, EH), Pn, EH, CZ)
+    ops.side(lambda: ops.linear_dw(mv(dh1), mv(z), (gW1, 0, EH), Pn, EH, CZ), (dh1, z), Pn)
     dP1 = zeros((R, EH), dev); dQ1 = zeros((R, EH), dev)
     L.call("fd_pair_reduce_acc", dh1, B, N, EH, dP1, dQ1, EH)
-    ops.linear_dw(mv(dP1), mv(e), (gW1, CZ, EH), R, EH, CE)
-    ops.linear_dw(mv(dQ1), mv(e), (gW1, CZ + CE, EH), R, EH, CE)
-    ops.bias_grad(mv(dQ1), G[f"{pre}.trunk.0.bias"], R, EH)
+    def _grads_1():
+        ops.linear_dw(mv(dP1), mv(e), (gW1, CZ, EH), R, EH, CE)
+        ops.linear_dw(mv(dQ1), mv(e), (gW1, CZ + CE, EH), R, EH, CE)
+        ops.bias_grad(mv(dQ1), G[f"{pre}.trunk.0.bias"], R, EH)
+    ops.side(_grads_1, (dP1, dQ1, e), R)
     ops.linear_dx(mv(dP1), (W1, CZ, EH), mv(de), R, EH, CE, beta=True)
     ops.linear_dx(mv(dQ1), (W1, CZ + CE, EH), mv(de), R, EH, CE, beta=True)
     ops.linear_dx(mv(dh1), (W1, 0, EH), mv(dz), Pn, EH, CZ, beta=True)          # dz += dh1 W1_z
@@ -319,6 +327,7 @@ def backward(P, G, sv, d_out):
     # node = init_node at block 0 input; both carry gradient into the node embedder
     ops.add_view(mv(dnode), mv(dinit), R, CS)
     nw.embed_bwd(P, G, sv["embed"], dnode, dz)
+    ops.join_grad_stream()   # the node-level weight gradients ran beside the dX chain (ops.side)
 
 
 def _frame_grad_fold(quat, dframe, dq, dt, R):

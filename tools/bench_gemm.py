@@ -53,6 +53,20 @@ SHAPES = [
     ("x3 edge_bwd_dX NN N128", P, 128, 384, True, False, 4, 1),
     ("x3 edge_bwd_dW TN", 384, 384, P, False, False, 4, 384),
     ("x3 edge_bwd_dW TN 128", 128, 384, P, False, False, 4, 768),
+    ("x3 dWks 384x128 ks96", 384, 128, P, False, False, 4, 96),
+    ("x3 dWks 384x128 ks192", 384, 128, P, False, False, 4, 192),
+    ("x3 dWks 384x128 ks384", 384, 128, P, False, False, 4, 384),
+    ("t2 dWks 384x128 ks192", 384, 128, P, False, False, 2, 192),
+    ("node dWks 15", 320, 320, 3840, False, False, 2, 15),
+    ("node dWks 30", 320, 320, 3840, False, False, 2, 30),
+    ("node dWks 60", 320, 320, 3840, False, False, 2, 60),
+    ("node dWks 256x2688 13", 256, 2688, 3840, False, False, 2, 13),
+    ("node dWks 256x2688 4", 256, 2688, 3840, False, False, 2, 4),
+    ("node dWks 256x256 15", 256, 256, 3840, False, False, 2, 15),
+    ("node dWks 256x256 60", 256, 256, 3840, False, False, 2, 60),
+    ("node NT 3840x320x320", 3840, 320, 320, True, True, 2, 1),
+    ("node NT 3840x320x320 t3", 3840, 320, 320, True, True, 3, 1),
+    ("node NN 3840x320x320", 3840, 320, 320, True, False, 2, 1),
     ("x3 dWks 64", 384, 384, P, False, False, 4, 64),
     ("x3 dWks 96", 384, 384, P, False, False, 4, 96),
     ("x3 dWks 128", 384, 384, P, False, False, 4, 128),
