@@ -60,7 +60,10 @@ typedef struct FdGemmDesc {
   int tile;              /* 0 = auto; fp32 MFMA (bitwise an fmaf chain over k): 1: 128x128, 2: 64x64, 3: 128x32;
                             4: 256x128 split-bf16 (each fp32 operand = 3 exact bf16 terms, 6 bf16-MFMA products,
                             fp32 accumulate: fp32 accuracy, not bitwise the fmaf chain).  Auto picks 4 for the
-                            large pair-level GEMMs unless FD_GEMM_EXACT_F32=1 is set in the environment. */
+                            large pair-level GEMMs unless FD_GEMM_EXACT_F32=1 is set in the environment.
+                            5: latency kernel (fp32 MFMA, 32x32 tiles, K split over the waves of a block) that auto
+                            picks when the problem has fewer 64x64 tiles than CUs (node-level GEMMs of sampling);
+                            needs K % 8 == 0 and unit-stride 16-byte aligned operands. */
   int ksplit;            /* >1: split K over blocks, C += alpha*A*B atomically
                             (weight gradients: tiny MxN, huge K); epilogue-free */
   int mtiles;            /* 0 = auto; >0: consecutive M tiles pipelined per block (un-batched, ksplit 1) */

@@ -474,6 +474,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 }
 
 #include "fd_gemm_split.h"   // gemm_bx3_kernel: tile code 4
+#include "fd_gemm_direct.h"  // gemm_direct_kernel: tile code 5
 
 // 16-byte staging is legal when the contiguous index is a multiple of 4 everywhere the kernel can touch it
 bool operands_vectorisable(const FdGemmDesc& d) {
@@ -555,6 +556,12 @@ int plan_tile(const FdGemmDesc& d, bool fast) {
     if ((cfg == 1 || (d.N >= 96 && d.M >= 1024 && blocks_x3 >= 96)) && fast && d.K >= 64 && bx3_layout_ok(d) &&
         split_enabled())
       cfg = 4;
+    // latency-bound launches (node-level GEMMs of sampling: fewer 64x64 tiles than CUs): 32x32 tiles, K split
+    // over the four waves of the block
+    const long blocks64 = (long)fd_cdiv(d.M, 64) * fd_cdiv(d.N, 64) * (d.batch > 0 ? d.batch : 1);
+    // (measured: 128x320x320 8 vs 11 us, 128x256x2688 25 vs 68 us, 1024x320x320 9 vs 12 us; with >= ~200 tiles of
+    // 64x64 the wider tile's operand reuse wins again)
+    if (cfg != 4 && blocks64 <= 128 && d.M <= 1024 && direct_ok(d)) cfg = 5;
   }
   if (!fast && cfg == 1) cfg = 2;   // the element-wise staging path is only instantiated for the small tiles
   return cfg;
@@ -645,6 +652,10 @@ extern "C" int fd_gemm(const FdGemmDesc* desc, void* stream_) {
     case 2: return fast ? launch_cfg<64, 64, 2, 2, true>(d, stream) : launch_cfg<64, 64, 2, 2, false>(d, stream);
     case 3: return fast ? launch_cfg<128, 32, 4, 1, true>(d, stream) : launch_cfg<128, 32, 4, 1, false>(d, stream);
     case 4: return launch_bx3(d, stream);
+    case 5:
+      FD_CHECK_ARG(direct_ok(d), "fd_gemm: tile 5 (latency kernel) needs K %% 8 == 0, unit-stride 16-byte aligned operands, "
+                                 "no pair epilogue / split-K / row sum");
+      return launch_direct(d, stream);
     default: fd_set_error("fd_gemm: bad tile config %d", cfg); return FD_ERR_ARG;
   }
 }

@@ -1,0 +1,136 @@
+// Latency GEMM (fd_gemm tile code 5) for the node-level launches of sampling: M = B*N rows is 128..1024, so the
+// 64x64 kernel runs 10..80 blocks and each of them walks the whole K range alone (12.5 us per launch at M = 128,
+// 60 % of a sampling forward).  Included by fd_gemm.hip inside its anonymous namespace.
+//
+// One block = one 32 x 32 output tile; its four waves SPLIT K (wave w takes the 8-k groups g = w mod 4), so the serial
+// MFMA chain is a quarter of K.  Operand fragments go global -> registers directly in MFMA layout (no LDS, no
+// barrier in the loop): lane (i = l & 31, h = l >> 5) loads the float4 A[i][8g+4h .. +3] (k-contiguous operand) or
+// four coalesced dwords (row-contiguous operand); four v_mfma_f32_32x32x2_f32 consume it.  Two groups are kept in
+// flight.  The four partial tiles meet in LDS and every thread finishes one float4 of the tile with the full fused
+// epilogue.  fp32 MFMA: exact fp32 products and sums (the k order differs from the 64x64 kernel's).
+constexpr int DG = 8;   // k per group
+
+template <bool KC>
+__device__ __forceinline__ void direct_load(float (&v)[4], const float* __restrict__ p, long kstride) {
+  if (KC) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = p[t * kstride];
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_direct_kernel(GemmArgs g) {
+  __shared__ float part[4][32][33];
+  const FdGemmDesc& d = g.d;
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int bm = (int)blockIdx.x / g.nblk_n, bn = (int)blockIdx.x % g.nblk_n;
+  const int m0 = bm * 32, n0 = bn * 32;
+  const int z = (int)blockIdx.y;
+  const int zo = z / d.bdiv, zi = z % d.bdiv;
+  const float* __restrict__ A = d.A + zo * d.a_so + zi * d.a_si;
+  const float* __restrict__ B = d.B + zo * d.b_so + zi * d.b_si;
+  float* __restrict__ C = d.C + zo * d.c_so + zi * d.c_si;
+
+  // rows / columns past the end are clamped: their results are never stored
+  const int ra = (m0 + l31 < d.M) ? m0 + l31 : d.M - 1;
+  const int rb = (n0 + l31 < d.N) ? n0 + l31 : d.N - 1;
+  const float* pa = A + (long)ra * d.a_rs + (long)(4 * h) * d.a_cs;
+  const float* pb = B + (long)rb * d.b_cs + (long)(4 * h) * d.b_rs;
+  const long ag = (long)DG * d.a_cs, bg = (long)DG * d.b_rs;   // pointer step per k group
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int ngroups = d.K / DG;   // K % 8 == 0 (checked by the host)
+  float a0[4], b0[4], a1[4], b1[4];
+  int gi = wave;
+  if (gi < ngroups) {
+    direct_load<A_KC>(a0, pa + gi * ag, d.a_cs);
+    direct_load<B_KC>(b0, pb + gi * bg, d.b_rs);
+  }
+  for (; gi < ngroups; gi += 8) {
+    const bool more1 = gi + 4 < ngroups;
+    if (more1) {
+      direct_load<A_KC>(a1, pa + (gi + 4) * ag, d.a_cs);
+      direct_load<B_KC>(b1, pb + (gi + 4) * bg, d.b_rs);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = fd::mfma_32x32x2(a0[t], b0[t], acc);
+    if (!more1) break;
+    if (gi + 8 < ngroups) {
+      direct_load<A_KC>(a0, pa + (gi + 8) * ag, d.a_cs);
+      direct_load<B_KC>(b0, pb + (gi + 8) * bg, d.b_rs);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = fd::mfma_32x32x2(a1[t], b1[t], acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
+  __syncthreads();
+
+  // thread -> (row, 4 consecutive columns) of the 32 x 32 tile
+  const int row = tid >> 3, c4 = tid & 7;
+  const int m = m0 + row;
+  if (m >= d.M) return;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int col = 4 * c4 + e;
+    v[e] = d.alpha * ((part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]));
+  }
+  const float rs = d.rowscale ? d.rowscale[m] : 1.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int n = n0 + 4 * c4 + e;
+    if (n >= d.N) continue;
+    float x = v[e];
+    if (d.bias) x += d.bias[n];
+    if (d.relu) x = x > 0.f ? x : 0.f;
+    if (d.gate) x = d.gate[(long)m * d.ld_gate + n] > 0.f ? x : 0.f;
+    x *= rs;
+    if (d.resid) x += d.resid[(long)m * d.ld_resid + n];
+    float* cp = C + (long)m * d.ldc + n;
+    if (d.beta) x += *cp;
+    *cp = x;
+  }
+}
+
+bool direct_ok(const FdGemmDesc& d) {
+  // unit-stride operands with 16-byte aligned k groups where they are read as float4; no pair epilogue, no split-K
+  if (d.K <= 0 || (d.K % DG) != 0 || d.pair_p || d.ksplit > 1 || d.a_rowsum) return false;
+  auto al4 = [](long x) { return (x & 3) == 0; };
+  const bool a_kc = (d.a_cs == 1), b_kc = (d.b_rs == 1);
+  if (a_kc) { if (!(fd_aligned16(d.A) && al4(d.a_rs) && al4(d.a_so) && al4(d.a_si))) return false; }
+  else if (d.a_rs != 1) return false;
+  if (b_kc) { if (!(fd_aligned16(d.B) && al4(d.b_cs) && al4(d.b_so) && al4(d.b_si))) return false; }
+  else if (d.b_cs != 1) return false;
+  return true;
+}
+
+int launch_direct(const FdGemmDesc& d, hipStream_t stream) {
+  GemmArgs g;
+  g.d = d;
+  g.nblk_m = fd_cdiv(d.M, 32);
+  g.nblk_n = fd_cdiv(d.N, 32);
+  g.ksplit = 1;
+  g.mtiles = 1;
+  g.epi_vec = 0;
+  const int nb = d.batch > 0 ? d.batch : 1;
+  dim3 grid(g.nblk_m * g.nblk_n, nb, 1), block(256, 1, 1);
+  const bool a_kc = (d.a_cs == 1), b_kc = (d.b_rs == 1);
+  if (a_kc && b_kc)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_direct_kernel<true, true>), grid, block, 0, stream, g);
+  else if (a_kc && !b_kc)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_direct_kernel<true, false>), grid, block, 0, stream, g);
+  else if (!a_kc && b_kc)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_direct_kernel<false, true>), grid, block, 0, stream, g);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_direct_kernel<false, false>), grid, block, 0, stream, g);
+  FD_CHECK_LAUNCH("fd_gemm(direct)");
+  return FD_OK;
+}

@@ -64,6 +64,16 @@ SHAPES = [
     ("node dWks 256x2688 4", 256, 2688, 3840, False, False, 2, 4),
     ("node dWks 256x256 15", 256, 256, 3840, False, False, 2, 15),
     ("node dWks 256x256 60", 256, 256, 3840, False, False, 2, 60),
+    ("lat t2 128x320x320", 128, 320, 320, True, True, 2, 1),
+    ("lat t5 128x320x320", 128, 320, 320, True, True, 5, 1),
+    ("lat t2 128x6816x256", 128, 6816, 256, True, True, 2, 1),
+    ("lat t5 128x6816x256", 128, 6816, 256, True, True, 5, 1),
+    ("lat t2 128x256x2688", 128, 256, 2688, True, True, 2, 1),
+    ("lat t5 128x256x2688", 128, 256, 2688, True, True, 5, 1),
+    ("lat t2 1024x320x320", 1024, 320, 320, True, True, 2, 1),
+    ("lat t5 1024x320x320", 1024, 320, 320, True, True, 5, 1),
+    ("lat t2 1024x960x320", 1024, 960, 320, True, True, 2, 1),
+    ("lat t5 1024x960x320", 1024, 960, 320, True, True, 5, 1),
     ("node NT 3840x320x320", 3840, 320, 320, True, True, 2, 1),
     ("node NT 3840x320x320 t3", 3840, 320, 320, True, True, 3, 1),
     ("node NN 3840x320x320", 3840, 320, 320, True, False, 2, 1),
