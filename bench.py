@@ -9,7 +9,9 @@ all-reduce + Adam.  value = residues/s over all ranks, inputs resident in HBM.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One JSON line on stdout (rank 0).  `roofline` = the dominant kernel (the fd_gemm tile with the largest share of the
-step: the 256x128 split-bf16 MFMA kernel), timed with HIP events on its own stream inside the timed region; `cpu_baseline` = the oracle
+step: the 256x128 split-bf16 MFMA kernel), timed with HIP events on its own stream -- in the timed region (where the
+weight-gradient side stream overlaps launches: `timed_region_overlapped_achieved`) and, for `achieved`, in three more
+steps right after it with launches serialised; `cpu_baseline` = the oracle
 (CPU port of the reference, oracle/framediff_oracle.py) on a bounded sample of the same workload.
 """
 import argparse
@@ -227,11 +229,23 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    prof, lib.gemm_profile = lib.gemm_profile, None
+    prof_timed, lib.gemm_profile = lib.gemm_profile, None
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
+    # In the timed region the weight-gradient GEMMs run on a second stream beside the main chain, so a launch's
+    # start/stop events also span the kernels it shares the GPU with.  The roofline of the dominant kernel is therefore
+    # taken from three more steps with that side stream switched off (launches serialised, same shapes, same data);
+    # the overlapped figure of the timed region is reported next to it.
+    from se3_diffusion_amd import ops as fops
+    side_was = fops.set_grad_stream(False)
+    lib.gemm_profile = []
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    prof, lib.gemm_profile = lib.gemm_profile, None
+    fops.set_grad_stream(side_was)
 
     if rank != 0:
         return
@@ -243,10 +257,12 @@ def main():
         rows = sorted(shapes.items(), key=lambda kv: -kv[1][1])
         sys.stderr.write("tile akc bkc (M,N,K,batch,gate,beta,pair,ksplit)  calls/step  ms/step  TF/s\n")
         for k, v in rows[:40]:
-            sys.stderr.write(f"{k}  {v[2] / a.steps:.1f}  {v[1] / a.steps * 1e3:.3f}  {v[0] / v[1] / 1e12:.1f}\n")
+            sys.stderr.write(f"{k}  {v[2] / 3:.1f}  {v[1] / 3 * 1e3:.3f}  {v[0] / v[1] / 1e12:.1f}\n")
     tile, dflops, dtime, dn, all_flops, tot_t = dominant_gemm(prof)
     kname, peak = _KERNELS[tile]
     achieved = dflops / dtime / 1e12
+    nprof = 3
+    t_tile, t_flops, t_time, _t_n, t_all_flops, _t_tot = dominant_gemm(prof_timed)
     ms = dt / a.steps * 1e3
     res = {
         "metric": "residues/sec IPA fwd+bwd" if a.mode == "train" else "residues/sec IPA fwd",
@@ -260,12 +276,15 @@ def main():
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": None, "kernel": kname,
                      "vs_fp32_mfma_peak": round(achieved / 157.3, 4),
-                     "launches_per_step": dn // max(1, a.steps),
+                     "measured_on": "3 steps right after the timed region with the gradient side stream off "
+                                    "(HIP events per fd_gemm launch on its stream)",
+                     "timed_region_overlapped_achieved": round(t_flops / max(t_time, 1e-9) / 1e12, 2),
+                     "launches_per_step": dn // nprof,
                      "avg_launch_us": round(dtime / max(1, dn) * 1e6, 2),
                      "algorithmic_flops_per_launch": round(dflops / max(1, dn), 1),
-                     "gemm_time_frac_of_step": round(tot_t / dt, 4),
+                     "gemm_time_frac_of_step": round(tot_t / nprof / (dt / a.steps), 4),
                      "all_gemm_tflops": round(all_flops / max(tot_t, 1e-9) / 1e12, 2),
-                     "step_model_tflops": round(all_flops / dt / 1e12, 2)},
+                     "step_model_tflops": round(t_all_flops / dt / 1e12, 2)},
     }
     if not a.no_cpu_baseline and world == 1:
         try:

@@ -93,6 +93,13 @@ def side(fn, tensors, rows):
     _SIDE["used"] = True
 
 
+def set_grad_stream(on):
+    """Enable / disable the gradient side stream; returns the previous setting."""
+    was = _SIDE["on"]
+    _SIDE["on"] = bool(on)
+    return was
+
+
 def join_grad_stream():
     """Main stream waits for every side-stream gradient launch; releases the operand references."""
     if _SIDE["used"]:
