@@ -77,6 +77,7 @@ _KERNELS = {
     1: ("gemm_kernel<128,128,2,2,*,*> (fp32 v_mfma_f32_32x32x2_f32)", 157.3),
     2: ("gemm_kernel<64,64,2,2,*,*> (fp32 v_mfma_f32_32x32x2_f32)", 157.3),
     3: ("gemm_kernel<128,32,4,1,*,*> (fp32 v_mfma_f32_32x32x2_f32)", 157.3),
+    6: ("gemm_bx3_kernel<128,*,*> (128x128 split-bf16 tile, two blocks per CU)", round(2500.0 / 6.0, 1)),
     5: ("gemm_direct_kernel<*,*> (32x32 latency tiles, fp32 v_mfma_f32_32x32x2_f32)", 157.3),
     4: ("gemm_bx3_kernel<*,*> (256x128, fp32 operands as 3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per k-step)",
         round(2500.0 / 6.0, 1)),

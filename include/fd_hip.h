@@ -63,7 +63,10 @@ typedef struct FdGemmDesc {
                             large pair-level GEMMs unless FD_GEMM_EXACT_F32=1 is set in the environment.
                             5: latency kernel (fp32 MFMA, 32x32 tiles, K split over the waves of a block) that auto
                             picks when the problem has fewer 64x64 tiles than CUs (node-level GEMMs of sampling);
-                            needs K % 8 == 0 and unit-stride 16-byte aligned operands. */
+                            needs K % 8 == 0 and unit-stride 16-byte aligned operands.
+                            6: the split-bf16 kernel with a 128x128 block tile (two blocks per CU); never picked
+                            automatically by fd_gemm (slower than 4 except for 128-row outputs), the host uses it
+                            for the N_out = 128 weight gradients. */
   int ksplit;            /* >1: split K over blocks, C += alpha*A*B atomically
                             (weight gradients: tiny MxN, huge K); epilogue-free */
   int mtiles;            /* 0 = auto; >0: consecutive M tiles pipelined per block (un-batched, ksplit 1) */

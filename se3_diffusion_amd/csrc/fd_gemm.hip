@@ -509,10 +509,11 @@ bool bx3_layout_ok(const FdGemmDesc& d) {
   return a_kc || (!a_kc && !b_kc);
 }
 
+template <int BM>
 int launch_bx3(const FdGemmDesc& d, hipStream_t stream) {
   GemmArgs g;
   g.d = d;
-  g.nblk_m = fd_cdiv(d.M, XBM);
+  g.nblk_m = fd_cdiv(d.M, BM);
   g.nblk_n = fd_cdiv(d.N, XBN);
   const int nb = d.batch > 0 ? d.batch : 1;
   g.ksplit = d.ksplit > 1 ? d.ksplit : 1;
@@ -521,13 +522,13 @@ int launch_bx3(const FdGemmDesc& d, hipStream_t stream) {
   g.mtiles = 1;
   g.epi_vec = epilogue_vectorisable(d, g.ksplit);
   const bool a_kc = (d.a_cs == 1), b_kc = (d.b_rs == 1);
-  dim3 grid(g.nblk_m * g.nblk_n, nb, g.ksplit), block(XTHR, 1, 1);
+  dim3 grid(g.nblk_m * g.nblk_n, nb, g.ksplit), block(SplitCfg<BM>::NTHR, 1, 1);
   if (a_kc && b_kc)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<true, true>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<BM, true, true>), grid, block, 0, stream, g);
   else if (a_kc && !b_kc)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<true, false>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<BM, true, false>), grid, block, 0, stream, g);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<false, false>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<BM, false, false>), grid, block, 0, stream, g);
   FD_CHECK_LAUNCH("fd_gemm(split-bf16)");
   return FD_OK;
 }
@@ -636,10 +637,10 @@ extern "C" int fd_gemm(const FdGemmDesc* desc, void* stream_) {
   }
   const bool fast = operands_vectorisable(d);
   const int cfg = plan_tile(d, fast);
-  if (cfg == 4)
-    FD_CHECK_ARG(fast && bx3_layout_ok(d), "fd_gemm: tile 4 (split-bf16) needs 16-byte aligned operands and a k-contiguous A "
+  if (cfg == 4 || cfg == 6)
+    FD_CHECK_ARG(fast && bx3_layout_ok(d), "fd_gemm: tiles 4/6 (split-bf16) need 16-byte aligned operands and a k-contiguous A "
                                            "or both operands row-contiguous");
-  if (d.a_rowsum && !((cfg == 2 || cfg == 4) && fast && d.a_cs != 1 && d.b_rs != 1 && d.batch <= 1)) {
+  if (d.a_rowsum && !((cfg == 2 || cfg == 4 || cfg == 6) && fast && d.a_cs != 1 && d.b_rs != 1 && d.batch <= 1)) {
     // the fused row-sum lives in the instantiations with both operands row-contiguous (the dW = dY^T X case) of
     // the 64x64 fp32 kernel and the split-bf16 kernel; anything else takes the stand-alone column-sum kernel
     FD_CHECK_ARG(d.a_rs == 1 && d.alpha == 1.0f && (d.batch <= 1), "fd_gemm: a_rowsum needs a row-contiguous A, alpha 1, no batch");
@@ -651,7 +652,8 @@ extern "C" int fd_gemm(const FdGemmDesc* desc, void* stream_) {
     case 1: return launch_cfg<128, 128, 2, 2, true>(d, stream);
     case 2: return fast ? launch_cfg<64, 64, 2, 2, true>(d, stream) : launch_cfg<64, 64, 2, 2, false>(d, stream);
     case 3: return fast ? launch_cfg<128, 32, 4, 1, true>(d, stream) : launch_cfg<128, 32, 4, 1, false>(d, stream);
-    case 4: return launch_bx3(d, stream);
+    case 4: return launch_bx3<256>(d, stream);
+    case 6: return launch_bx3<128>(d, stream);
     case 5:
       FD_CHECK_ARG(direct_ok(d), "fd_gemm: tile 5 (latency kernel) needs K %% 8 == 0, unit-stride 16-byte aligned operands, "
                                  "no pair epilogue / split-K / row sum");

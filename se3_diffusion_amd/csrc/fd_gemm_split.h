@@ -1,4 +1,4 @@
-// Split-bf16 GEMM kernel (fd_gemm tile code 4) for the pair-level GEMMs.  Included by fd_gemm.hip inside its
+// Split-bf16 GEMM kernel (fd_gemm tile codes 4 and 6) for the pair-level GEMMs.  Included by fd_gemm.hip inside its
 // anonymous namespace (uses GemmArgs, store_tile, store_tile_vec, fd_xcd_swizzle).
 //
 // gfx950 runs the bf16 MFMA at 16x the fp32-MFMA rate.  An fp32 value splits EXACTLY into three bf16 terms
@@ -11,25 +11,36 @@
 // Operands stay fp32 in HBM; the split happens in registers on the way global -> LDS (11 VALU ops per element
 // pair).  The block is wave-specialised so that this VALU work never sits in the instruction stream of a wave that
 // feeds the matrix pipe:
-//   * 8 consumer waves (4 x 2; wave tile 64 x 64 of the 256 x 128 block tile) issue only ds_read_b128 + MFMA;
-//   * 4 producer waves (one per SIMD) load later stages from global memory, split them and write them to LDS.
+//   * consumer waves (wave tile 64 x 64) issue only ds_read_b128 + MFMA;
+//   * producer waves load later stages from global memory, split them and write them to LDS.
 // A stage is 16 k (one MFMA step) of every row: three 32-byte bf16 planes + 16 B pad = 112 B per row (7 x 16 B:
 // conflict-free ds_read_b128; the producer's row order makes every 8-lane ds_write_b128 group tile one 128-byte
-// bank window).  LDS holds a RING OF THREE stages: while the consumers multiply stage s out of registers they
-// prefetch the fragments of stage s+1 (complete since the previous barrier) and the producers fill stage s+2, so
-// the single barrier per stage never has an LDS read or a global load waiting behind it.
+// bank window).
+//
+// Two block shapes (BM x 128 output tile, BM/64 x 2 consumer waves, BM/64 producer waves):
+//   BM = 256 (tile 4): 12 waves, LDS ring of THREE stages = 129 KB -> one block per CU.  While the consumers multiply
+//     stage s out of registers they prefetch the fragments of stage s+1 (complete since the previous barrier) and
+//     the producers fill stage s+2: the single barrier per stage never has an LDS read waiting behind it.
+//   BM = 128 (tile 6): 6 waves, ring of TWO stages, 66 KB -> two blocks per CU, so the prologue and the (HBM-heavy)
+//     epilogue of one block run under the MFMA loop of the other; the natural shape for the N_out = 128 weight
+//     gradients too.
 constexpr int XBK = 16;
 constexpr int XROWB = 3 * XBK * 2 + 16;   // bytes per staged row
-constexpr int XCONS = 512;                // consumer (MFMA) threads: waves 0..7
-constexpr int XPROD = 256;                // producer (load + split + LDS store) threads: waves 8..11
-constexpr int XTHR = XCONS + XPROD;
-constexpr int XBM = 256, XBN = 128;
-constexpr int XSTAGE = (XBM + XBN) * XROWB;
-constexpr int XRING = 3;
-constexpr int XEPI = XBM * (XBN + 4) * 4;   // the vector epilogue transposes the C tile through LDS
-constexpr int XLDS = XRING * XSTAGE > XEPI ? XRING * XSTAGE : XEPI;
-static_assert(XLDS <= 160 * 1024, "LDS");
-static_assert(XBM == XPROD, "the fused row sum relies on producer thread t staging row t of a row-contiguous A");
+constexpr int XBN = 128;
+constexpr int XBM = 256;                  // the wide shape (tile 4)
+
+template <int BM>
+struct SplitCfg {
+  static constexpr int NCONS = BM * 2;           // consumer threads: (BM / 64) x 2 waves
+  static constexpr int NPROD = BM;               // producer threads: BM / 64 waves
+  static constexpr int NTHR = NCONS + NPROD;
+  static constexpr int STAGE = (BM + XBN) * XROWB;
+  static constexpr int RING = BM == 256 ? 3 : 2;
+  static constexpr int EPI = BM * (XBN + 4) * 4;  // the vector epilogue transposes the C tile through LDS
+  static constexpr int LDS = RING * STAGE > EPI ? RING * STAGE : EPI;
+  static constexpr int BLOCKS_PER_CU = BM == 256 ? 1 : 2;
+  static_assert(LDS * BLOCKS_PER_CU <= 160 * 1024, "LDS");
+};
 
 __device__ __forceinline__ void split8(const float (&x)[8], uint4& s0, uint4& s1, uint4& s2) {
   unsigned t0[4], t1[4], t2[4];
@@ -49,12 +60,12 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4& s0, uint4& s1
   s2 = make_uint4(t2[0], t2[1], t2[2], t2[3]);
 }
 
-// Stages a ROWS x 16 operand tile.  A slot = (row, group of 8 consecutive k).
+// Stages a ROWS x 16 operand tile with NPROD producer threads.  A slot = (row, group of 8 consecutive k).
 //   KC : k contiguous in memory   -> 2 x float4 per slot, 2 lanes per row
 //   !KC: row contiguous in memory -> 8 dword loads per slot (coalesced across the lanes = rows)
-template <int ROWS, bool KC>
+template <int ROWS, bool KC, int NPROD>
 struct SplitStager {
-  static constexpr int NS = ROWS * 2 / XPROD;
+  static constexpr int NS = ROWS * 2 / NPROD;
   const float* p[NS];
   int kofs[NS];   // first k of the slot inside the stage
   int lofs[NS];   // LDS byte offset of the slot (plane 0)
@@ -66,7 +77,7 @@ struct SplitStager {
     kstep = (long)XBK * cs_;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      const int f = tid + XPROD * i;   // tid = producer thread index
+      const int f = tid + NPROD * i;   // tid = producer thread index
       // KC: two lanes cover the 64 contiguous bytes a row contributes to a stage; the four rows of an 8-lane
       // ds_write_b128 group are taken 2 apart (2 * 112 B = 96 mod 128: the group tiles one 32-bank window)
       const int q = f >> 1;
@@ -134,11 +145,13 @@ struct SplitStager {
   }
 };
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(XTHR, 1) void gemm_bx3_kernel(GemmArgs g) {
-  constexpr int BM = XBM, BN = XBN, TM = 2, TN = 2;
+template <int BM, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(SplitCfg<BM>::NTHR, SplitCfg<BM>::BLOCKS_PER_CU) void gemm_bx3_kernel(GemmArgs g) {
+  using Cfg = SplitCfg<BM>;
+  constexpr int BN = XBN, TM = 2, TN = 2;
+  constexpr int NCONS = Cfg::NCONS, NPROD = Cfg::NPROD, STAGE = Cfg::STAGE, RING = Cfg::RING;
   constexpr int A_BYTES = BM * XROWB;
-  __shared__ __attribute__((aligned(16))) char lds[XLDS];
+  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS];
 
   const FdGemmDesc& d = g.d;
   const int tid = (int)threadIdx.x;
@@ -159,15 +172,15 @@ __global__ __launch_bounds__(XTHR, 1) void gemm_bx3_kernel(GemmArgs g) {
   const int nk = nkt - kt0;
   if (nk <= 0) return;
 
-  if (tid >= XCONS) {
+  if (tid >= NCONS) {
     // ---- producer waves: global -> registers -> (split) -> LDS ring; two register sets = two stages in flight ----
-    const int ptid = tid - XCONS;
+    const int ptid = tid - NCONS;
     fd::raise_wave_priority();   // the producer's instruction stream must never wait for an issue slot
     const float* __restrict__ A = d.A + zo * d.a_so + zi * d.a_si;
     const float* __restrict__ B = d.B + zo * d.b_so + zi * d.b_si;
-    SplitStager<BM, A_KC> sa;
-    SplitStager<BN, B_KC> sb;
-    constexpr int NSA = SplitStager<BM, A_KC>::NS, NSB = SplitStager<BN, B_KC>::NS;
+    SplitStager<BM, A_KC, NPROD> sa;
+    SplitStager<BN, B_KC, NPROD> sb;
+    constexpr int NSA = SplitStager<BM, A_KC, NPROD>::NS, NSB = SplitStager<BN, B_KC, NPROD>::NS;
     float ra[2][NSA][8], rb[2][NSB][8];
     sa.init(A, d.a_rs, d.a_cs, m0, d.M, kt0 * XBK, ptid);
     sb.init(B, d.b_cs, d.b_rs, n0, d.N, kt0 * XBK, ptid);   // the staged "row" of B is n
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(XTHR, 1) void gemm_bx3_kernel(GemmArgs g) {
       ++lk;
     };
     // fused bias gradient of dW = dY^T X (A = dY^T row-contiguous: producer thread t stages row m0 + t in all of
-    // its slots): row sums of A over k, taken from the registers on their way to LDS
+    // its slots, NPROD == BM): row sums of A over k, taken from the registers on their way to LDS
     const bool do_rowsum = !A_KC && d.a_rowsum != nullptr && bn == 0 && z == 0;
     float rsum = 0.f;
     int wbuf = 0;   // ring slot of the next LDS store
@@ -188,32 +201,35 @@ __global__ __launch_bounds__(XTHR, 1) void gemm_bx3_kernel(GemmArgs g) {
         for (int i = 0; i < NSA; ++i)
           rsum += ((xa[i][0] + xa[i][1]) + (xa[i][2] + xa[i][3])) + ((xa[i][4] + xa[i][5]) + (xa[i][6] + xa[i][7]));
       }
-      char* dst = lds + wbuf * XSTAGE;
+      char* dst = lds + wbuf * STAGE;
       sa.store(xa, dst);
       sb.store(xb, dst + A_BYTES);
-      wbuf = (wbuf == XRING - 1) ? 0 : wbuf + 1;
+      wbuf = (wbuf == RING - 1) ? 0 : wbuf + 1;
     };
+    // AHEAD = how many stages beyond the one being multiplied are complete in LDS at a barrier
+    constexpr int AHEAD = RING - 1;
     issue(ra[0], rb[0]);
     if (nk > 1) issue(ra[1], rb[1]);
     put(ra[0], rb[0]);
     if (nk > 2) issue(ra[0], rb[0]);
-    if (nk > 1) {
+    if (AHEAD == 2 && nk > 1) {
       put(ra[1], rb[1]);
       if (nk > 3) issue(ra[1], rb[1]);
     }
-    __syncthreads();   // stages 0 and 1 are in the ring
-    // during stage `it`: stage it+2 goes registers -> ring slot (it+2) % 3 (last read, as stage it-1, two barriers
-    // ago) and the loads of stage it+4 refill the register set
+    __syncthreads();   // the first AHEAD stages are in the ring
+    // during stage `it`: stage it+AHEAD goes registers -> its ring slot (last read AHEAD barriers ago) and the loads
+    // of stage it+AHEAD+2 refill the register set
     auto step = [&](int it, float (&xa)[NSA][8], float (&xb)[NSB][8]) {
-      if (it + 2 < nk) {
+      if (it + AHEAD < nk) {
         put(xa, xb);
-        if (it + 4 < nk) issue(xa, xb);
+        if (it + AHEAD + 2 < nk) issue(xa, xb);
       }
       __syncthreads();
     };
+    // the register set holding stage s is s & 1
     for (int it = 0; it < nk; it += 2) {
-      step(it, ra[0], rb[0]);
-      if (it + 1 < nk) step(it + 1, ra[1], rb[1]);
+      step(it, ra[AHEAD & 1], rb[AHEAD & 1]);
+      if (it + 1 < nk) step(it + 1, ra[(AHEAD + 1) & 1], rb[(AHEAD + 1) & 1]);
     }
     if (!A_KC && do_rowsum && m0 + ptid < d.M) atomicAdd(d.a_rowsum + m0 + ptid, d.alpha * rsum);
     if (g.epi_vec) {   // the two barriers of the consumers' LDS-transposed epilogue
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(XTHR, 1) void gemm_bx3_kernel(GemmArgs g) {
   uint4 fa[2][TM][3], fb[2][TN][3];
   int rbuf = 0;   // ring slot of the next fragment read
   auto read_frags = [&](uint4 (&xa)[TM][3], uint4 (&xb)[TN][3]) {
-    const char* st = lds + rbuf * XSTAGE;
+    const char* st = lds + rbuf * STAGE;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
 #pragma unroll
@@ -253,7 +269,7 @@ __global__ __launch_bounds__(XTHR, 1) void gemm_bx3_kernel(GemmArgs g) {
       for (int j = 0; j < TN; ++j)
         xb[j][s] = *reinterpret_cast<const uint4*>(st + b_frag + j * 32 * XROWB + s * 2 * XBK);
     }
-    rbuf = (rbuf == XRING - 1) ? 0 : rbuf + 1;
+    rbuf = (rbuf == RING - 1) ? 0 : rbuf + 1;
   };
   // term pairs (i, j) with i + j <= 2, smallest first; the four accumulators are interleaved so that dependent
   // MFMAs are four issues apart
@@ -268,23 +284,33 @@ __global__ __launch_bounds__(XTHR, 1) void gemm_bx3_kernel(GemmArgs g) {
         for (int j = 0; j < TN; ++j) acc[i][j] = fd::mfma_32x32x16_bf16(xa[i][PA[p]], xb[j][PB[p]], acc[i][j]);
     }
   };
-  // stage it is multiplied out of registers while the fragments of stage it+1 (complete in the ring since the last
-  // barrier) are fetched; the barrier itself carries no LDS wait on this side
-  auto step = [&](int it, uint4 (&ca)[TM][3], uint4 (&cb)[TN][3], uint4 (&na)[TM][3], uint4 (&nb)[TN][3]) {
-    if (it + 1 < nk) read_frags(na, nb);
-    mfmas(ca, cb);
-    fd::block_barrier_nofence();
-  };
 
-  __syncthreads();   // stages 0 and 1 are in the ring
-  read_frags(fa[0], fb[0]);
-  for (int it = 0; it < nk; it += 2) {
-    step(it, fa[0], fb[0], fa[1], fb[1]);
-    if (it + 1 < nk) step(it + 1, fa[1], fb[1], fa[0], fb[0]);
+  __syncthreads();   // the first stages are in the ring
+  if (RING == 3) {
+    // stage it is multiplied out of registers while the fragments of stage it+1 (complete in the ring since the
+    // last barrier) are fetched; the barrier itself carries no LDS wait on this side
+    auto step = [&](int it, uint4 (&ca)[TM][3], uint4 (&cb)[TN][3], uint4 (&na)[TM][3], uint4 (&nb)[TN][3]) {
+      if (it + 1 < nk) read_frags(na, nb);
+      mfmas(ca, cb);
+      fd::block_barrier_nofence();
+    };
+    read_frags(fa[0], fb[0]);
+    for (int it = 0; it < nk; it += 2) {
+      step(it, fa[0], fb[0], fa[1], fb[1]);
+      if (it + 1 < nk) step(it + 1, fa[1], fb[1], fa[0], fb[0]);
+    }
+  } else {
+    // two-stage ring: stage it+1 is only complete at the barrier that ends stage it, so its fragments are fetched
+    // after the barrier; the co-resident second block covers that latency
+    for (int it = 0; it < nk; ++it) {
+      read_frags(fa[0], fb[0]);
+      mfmas(fa[0], fb[0]);
+      fd::block_barrier_nofence();
+    }
   }
 
   if (g.epi_vec)
-    store_tile_vec<BM, BN, TM, TN, XCONS>(d, C, acc, reinterpret_cast<float*>(lds), m0, n0, wm, wn, h, l31, tid);
+    store_tile_vec<BM, BN, TM, TN, NCONS>(d, C, acc, reinterpret_cast<float*>(lds), m0, n0, wm, wn, h, l31, tid);
   else
     store_tile<TM, TN>(d, C, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, h, l31, g.ksplit > 1);
 }

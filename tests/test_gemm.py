@@ -196,13 +196,13 @@ def test_gemm_split_unsupported_layout_raises(emu_lib):
         _run(emu_lib, "cpu", 33, 6, 65, True, True, 4)         # unaligned operands
 
 
-def _splitk4(lib, dev, M=136, N=72, K=1000, ks=5):
+def _splitk4(lib, dev, M=136, N=72, K=1000, ks=5, tile=4):
     g = torch.Generator().manual_seed(4)
     dY = torch.randn(K, M, generator=g)
     X = torch.randn(K, N, generator=g)
     C0 = torch.randn(M, N, generator=g)
     C = C0.clone().to(dev)
-    lib.gemm(dY.to(dev), X.to(dev), C, M, N, K, (1, M), (N, 1), N, ksplit=ks, tile=4)
+    lib.gemm(dY.to(dev), X.to(dev), C, M, N, K, (1, M), (N, 1), N, ksplit=ks, tile=tile)
     ref = C0.double() + dY.double().t() @ X.double()
     assert (C.cpu().double() - ref).abs().max() < 2e-6 * ref.abs().max()
 
@@ -225,7 +225,7 @@ def test_gemm_split_gpu(hip_lib):
     assert _run(hip_lib, "cuda", 65536, 128, 128, True, True, 0) < 2e-6
 
 
-def _splitk4_rowsum(lib, dev, M=384, N=136, K=3000, ks=6):
+def _splitk4_rowsum(lib, dev, M=384, N=136, K=3000, ks=6, tile=4):
     """dW = dY^T X on the split-bf16 kernel with the bias gradient (column sums of dY) fused into the producers"""
     g = torch.Generator().manual_seed(8)
     dY = torch.randn(K, M, generator=g)
@@ -233,7 +233,7 @@ def _splitk4_rowsum(lib, dev, M=384, N=136, K=3000, ks=6):
     C = torch.zeros(M, N).to(dev)
     db0 = torch.randn(M, generator=g)
     db = db0.clone().to(dev)
-    lib.gemm(dY.to(dev), X.to(dev), C, M, N, K, (1, M), (N, 1), N, ksplit=ks, tile=4, a_rowsum=db)
+    lib.gemm(dY.to(dev), X.to(dev), C, M, N, K, (1, M), (N, 1), N, ksplit=ks, tile=tile, a_rowsum=db)
     ref = dY.double().t() @ X.double()
     assert (C.cpu().double() - ref).abs().max() < 2e-6 * ref.abs().max()
     rs = db0.double() + dY.double().sum(0)
@@ -248,3 +248,28 @@ def test_gemm_split_rowsum_emu(emu_lib):
 def test_gemm_split_rowsum_gpu(hip_lib):
     _splitk4_rowsum(hip_lib, "cuda")
     _splitk4_rowsum(hip_lib, "cuda", M=384, N=384, K=65536, ks=64)
+
+
+# ---- tile 6: the same split-bf16 kernel with a 128 x 128 block tile, two blocks per CU, two-stage LDS ring ----
+@pytest.mark.parametrize("layout", SPLIT_LAYOUTS)
+def test_gemm_split128_layouts_emu(emu_lib, layout):
+    for (M, N, K) in SPLIT_CASES[:4]:
+        assert _run(emu_lib, "cpu", M, N, K, layout[0], layout[1], 6) < 2e-6, (M, N, K)
+    assert _run(emu_lib, "cpu", 152, 132, 72, layout[0], layout[1], 6, epi=True) < 2e-6
+
+
+def test_gemm_split128_splitk_rowsum_emu(emu_lib):
+    _splitk4(emu_lib, "cpu", tile=6)
+    _splitk4_rowsum(emu_lib, "cpu", M=200, N=72, K=200, ks=3, tile=6)
+
+
+@pytest.mark.gpu
+def test_gemm_split128_gpu(hip_lib):
+    for (a_kc, b_kc) in SPLIT_LAYOUTS:
+        for (M, N, K) in SPLIT_CASES:
+            assert _run(hip_lib, "cuda", M, N, K, a_kc, b_kc, 6) < 2e-6, (a_kc, b_kc, M, N, K)
+        assert _run(hip_lib, "cuda", 300, 132, 72, a_kc, b_kc, 6, epi=True) < 2e-6
+    _splitk4(hip_lib, "cuda", tile=6)
+    _splitk4(hip_lib, "cuda", M=128, N=384, K=40000, ks=64, tile=6)
+    _splitk4_rowsum(hip_lib, "cuda", tile=6)
+    _splitk4_rowsum(hip_lib, "cuda", M=128, N=128, K=65536, ks=64, tile=6)

@@ -44,6 +44,19 @@ SHAPES = [
     ("probe shortK bigN", 32768, 4096, 384, True, True, 1, 1),
     ("probe longK N384", 122880, 384, 1536, True, True, 1, 1),
     ("probe K384 N384 M64k", 65536, 384, 384, True, True, 1, 1),
+    # split-bf16, two blocks per CU (tile 6)
+    ("y6 edge_fwd_W2 NT", P, 384, 384, True, True, 6, 1),
+    ("y6 edge_fwd_W1z NT", P, 384, 128, True, True, 6, 1),
+    ("y6 edge_fwd_Wf NT", P, 128, 384, True, True, 6, 1),
+    ("y6 edge_fwd_Wfz NT", P, 128, 128, True, True, 6, 1),
+    ("y6 edge_bwd_dX NN", P, 384, 384, True, False, 6, 1),
+    ("y6 edge_bwd_dX NN N128", P, 128, 384, True, False, 6, 1),
+    ("y6 edge_bwd_dW TN", 384, 384, P, False, False, 6, 128),
+    ("y6 dW 384x128", 384, 128, P, False, False, 6, 256),
+    ("y6 dW 128x384", 128, 384, P, False, False, 6, 256),
+    ("y6 dW 128x128", 128, 128, P, False, False, 6, 768),
+    ("y6 sample edge W2 N=128", 16384, 384, 384, True, True, 6, 1),
+    ("y6 square 4096 NT", 4096, 4096, 4096, True, True, 6, 1),
     # split-bf16 (tile 4) on the same pair-level shapes
     ("x3 edge_fwd_W2 NT", P, 384, 384, True, True, 4, 1),
     ("x3 edge_fwd_W1z NT", P, 384, 128, True, True, 4, 1),
