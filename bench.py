@@ -184,7 +184,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an AMD GPU (the hot path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    from se3_diffusion_amd import hip, train_step as ts
+    from se3_diffusion_amd import hip, loss as floss, train_step as ts
     from se3_diffusion_amd.model.score_network import ScoreNetwork
     lib = hip.get_lib()
 
@@ -210,7 +210,7 @@ def main():
             return
         grads.zero()
         out = model(batch)
-        loss = ts.dsm_loss(batch, out, gt37)
+        loss = floss.dsm_loss(batch, out, gt37)     # fused Experiment.loss_fn arithmetic (fd_dsm_loss)
         loss.backward()
         grads.all_reduce_mean()
         opt.step()
@@ -271,7 +271,7 @@ def main():
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"config/base.yaml ScoreNetwork ({a.blocks} IPA blocks, 17.4M params), per-GPU batch "
-                               f"B={B} x N={N} residues, {'fwd + DSM loss + bwd + RCCL grad all-reduce + Adam' if a.mode == 'train' else 'forward only'}",
+                               f"B={B} x N={N} residues, {'fwd + fused DSM loss + bwd + RCCL grad all-reduce + Adam' if a.mode == 'train' else 'forward only'}",
                    "parallelism": f"dp{world}", "global_batch": world * B, "n_res": N,
                    "arithmetic": "fp32 storage and accumulation everywhere; pair-level GEMMs = 3-term bf16 split on the bf16 MFMA (fp32-accurate, FD_GEMM_EXACT_F32=1 forces the fp32 MFMA), all other GEMMs fp32 MFMA, IGSO(3) fp64"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",

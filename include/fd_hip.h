@@ -183,6 +183,40 @@ int fd_se3_reverse_step(const float* rig_t, const double* rot_score, const doubl
                         lets one captured hipGraph serve every t */, double dt, double noise_scale,
                         double coord_scale, int center, int diffuse_rot, int diffuse_trans, float* out, void* stream);
 
+/* ---- training loss (the step next to the hot path): experiments/train_se3_diffusion.py:524-693 ----
+ * Experiment.loss_fn, separate_rot_loss branch: translation score / x0 loss, rotation axis + angle loss,
+ * backbone-atom loss and the 5N x 5N distance-matrix loss with their per-example normalisers and t filters, value AND
+ * gradient w.r.t. the network outputs in three launches.  loss[0] = sum_b final_b / #non-empty examples.
+ * terms[b] = {trans_score_loss, trans_x0_loss, axis_loss, angle_loss (weighted), bb_atom_loss (weighted),
+ * dist_mat_loss (weighted), final_b, sum of the loss mask}.  scratch: B*N*15 + 2*B floats. */
+typedef struct FdLossDesc {
+  int B, N;
+  const float* res_mask;            /* [B,N] */
+  const float* fixed_mask;          /* [B,N] */
+  const float* t;                   /* [B]   */
+  const float* gt_trans_score;      /* [B,N,3] */
+  const double* gt_rot_score;       /* [B,N,3] */
+  const float* trans_score_scaling; /* [B] */
+  const float* rot_score_scaling;   /* [B] */
+  const float* gt_rigids;           /* [B,N,7] rigids_0 */
+  const float* gt_atom37;           /* [B,N,37,3] */
+  const double* rot_score;          /* network outputs: [B,N,3] fp64 */
+  const float* trans_score;         /* [B,N,3] */
+  const float* rigids;              /* [B,N,7] */
+  const float* atom37;              /* [B,N,37,3] */
+  float coordinate_scaling, trans_x0_threshold, trans_loss_weight, rot_loss_weight, rot_loss_t_threshold;
+  float bb_atom_loss_weight, bb_atom_loss_t_filter, aux_loss_weight, dist_mat_loss_weight, dist_mat_loss_t_filter;
+  double* d_rot_score;              /* gradients of loss[0], same shapes as the outputs */
+  float* d_trans_score;
+  float* d_rigids;
+  float* d_atom37;
+  float* terms;                     /* [B,8] */
+  float* loss;                      /* [1] */
+  float* scratch;
+} FdLossDesc;
+
+int fd_dsm_loss(const FdLossDesc* desc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,23 @@ class FdHeadConst(Structure):
     ]
 
 
+class FdLossDesc(Structure):
+    _fields_ = [
+        ("B", c_int), ("N", c_int),
+        ("res_mask", c_void_p), ("fixed_mask", c_void_p), ("t", c_void_p),
+        ("gt_trans_score", c_void_p), ("gt_rot_score", c_void_p),
+        ("trans_score_scaling", c_void_p), ("rot_score_scaling", c_void_p),
+        ("gt_rigids", c_void_p), ("gt_atom37", c_void_p),
+        ("rot_score", c_void_p), ("trans_score", c_void_p), ("rigids", c_void_p), ("atom37", c_void_p),
+        ("coordinate_scaling", c_float), ("trans_x0_threshold", c_float), ("trans_loss_weight", c_float),
+        ("rot_loss_weight", c_float), ("rot_loss_t_threshold", c_float),
+        ("bb_atom_loss_weight", c_float), ("bb_atom_loss_t_filter", c_float), ("aux_loss_weight", c_float),
+        ("dist_mat_loss_weight", c_float), ("dist_mat_loss_t_filter", c_float),
+        ("d_rot_score", c_void_p), ("d_trans_score", c_void_p), ("d_rigids", c_void_p), ("d_atom37", c_void_p),
+        ("terms", c_void_p), ("loss", c_void_p), ("scratch", c_void_p),
+    ]
+
+
 def _ptr(t, off=0):
     """Raw address of a tensor (plus an element offset)."""
     if t is None:
@@ -98,6 +115,7 @@ _SIGS = {
     "fd_sample_ref": "pppppidpls",
     "fd_forward_marginal": "ppppppidddipppp" + "ls",
     "fd_se3_reverse_step": "ppppppiiddpdddiiips",
+    "fd_dsm_loss": "Ss",
 }
 # exact argument lists, kept next to the header for the symbol-export test
 _CT = {"p": c_void_p, "i": c_int, "l": c_long, "f": c_float, "d": c_double, "S": c_void_p, "s": c_void_p}
