@@ -6,8 +6,8 @@
 // evaluates as ~150 elementwise / reduction launches over materialised [B,5N,5N] tensors (1.7 ms of a 39 ms step
 // here).  Forward value and the gradient w.r.t. the network outputs come out of the same pass:
 //   K1 (block per example)   per-residue terms: sums, per-example losses, gradients of rot/trans score, x0, atoms
-//   K2 (block per 256 atoms) distance-matrix term: distances on the fly from the [B,5N,3] atoms, loss sum, pair
-//                            count and the un-normalised per-atom gradient (thread i walks all j: no atomics on it)
+//   K2 (block per 64 atoms)  distance-matrix term: distances on the fly from the [B,5N,3] atoms, loss sum, pair
+//                            count and the un-normalised per-atom gradient (lane i, the waves split j: no atomics on it)
 //   K3 (block per example)   normalise the distance term, add its gradient, total loss
 // Rotation terms are evaluated in fp64 (the network's rot_score is fp64), everything else in fp32 as the reference.
 #include "fd_common.h"
@@ -174,14 +174,18 @@ __global__ __launch_bounds__(LT) void dsm_residue_kernel(FdLossDesc d) {
 }
 
 // distance-matrix term.  Atom a = 5 n + k (k < 5).  Ordered pair (i, j): gd = |g_i - g_j| flm_i, pd = |x_i - x_j| flm_i,
-// pmask = flm_i frm_j [gd < 6]; loss sum over pmask (gd - pd)^2, count over pmask.  Thread i accumulates the gradient
-// of x_i from both (i, j) and (j, i).
+// pmask = flm_i frm_j [gd < 6]; loss sum over pmask (gd - pd)^2, count over pmask.  A block owns 64 atoms i; its four
+// waves split the j range (tiles of 256 atoms staged in LDS, wave w walks entries w, w+4, ...); lane i accumulates the
+// gradient of x_i from both (i, j) and (j, i), the four partial gradients meet in LDS.
+constexpr int DT_I = 64;
 __global__ __launch_bounds__(LT) void dsm_distmat_kernel(FdLossDesc d) {
   __shared__ float xs[LT][3], gs[LT][3], fl[LT], fr[LT];
+  __shared__ float gpart[4][DT_I][3];
   __shared__ float redf[LT / 64];
   const int b = (int)blockIdx.y, tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int N = d.N, A = 5 * N;
-  const int i = (int)blockIdx.x * LT + tid;
+  const int i = (int)blockIdx.x * DT_I + lane;
   const bool vi = i < A;
   float xi[3] = {0.f, 0.f, 0.f}, gi[3] = {0.f, 0.f, 0.f}, fi = 0.f, ri = 0.f;
   if (vi) {
@@ -213,10 +217,12 @@ __global__ __launch_bounds__(LT) void dsm_distmat_kernel(FdLossDesc d) {
     __syncthreads();
     const int nj = (A - j0 < LT) ? A - j0 : LT;
     if (vi) {
-      for (int jj = 0; jj < nj; ++jj) {
+      for (int jj = wave; jj < nj; jj += 4) {
         const float ax = xi[0] - xs[jj][0], ay = xi[1] - xs[jj][1], az = xi[2] - xs[jj][2];
         const float bx = gi[0] - gs[jj][0], by = gi[1] - gs[jj][1], bz = gi[2] - gs[jj][2];
-        const float dd = sqrtf(ax * ax + ay * ay + az * az);
+        const float d2 = ax * ax + ay * ay + az * az;
+        const float inv = d2 > 0.f ? rsqrtf(d2) : 0.f;   // 1 / |x_i - x_j| (0 on coincident points: zero sub-gradient)
+        const float dd = d2 * inv;
         const float gg = sqrtf(bx * bx + by * by + bz * bz);
         const float fj = fl[jj], rj = fr[jj];
         // (i, j)
@@ -228,20 +234,20 @@ __global__ __launch_bounds__(LT) void dsm_distmat_kernel(FdLossDesc d) {
         // (j, i)
         const float gd2 = gg * fj, pd2 = dd * fj;
         const float pm2 = fj * ri * (gd2 < 6.f ? 1.f : 0.f);
-        const float c = -2.f * (pm * fi * e + pm2 * fj * (gd2 - pd2));
-        if (dd > 0.f) {
-          const float s = c / dd;
-          gx += s * ax; gy += s * ay; gz += s * az;
-        }
+        const float s = -2.f * (pm * fi * e + pm2 * fj * (gd2 - pd2)) * inv;
+        gx += s * ax; gy += s * ay; gz += s * az;
       }
     }
   }
-  if (vi) {
-    float* G = d.scratch + ((long)b * A + i) * 3;
-    G[0] = gx; G[1] = gy; G[2] = gz;
-  }
-  const float St = block_sum(S, redf);
+  gpart[wave][lane][0] = gx; gpart[wave][lane][1] = gy; gpart[wave][lane][2] = gz;
+  const float St = block_sum(S, redf);     // (two barriers inside: gpart is visible afterwards)
   const float ct = block_sum(cnt, redf);
+  if (tid < DT_I * 3) {
+    const int il = tid / 3, c = tid % 3;
+    const int ia = (int)blockIdx.x * DT_I + il;
+    if (ia < A)
+      d.scratch[((long)b * A + ia) * 3 + c] = (gpart[0][il][c] + gpart[1][il][c]) + (gpart[2][il][c] + gpart[3][il][c]);
+  }
   if (tid == 0) {
     atomicAdd(&d.scratch[(long)d.B * N * 15 + 2 * b + 0], St);
     atomicAdd(&d.scratch[(long)d.B * N * 15 + 2 * b + 1], ct);
@@ -295,7 +301,7 @@ extern "C" int fd_dsm_loss(const FdLossDesc* desc, void* stream_) {
                "fd_dsm_loss: null operand");
   hipLaunchKernelGGL(dsm_residue_kernel, dim3((unsigned)d.B), dim3(LT), 0, stream, d);
   FD_CHECK_LAUNCH("fd_dsm_loss(residue terms)");
-  hipLaunchKernelGGL(dsm_distmat_kernel, dim3((unsigned)fd_cdiv(5L * d.N, LT), (unsigned)d.B), dim3(LT), 0, stream, d);
+  hipLaunchKernelGGL(dsm_distmat_kernel, dim3((unsigned)fd_cdiv(5L * d.N, DT_I), (unsigned)d.B), dim3(LT), 0, stream, d);
   FD_CHECK_LAUNCH("fd_dsm_loss(distance matrix)");
   hipLaunchKernelGGL(dsm_finalize_kernel, dim3((unsigned)d.B), dim3(LT), 0, stream, d);
   FD_CHECK_LAUNCH("fd_dsm_loss(finalize)");
