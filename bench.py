@@ -277,6 +277,8 @@ def main():
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": None, "kernel": kname,
                      "vs_fp32_mfma_peak": round(achieved / 157.3, 4),
+                     "traffic_note": "PMC (offline, profiles/r01_pmc_fd_gemm.md): 1.62 GB HBM per M=491520,N=K=384 launch "
+                                     "vs 1.51 GB algorithmic (FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                      "measured_on": "3 steps right after the timed region with the gradient side stream off "
                                     "(HIP events per fd_gemm launch on its stream)",
                      "timed_region_overlapped_achieved": round(t_flops / max(t_time, 1e-9) / 1e12, 2),
