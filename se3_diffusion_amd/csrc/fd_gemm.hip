@@ -523,12 +523,22 @@ int launch_bx3(const FdGemmDesc& d, hipStream_t stream) {
   g.epi_vec = epilogue_vectorisable(d, g.ksplit);
   const bool a_kc = (d.a_cs == 1), b_kc = (d.b_rs == 1);
   dim3 grid(g.nblk_m * g.nblk_n, nb, g.ksplit), block(SplitCfg<BM>::NTHR, 1, 1);
-  if (a_kc && b_kc)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<BM, true, true>), grid, block, 0, stream, g);
-  else if (a_kc && !b_kc)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<BM, true, false>), grid, block, 0, stream, g);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<BM, false, false>), grid, block, 0, stream, g);
+  // the 256-row shape without split-K accumulates transposed and stores float4s straight from registers
+  static const bool no_trans = getenv("FD_GEMM_NOTRANS") != nullptr;   // (A/B measurements)
+  const bool trans = BM == 256 && g.ksplit == 1 && a_kc && !no_trans;
+  if (a_kc && b_kc) {
+    if (trans)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<BM, true, true, BM == 256>), grid, block, 0, stream, g);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<BM, true, true, false>), grid, block, 0, stream, g);
+  } else if (a_kc && !b_kc) {
+    if (trans)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<BM, true, false, BM == 256>), grid, block, 0, stream, g);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<BM, true, false, false>), grid, block, 0, stream, g);
+  } else {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<BM, false, false, false>), grid, block, 0, stream, g);
+  }
   FD_CHECK_LAUNCH("fd_gemm(split-bf16)");
   return FD_OK;
 }

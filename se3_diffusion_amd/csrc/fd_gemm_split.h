@@ -42,6 +42,97 @@ struct SplitCfg {
   static_assert(LDS * BLOCKS_PER_CU <= 160 * 1024, "LDS");
 };
 
+// LDS-free epilogue for the TRANSPOSED accumulation (the B fragment is the MFMA's row operand): a lane holds four
+// consecutive COLUMNS of one output row per accumulator group, so bias / pair / gate / residual / old C / C move as
+// float4s straight between registers and global memory -- no LDS round trip, no barrier.
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile_t(const FdGemmDesc& d, float* __restrict__ C, f32x16 (&acc)[TM][TN],
+                                             int m_base, int n_base, int h, int l31, bool vec) {
+  // acc[i][j][r]: row m = m_base + 32 i + l31, column n = n_base + 32 j + 8 (r >> 2) + 4 h + (r & 3)
+  const bool has_pair = d.pair_p != nullptr, has_gate = d.gate != nullptr, has_res = d.resid != nullptr;
+  const bool has_rs = d.rowscale != nullptr, has_beta = d.beta != 0, has_bias = d.bias != nullptr;
+  const int nres = d.nres;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int mr = m_base + i * 32 + l31;
+    const bool mok = mr < d.M;
+    const int m = mok ? mr : d.M - 1;
+    const float rs = has_rs ? d.rowscale[m] : 1.f;
+    const float* pp = C;
+    const float* pq = C;
+    if (has_pair) {
+      const int q = m / nres;
+      const int jj = m - q * nres;
+      const int bb = q / nres;
+      pp = d.pair_p + (long)q * d.ld_pair;
+      pq = d.pair_q + ((long)bb * nres + jj) * d.ld_pair;
+    }
+    float* crow = C + (long)m * d.ldc;
+    const float* grow = has_gate ? d.gate + (long)m * d.ld_gate : C;
+    const float* rrow = has_res ? d.resid + (long)m * d.ld_resid : C;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int nr = n_base + j * 32 + 8 * gq + 4 * h;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = d.alpha * acc[i][j][4 * gq + e];
+        if (vec) {
+          // N % 4 == 0: the float4 is entirely inside or outside
+          const bool nok = nr < d.N;
+          const int n = nok ? nr : 0;
+          if (has_bias) {
+            const float4 t = *reinterpret_cast<const float4*>(d.bias + n);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+          }
+          if (has_pair) {
+            const float4 a = *reinterpret_cast<const float4*>(pp + n);
+            const float4 b = *reinterpret_cast<const float4*>(pq + n);
+            v[0] += a.x + b.x; v[1] += a.y + b.y; v[2] += a.z + b.z; v[3] += a.w + b.w;
+          }
+          if (d.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          if (has_gate) {
+            const float4 t = *reinterpret_cast<const float4*>(grow + n);
+            v[0] = t.x > 0.f ? v[0] : 0.f; v[1] = t.y > 0.f ? v[1] : 0.f;
+            v[2] = t.z > 0.f ? v[2] : 0.f; v[3] = t.w > 0.f ? v[3] : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= rs;
+          if (has_res) {
+            const float4 t = *reinterpret_cast<const float4*>(rrow + n);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+          }
+          if (has_beta) {
+            const float4 t = *reinterpret_cast<const float4*>(crow + n);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+          }
+          if (mok && nok) *reinterpret_cast<float4*>(crow + n) = make_float4(v[0], v[1], v[2], v[3]);
+          fd::sched_fence();   // keep the 16 float4 groups from being software-pipelined into one register spike
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ne = nr + e;
+            const bool nok = ne < d.N;
+            const int n = nok ? ne : 0;
+            float x = v[e];
+            if (has_bias) x += d.bias[n];
+            if (has_pair) x += pp[n] + pq[n];
+            if (d.relu) x = x > 0.f ? x : 0.f;
+            if (has_gate) x = grow[n] > 0.f ? x : 0.f;
+            x *= rs;
+            if (has_res) x += rrow[n];
+            if (has_beta) x += crow[n];
+            if (mok && nok) crow[n] = x;
+          }
+        }
+      }
+  }
+}
+
 __device__ __forceinline__ void split8(const float (&x)[8], uint4& s0, uint4& s1, uint4& s2) {
   unsigned t0[4], t1[4], t2[4];
 #pragma unroll
@@ -145,7 +236,9 @@ struct SplitStager {
   }
 };
 
-template <int BM, bool A_KC, bool B_KC>
+// TRANS: transposed accumulation + LDS-free float4 epilogue (needs ksplit == 1: its split-K atomics would touch one
+// cache line per lane); !TRANS: row-major accumulation, LDS-transposed epilogue or split-K atomics.
+template <int BM, bool A_KC, bool B_KC, bool TRANS>
 __global__ __launch_bounds__(SplitCfg<BM>::NTHR, SplitCfg<BM>::BLOCKS_PER_CU) void gemm_bx3_kernel(GemmArgs g) {
   using Cfg = SplitCfg<BM>;
   constexpr int BN = XBN, TM = 2, TN = 2;
@@ -173,7 +266,7 @@ __global__ __launch_bounds__(SplitCfg<BM>::NTHR, SplitCfg<BM>::BLOCKS_PER_CU) vo
   if (nk <= 0) return;
 
   if (tid >= NCONS) {
-    // ---- producer waves: global -> registers -> (split) -> LDS ring; two register sets = two stages in flight ----
+    // ---- producer waves: global -> registers -> (split) -> LDS ring ----
     const int ptid = tid - NCONS;
     fd::raise_wave_priority();   // the producer's instruction stream must never wait for an issue slot
     const float* __restrict__ A = d.A + zo * d.a_so + zi * d.a_si;
@@ -181,7 +274,11 @@ __global__ __launch_bounds__(SplitCfg<BM>::NTHR, SplitCfg<BM>::BLOCKS_PER_CU) vo
     SplitStager<BM, A_KC, NPROD> sa;
     SplitStager<BN, B_KC, NPROD> sb;
     constexpr int NSA = SplitStager<BM, A_KC, NPROD>::NS, NSB = SplitStager<BN, B_KC, NPROD>::NS;
-    float ra[2][NSA][8], rb[2][NSB][8];
+    // NSET register sets = NSET stages of global loads in flight per producer thread (stage s lives in set s % NSET).
+    // (Four sets were measured on the HBM-streamed pair tensor: no change against two -- 1.06 ms on the K = 384
+    // edge shape either way -- so the load latency is not what separates it from an L2-resident operand.)
+    constexpr int NSET = 2;
+    float ra[NSET][NSA][8], rb[NSET][NSB][8];
     sa.init(A, d.a_rs, d.a_cs, m0, d.M, kt0 * XBK, ptid);
     sb.init(B, d.b_cs, d.b_rs, n0, d.N, kt0 * XBK, ptid);   // the staged "row" of B is n
     int lk = kt0;   // stage of the next global load
@@ -208,31 +305,32 @@ __global__ __launch_bounds__(SplitCfg<BM>::NTHR, SplitCfg<BM>::BLOCKS_PER_CU) vo
     };
     // AHEAD = how many stages beyond the one being multiplied are complete in LDS at a barrier
     constexpr int AHEAD = RING - 1;
-    issue(ra[0], rb[0]);
-    if (nk > 1) issue(ra[1], rb[1]);
-    put(ra[0], rb[0]);
-    if (nk > 2) issue(ra[0], rb[0]);
-    if (AHEAD == 2 && nk > 1) {
-      put(ra[1], rb[1]);
-      if (nk > 3) issue(ra[1], rb[1]);
-    }
+#pragma unroll
+    for (int u = 0; u < NSET; ++u)
+      if (u < nk) issue(ra[u], rb[u]);
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u)
+      if (u < nk) {
+        put(ra[u], rb[u]);
+        if (u + NSET < nk) issue(ra[u], rb[u]);
+      }
     __syncthreads();   // the first AHEAD stages are in the ring
     // during stage `it`: stage it+AHEAD goes registers -> its ring slot (last read AHEAD barriers ago) and the loads
-    // of stage it+AHEAD+2 refill the register set
+    // of stage it+AHEAD+NSET refill the register set
     auto step = [&](int it, float (&xa)[NSA][8], float (&xb)[NSB][8]) {
       if (it + AHEAD < nk) {
         put(xa, xb);
-        if (it + AHEAD + 2 < nk) issue(xa, xb);
+        if (it + AHEAD + NSET < nk) issue(xa, xb);
       }
       __syncthreads();
     };
-    // the register set holding stage s is s & 1
-    for (int it = 0; it < nk; it += 2) {
-      step(it, ra[AHEAD & 1], rb[AHEAD & 1]);
-      if (it + 1 < nk) step(it + 1, ra[(AHEAD + 1) & 1], rb[(AHEAD + 1) & 1]);
+    for (int it = 0; it < nk; it += NSET) {
+#pragma unroll
+      for (int u = 0; u < NSET; ++u)
+        if (it + u < nk) step(it + u, ra[(AHEAD + u) % NSET], rb[(AHEAD + u) % NSET]);
     }
     if (!A_KC && do_rowsum && m0 + ptid < d.M) atomicAdd(d.a_rowsum + m0 + ptid, d.alpha * rsum);
-    if (g.epi_vec) {   // the two barriers of the consumers' LDS-transposed epilogue
+    if (!TRANS && g.epi_vec) {   // the two barriers of the consumers' LDS-transposed epilogue
       __syncthreads();
       __syncthreads();
     }
@@ -281,7 +379,9 @@ __global__ __launch_bounds__(SplitCfg<BM>::NTHR, SplitCfg<BM>::BLOCKS_PER_CU) vo
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = fd::mfma_32x32x16_bf16(xa[i][PA[p]], xb[j][PB[p]], acc[i][j]);
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = TRANS ? fd::mfma_32x32x16_bf16(xb[j][PB[p]], xa[i][PA[p]], acc[i][j])
+                            : fd::mfma_32x32x16_bf16(xa[i][PA[p]], xb[j][PB[p]], acc[i][j]);
     }
   };
 
@@ -309,7 +409,9 @@ __global__ __launch_bounds__(SplitCfg<BM>::NTHR, SplitCfg<BM>::BLOCKS_PER_CU) vo
     }
   }
 
-  if (g.epi_vec)
+  if (TRANS)
+    store_tile_t<TM, TN>(d, C, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, h, l31, g.epi_vec != 0);
+  else if (g.epi_vec)
     store_tile_vec<BM, BN, TM, TN, NCONS>(d, C, acc, reinterpret_cast<float*>(lds), m0, n0, wm, wn, h, l31, tid);
   else
     store_tile<TM, TN>(d, C, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, h, l31, g.ksplit > 1);

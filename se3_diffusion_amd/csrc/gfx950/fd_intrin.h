@@ -43,6 +43,9 @@ __device__ __forceinline__ void raise_wave_priority() { __builtin_amdgcn_s_setpr
 // s_barrier without the LDS/memory fence of __syncthreads(): for a wave that has nothing to publish at the barrier
 __device__ __forceinline__ void block_barrier_nofence() { __builtin_amdgcn_s_barrier(); }
 
+// compiler-only fence: memory operations are not moved across it (bounds register live ranges in unrolled epilogues)
+__device__ __forceinline__ void sched_fence() { asm volatile("" ::: "memory"); }
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 
