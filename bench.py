@@ -199,9 +199,12 @@ def main():
     model.train()
     batch = ts.synthetic_batch(B, N, dev, seed=100 + rank)
     gt37, _ = ts.backbone_atoms(batch["rigids_0"], batch["torsion_angles_sin_cos"][..., 2, :])
-    grads = fdist.FlatGrads(model.parameters())
+    from se3_diffusion_amd.optim import FlatAdam
+    # Adam (torch.optim.Adam's rule, lr 1e-4 as train_se3_diffusion.py:139) over flat parameter / gradient / moment
+    # buffers: param.grad are views of ONE buffer (single RCCL all-reduce), the update is one launch
+    opt = FlatAdam(model.parameters(), lr=1e-4)
+    grads = opt
     model.accumulate_into_grad = True      # backward kernels accumulate straight into the flat all-reduce buffer
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)   # same update rule, one multi-tensor kernel
 
     def step():
         if a.mode == "forward":

@@ -217,6 +217,12 @@ typedef struct FdLossDesc {
 
 int fd_dsm_loss(const FdLossDesc* desc, void* stream);
 
+/* Adam (torch.optim.Adam defaults, experiments/train_se3_diffusion.py:139) over flat fp32 buffers of n elements
+ * (n % 4 == 0, 16-byte aligned): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps) with bc_i = 1 - b_i^t supplied by the host. */
+int fd_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                 float bc1, float bc2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -307,3 +307,46 @@ extern "C" int fd_dsm_loss(const FdLossDesc* desc, void* stream_) {
   FD_CHECK_LAUNCH("fd_dsm_loss(finalize)");
   return FD_OK;
 }
+
+// ---- Adam over flat fp32 buffers (one launch for all 282 parameter tensors) -----------------------------------------
+// The update rule of torch.optim.Adam with its defaults (no weight decay, no amsgrad), as configured by
+// experiments/train_se3_diffusion.py:139 (Adam, lr 1e-4):
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps),  bc_i = 1 - b_i^t
+namespace {
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long n4,
+                                                        float lr, float b1, float b2, float eps, float bc1,
+                                                        float rsqrt_bc2) {
+  const float step = lr / bc1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 P = reinterpret_cast<float4*>(p)[i];
+    const float4 Gd = reinterpret_cast<const float4*>(g)[i];
+    float4 M = reinterpret_cast<float4*>(m)[i];
+    float4 V = reinterpret_cast<float4*>(v)[i];
+#define FD_ADAM1(c)                                             \
+  M.c = b1 * M.c + (1.f - b1) * Gd.c;                           \
+  V.c = b2 * V.c + (1.f - b2) * Gd.c * Gd.c;                    \
+  P.c -= step * M.c / (sqrtf(V.c) * rsqrt_bc2 + eps);
+    FD_ADAM1(x) FD_ADAM1(y) FD_ADAM1(z) FD_ADAM1(w)
+#undef FD_ADAM1
+    reinterpret_cast<float4*>(p)[i] = P;
+    reinterpret_cast<float4*>(m)[i] = M;
+    reinterpret_cast<float4*>(v)[i] = V;
+  }
+}
+}  // namespace
+
+extern "C" int fd_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                            float eps, float bc1, float bc2, void* stream) {
+  FD_CHECK_ARG(p && g && m && v, "fd_adam_step: null operand");
+  FD_CHECK_ARG((n & 3) == 0 && fd_aligned16(p) && fd_aligned16(g) && fd_aligned16(m) && fd_aligned16(v),
+               "fd_adam_step: flat buffers must be 16-byte aligned with a length that is a multiple of 4");
+  if (n == 0) return FD_OK;
+  const long n4 = n / 4;
+  long gsz = (n4 + 255) / 256;
+  const int grid = (int)(gsz > 4096 ? 4096 : gsz);
+  hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, lr, b1, b2, eps,
+                     bc1, 1.0f / sqrtf(bc2));
+  FD_CHECK_LAUNCH("fd_adam_step");
+  return FD_OK;
+}

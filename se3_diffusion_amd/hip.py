@@ -116,6 +116,7 @@ _SIGS = {
     "fd_forward_marginal": "ppppppidddipppp" + "ls",
     "fd_se3_reverse_step": "ppppppiiddpdddiiips",
     "fd_dsm_loss": "Ss",
+    "fd_adam_step": "pppplffffffs",
 }
 # exact argument lists, kept next to the header for the symbol-export test
 _CT = {"p": c_void_p, "i": c_int, "l": c_long, "f": c_float, "d": c_double, "S": c_void_p, "s": c_void_p}
