@@ -87,6 +87,18 @@ SHAPES = [
     ("lat t5 1024x320x320", 1024, 320, 320, True, True, 5, 1),
     ("lat t2 1024x960x320", 1024, 960, 320, True, True, 2, 1),
     ("lat t5 1024x960x320", 1024, 960, 320, True, True, 5, 1),
+    ("n5 NT 3840x320x320 t5", 3840, 320, 320, True, True, 5, 1),
+    ("n5 NT 3840x320x320 t2", 3840, 320, 320, True, True, 2, 1),
+    ("n5 NN 3840x320x320 t5", 3840, 320, 320, True, False, 5, 1),
+    ("n5 NN 3840x320x320 t2", 3840, 320, 320, True, False, 2, 1),
+    ("n5 NT 3840x960x320 t5", 3840, 960, 320, True, True, 5, 1),
+    ("n5 NT 3840x960x320 t2", 3840, 960, 320, True, True, 2, 1),
+    ("n5 NT 3840x256x2688 t5", 3840, 256, 2688, True, True, 5, 1),
+    ("n5 NT 3840x256x2688 t2", 3840, 256, 2688, True, True, 2, 1),
+    ("n5 NT 3840x256x256 t5", 3840, 256, 256, True, True, 5, 1),
+    ("n5 NT 3840x256x256 t2", 3840, 256, 256, True, True, 2, 1),
+    ("n5 NN 3840x2688x256 t5", 3840, 2688, 256, True, False, 5, 1),
+    ("n5 NN 3840x2688x256 t2", 3840, 2688, 256, True, False, 2, 1),
     ("node NT 3840x320x320", 3840, 320, 320, True, True, 2, 1),
     ("node NT 3840x320x320 t3", 3840, 320, 320, True, True, 3, 1),
     ("node NN 3840x320x320", 3840, 320, 320, True, False, 2, 1),
