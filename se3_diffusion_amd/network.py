@@ -89,7 +89,7 @@ def mlp3_ln_bwd(P, G, pre, sv, dy):
     _lin_grads(G, f"{pre}.0.weight", f"{pre}.0.bias", mv(dh1), sv["x"], M, Cc, K0)
 
 
-def embed_fwd(P, feats, B, N):
+def embed_fwd(P, feats, B, N, cache=None):
     dev = feats["res_mask"]
     mask = feats["res_mask"]
     tfreq, idenom, lower, upper = ops.feature_tables(dev.device)
@@ -102,7 +102,9 @@ def embed_fwd(P, feats, B, N):
     node, sv_n = mlp3_ln_fwd(P, "embedding_layer.node_embedder", mv(nf), R, 65, CS, mask)
     ef = empty((Pn, 120), dev)
     lib().call("fd_edge_feats", seq, tscaled, fixed, feats["sc_ca_t"], tfreq, idenom, lower, upper, ef, B, N)
-    emask = pair_mask(mask, B, N)
+    emask = pair_mask(mask, B, N) if cache is None else cache.setdefault("emask", None)
+    if emask is None:
+        emask = cache["emask"] = pair_mask(mask, B, N)
     edge, sv_e = mlp3_ln_fwd(P, "embedding_layer.edge_embedder", mv(ef), Pn, 120, CZ, emask)
     return node, edge, dict(node=sv_n, edge=sv_e, emask=emask)
 
@@ -122,7 +124,7 @@ def pair_mask(mask, B, N):
 
 
 # --------------------------------------------------------------------------- IPA
-def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N):
+def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
     """x1 = s + mask * IPA(s, z, T).  s: matrix view [R,256]."""
     dev = z
     R, Pn = B * N, B * N * N
@@ -133,8 +135,13 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N):
     ops.linear(s, mv(P[f"{pre}.linear_kv_points.weight"]), P[f"{pre}.linear_kv_points.bias"], (proj, 6336, LDP), R, 480, CS)
     qp = empty((R, H, PQ * 3), dev); kp = empty((R, H, PQ * 3), dev); vp = empty((R, H, PV * 3), dev)
     lib().call("fd_ipa_points_fwd", proj, quat, trans, qp, kp, vp, R, H, C, PQ, PV)
-    W40 = torch.cat([P[f"{pre}.linear_b.weight"], P[f"{pre}.down_z.weight"]], 0).contiguous()   # tiny pack
-    b40 = torch.cat([P[f"{pre}.linear_b.bias"], P[f"{pre}.down_z.bias"]], 0).contiguous()
+    if cache is not None and ("W40", pre) in cache:
+        W40, b40 = cache[("W40", pre)]
+    else:
+        W40 = torch.cat([P[f"{pre}.linear_b.weight"], P[f"{pre}.down_z.weight"]], 0).contiguous()   # tiny pack
+        b40 = torch.cat([P[f"{pre}.linear_b.bias"], P[f"{pre}.down_z.bias"]], 0).contiguous()
+        if cache is not None:
+            cache[("W40", pre)] = (W40, b40)
     zb = empty((Pn, ZB), dev)
     ops.linear(mv(z), mv(W40), b40, mv(zb), Pn, ZB, CZ)
     A = empty((B, H, N, N), dev)

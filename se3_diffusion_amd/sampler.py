@@ -45,6 +45,9 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
     dt = 1.0 / num_t
     was_training = model.training
     model.eval()
+    # masks and weights are constant over the trajectory: their derived tensors (pair mask, diffuse mask, key mask,
+    # packed linear_b / down_z weights) are built by the first forward and reused by the other 500 (trunk._cached)
+    model._fd_static = {}
     lib = hip.get_lib()
     saved_prof, lib.gemm_profile = lib.gemm_profile, (None if use_graph else lib.gemm_profile)
     # static state (updated in place so a captured graph sees it)
@@ -124,6 +127,7 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
             psi.copy_(out["psi"])
         if return_traj:
             traj.append(st["rigids_t"].clone())
+    del model._fd_static
     if was_training:
         model.train()
     lib.gemm_profile = saved_prof

@@ -231,31 +231,54 @@ def _prep_feats(feats):
     return f
 
 
-def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_bool_mask=False, save=True):
-    """ScoreNetwork.forward.  Returns (outputs, saved-for-backward or None)."""
+def _cached(cache, key, fn):
+    """Mask- / weight-derived constants of a sampling run (the sampler owns `cache` for one trajectory: masks and
+    weights do not change between its 500 forwards, so ~15 tiny launches per forward are computed once)."""
+    if cache is None:
+        return fn()
+    if key not in cache:
+        cache[key] = fn()
+    return cache[key]
+
+
+def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_bool_mask=False, save=True, cache=None):
+    """ScoreNetwork.forward.  Returns (outputs, saved-for-backward or None).  `cache`: see _cached (no-grad only)."""
+    if save:
+        cache = None
     f = _prep_feats(feats)
     B, N = f["res_mask"].shape
     R = B * N
     L = lib()
     mask = f["res_mask"]
     dev = mask
-    node0, z, sv_embed = nw.embed_fwd(P, f, B, N)
+    if cache is not None:
+        # the cache is only valid for the static mask buffers it was built from
+        sig = (B, N, mask.data_ptr(), f["fixed_mask"].data_ptr(), bool(tfmr_bool_mask))
+        if cache.get("_sig") != sig:
+            cache.clear()
+            cache["_sig"] = sig
+    node0, z, sv_embed = nw.embed_fwd(P, f, B, N, cache)
     emask = sv_embed["emask"]
-    dmask = empty((B, N), dev)
-    L.call("fd_rowscale", (1 - f["fixed_mask"]).contiguous(), 1, mask.reshape(-1), dmask, 1, R, 1)
+
+    def _dmask():
+        dm = empty((B, N), dev)
+        L.call("fd_rowscale", (1 - f["fixed_mask"]).contiguous(), 1, mask.reshape(-1), dm, 1, R, 1)
+        return dm
+    dmask = _cached(cache, "dmask", _dmask)
     rig = f["rigids_t"]
     quat = rig[..., :4].contiguous().view(R, 4)
     trans = (rig[..., 4:] * dconf[0]).contiguous().view(R, 3)                  # scale_rigids (A -> nm)
     init_node = node0                                                          # already masked (LN rowscale)
     node = node0
     if tfmr_bool_mask:
-        key_add = torch.where(mask > 0, torch.zeros_like(mask), torch.full_like(mask, float("-inf")))
+        key_add = _cached(cache, "key_add", lambda: torch.where(mask > 0, torch.zeros_like(mask),
+                                                                 torch.full_like(mask, float("-inf"))))
     else:
         key_add = (1 - mask).contiguous()
     stages = []
     for b in range(num_blocks):
         pre = f"score_model.trunk.ipa_{b}"
-        x1, sv_ipa = nw.ipa_fwd(P, pre, mv(node), z, quat, trans, mask.view(-1), B, N)
+        x1, sv_ipa = nw.ipa_fwd(P, pre, mv(node), z, quat, trans, mask.view(-1), B, N, cache)
         u, sv_ln = nw.ln_skip_fwd(P, b, x1, init_node, R)
         u0 = u
         sv_t = []
