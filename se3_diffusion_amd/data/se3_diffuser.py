@@ -101,6 +101,44 @@ class SE3Diffuser:
         return {'rigids_t': out, 'trans_score': ts.view(shp + (3,)).cpu().numpy(), 'rot_score': rs.view(shp + (3,)).cpu().numpy(),
                 'trans_score_scaling': r3.score_scaling(t), 'rot_score_scaling': so3.score_scaling(t)}
 
+    def forward_marginal_batch(self, rigids_0, t, diffuse_mask=None, noise=None, generator=None):
+        """Device-side training-batch generation: the reference noises every example in DataLoader workers
+        with scipy (pdb_data_loader.py:240-262 -> forward_marginal per example); here a whole batch
+        rigids_0 [B,N,7] (device) with per-example times t [B] is noised by fd_forward_marginal, one launch per example,
+        and everything stays on the device.  noise = (z_axis [B,N,3], u [B,N], z_trans [B,N,3]) float64 injects the draws
+        (parity tests); by default they are drawn on the device in the reference's order (rotation axis, angle, then
+        translation).  Returns the training-batch entries rigids_t [B,N,7] f32, rot_score / trans_score [B,N,3] f32,
+        rot_score_scaling / trans_score_scaling [B] f32 (pdb_data_loader.py:245-262 casts them the same way)."""
+        from .. import hip
+        assert self._diffuse_rot and self._diffuse_trans, "device batch generation is built for diffuse_rot and diffuse_trans"
+        dev = rigids_0.device
+        B, N, _ = rigids_0.shape
+        t = np.asarray(t, dtype=np.float64).reshape(B)
+        so3, r3 = self._so3_diffuser, self._r3_diffuser
+        cdf, omega = so3.device_tables(dev)
+        if noise is None:
+            z_axis = torch.randn((B, N, 3), dtype=torch.float64, device=dev, generator=generator)
+            u = torch.rand((B, N), dtype=torch.float64, device=dev, generator=generator)
+            z_trans = torch.randn((B, N, 3), dtype=torch.float64, device=dev, generator=generator)
+        else:
+            z_axis, u, z_trans = (_f64(x, dev).contiguous() for x in noise)
+        r0 = rigids_0.to(torch.float32).contiguous()
+        rt = torch.empty_like(r0)
+        rs = torch.empty((B, N, 3), dtype=torch.float64, device=dev)
+        ts = torch.empty((B, N, 3), dtype=torch.float64, device=dev)
+        mask = None if diffuse_mask is None else torch.as_tensor(diffuse_mask, dtype=torch.float32, device=dev).contiguous()
+        lib = hip.get_lib()
+        for b in range(B):
+            idx = int(so3.t_to_idx(float(t[b])))
+            lib.call("fd_forward_marginal", (r0, b * N * 7), (z_axis, b * N * 3), (u, b * N), (z_trans, b * N * 3),
+                     (cdf, idx * cdf.shape[1]), omega, omega.numel(), float(so3.discrete_sigma[idx]),
+                     float(r3.marginal_b_t(float(t[b]))), float(r3._r3_conf.coordinate_scaling), 1000,
+                     None if mask is None else (mask, b * N), (rt, b * N * 7), (rs, b * N * 3), (ts, b * N * 3), N)
+        f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
+        return {'rigids_t': rt, 'rot_score': rs.to(torch.float32), 'trans_score': ts.to(torch.float32),
+                'rot_score_scaling': f32([so3.score_scaling(float(x)) for x in t]),
+                'trans_score_scaling': f32([r3.score_scaling(float(x)) for x in t])}
+
     # ------------------------------------------------------------------ scores
     def calc_trans_0(self, trans_score, trans_t, t):
         return self._r3_diffuser.calc_trans_0(trans_score, trans_t, t)

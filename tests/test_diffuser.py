@@ -131,13 +131,17 @@ def test_sample_ref_kernel_emu(diff, use_emu):
     _check_sample_ref(t7.numpy())
 
 
-def _check_fm(out):
+def _check_fm(out, f32_scores=False):
     t7 = out["rigids_t"].cpu().numpy() if torch.is_tensor(out["rigids_t"]) else out["rigids_t"]
     assert np.abs(rotmats(t7) - rotmats(G["fm_rigids_t"])).max() < 3e-6
     assert np.abs(t7[..., 4:] - G["fm_rigids_t"][..., 4:]).max() < 3e-5
-    assert np.allclose(out["trans_score"], G["fm_trans_score"], rtol=1e-9, atol=1e-10)
-    assert np.allclose(out["rot_score"], G["fm_rot_score"], rtol=1e-7, atol=1e-9)
-    assert np.allclose(out["trans_score_scaling"], G["fm_trans_score_scaling"]) and np.allclose(out["rot_score_scaling"], G["fm_rot_score_scaling"], rtol=1e-8)
+    # (the batch generator returns the scores as float32 training-batch entries)
+    rt, at = (1e-6, 1e-6) if f32_scores else (1e-9, 1e-10)
+    assert np.allclose(out["trans_score"], G["fm_trans_score"], rtol=rt, atol=at)
+    assert np.allclose(out["rot_score"], G["fm_rot_score"], rtol=max(rt, 1e-7), atol=max(at, 1e-9))
+    rs = 1e-6 if f32_scores else 1e-8
+    assert np.allclose(out["trans_score_scaling"], G["fm_trans_score_scaling"], rtol=max(rs, 1e-7))
+    assert np.allclose(out["rot_score_scaling"], G["fm_rot_score_scaling"], rtol=rs)
 
 
 def test_forward_marginal_host(diff):
@@ -168,6 +172,32 @@ def test_forward_marginal_kernel_emu(diff, use_emu):
     _fm_kernel(diff, "cpu")
 
 
+def _fm_batch(diff, dev):
+    """forward_marginal_batch (device training-batch generation, per-example t) == the golden single-example result
+    for the example that carries the golden noise, and per-example calls for the others"""
+    n = 10
+    r0 = torch.tensor(G["fm_rigids0"])
+    rs = np.random.RandomState(4)
+    B = 3
+    z_axis = rs.standard_normal((B, n, 3)); u = rs.uniform(size=(B, n)); z_trans = rs.standard_normal((B, n, 3))
+    z_axis[1], u[1], z_trans[1] = G["fm_randn"], G["fm_rand"], G["fm_normal"]
+    t = np.array([0.13, float(G["fm_t"]), 0.77])
+    out = diff.forward_marginal_batch(r0[None].repeat(B, 1, 1).to(dev), t, noise=(z_axis, u, z_trans))
+    so3, r3 = diff._so3_diffuser, diff._r3_diffuser
+    _check_fm(dict(rigids_t=out["rigids_t"][1], trans_score=out["trans_score"][1].double().cpu().numpy(),
+                   rot_score=out["rot_score"][1].double().cpu().numpy(),
+                   trans_score_scaling=float(out["trans_score_scaling"][1]), rot_score_scaling=float(out["rot_score_scaling"][1])),
+              f32_scores=True)
+    for b in (0, 2):
+        assert abs(float(out["rot_score_scaling"][b]) - so3.score_scaling(t[b])) < 1e-5 * so3.score_scaling(t[b])
+        assert abs(float(out["trans_score_scaling"][b]) - r3.score_scaling(t[b])) < 1e-5 * r3.score_scaling(t[b])
+        assert torch.isfinite(out["rigids_t"][b]).all() and not torch.equal(out["rigids_t"][b], out["rigids_t"][1])
+
+
+def test_forward_marginal_batch_emu(diff, use_emu):
+    _fm_batch(diff, "cpu")
+
+
 def test_igso3_tables_kernel_emu(diff, use_emu):
     """fd_igso3_tables on a sub-grid vs the cached full tables."""
     from se3_diffusion_amd import hip
@@ -189,6 +219,7 @@ def test_diffuser_kernels_gpu(hip_lib, tmp_path):
     _reverse_kernel(d, "cuda")
     _check_sample_ref(d.sample_ref_device(11, "cuda", noise=(G["sr_randn"], G["sr_rand"], G["sr_normal"])).cpu().numpy())
     _fm_kernel(d, "cuda")
+    _fm_batch(d, "cuda")
     np.random.seed(55)
     _check_fm(d.forward_marginal(ru.Rigid.from_tensor_7(torch.tensor(G["fm_rigids0"]).cuda()), float(G["fm_t"])))
     np.random.seed(123)
