@@ -574,6 +574,12 @@ int plan_tile(const FdGemmDesc& d, bool fast) {
     // 64x64 the wider tile's operand reuse wins again)
     if (cfg != 4 && blocks64 <= 128 && d.M <= 1024 && direct_ok(d)) cfg = 5;
   }
+  if ((cfg == 4 || cfg == 6) && !split_enabled()) {
+    // FD_GEMM_EXACT_F32=1 also overrides explicit requests for the split-bf16 kernel (the host asks for it on the
+    // weight gradients)
+    const long blocks128 = (long)fd_cdiv(d.M, 128) * fd_cdiv(d.N, 128) * (d.batch > 0 ? d.batch : 1);
+    cfg = (blocks128 >= 512 && d.N >= 96 && !d.a_rowsum) ? 1 : 2;
+  }
   if (!fast && cfg == 1) cfg = 2;   // the element-wise staging path is only instantiated for the small tiles
   return cfg;
 }
