@@ -75,8 +75,10 @@ typedef struct FdGemmDesc {
 } FdGemmDesc;
 
 int fd_gemm(const FdGemmDesc* desc, void* stream);
-/* the tile code (1..4) fd_gemm would run this descriptor with; no launch */
+/* the tile code (1..6) fd_gemm would run this descriptor with; no launch */
 int fd_gemm_plan(const FdGemmDesc* desc);
+/* exact != 0: every later fd_gemm runs on the fp32-MFMA kernels (as FD_GEMM_EXACT_F32=1); returns the previous mode */
+int fd_gemm_set_exact_f32(int exact);
 
 /* ---- LayerNorm / reductions (HBM-bound) -------------------------------
  * torch.nn.LayerNorm (eps 1e-5, biased variance) at score_network.py:73,85,

@@ -543,13 +543,14 @@ int launch_bx3(const FdGemmDesc& d, hipStream_t stream) {
   return FD_OK;
 }
 
-// FD_GEMM_EXACT_F32=1 keeps every GEMM on the fp32-MFMA (fmaf-chain) kernels
+// FD_GEMM_EXACT_F32=1 (or fd_gemm_set_exact_f32) keeps every GEMM on the fp32-MFMA (fmaf-chain) kernels
+int g_split_mode = -1;   // -1: not read yet, 0: exact fp32 only, 1: split-bf16 allowed
 bool split_enabled() {
-  static const bool on = [] {
+  if (g_split_mode < 0) {
     const char* e = getenv("FD_GEMM_EXACT_F32");
-    return !(e && e[0] && e[0] != '0');
-  }();
-  return on;
+    g_split_mode = (e && e[0] && e[0] != '0') ? 0 : 1;
+  }
+  return g_split_mode != 0;
 }
 
 // tile selection: 1 = 128x128, 2 = 64x64, 3 = 128x32 (fp32 MFMA); 4 = 256x128 split-bf16.
@@ -630,6 +631,12 @@ int launch_cfg(const FdGemmDesc& d, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" int fd_gemm_set_exact_f32(int exact) {
+  const int was = split_enabled() ? 0 : 1;
+  g_split_mode = exact ? 0 : 1;
+  return was;
+}
 
 extern "C" int fd_gemm_plan(const FdGemmDesc* desc) {
   FD_CHECK_ARG(desc != nullptr, "fd_gemm_plan: null descriptor");
