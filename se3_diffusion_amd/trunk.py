@@ -305,10 +305,6 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
                      bool_mask=tfmr_bool_mask, mask=mask, dmask=dmask)
 
 
-def _const(dev, n, v):
-    return torch.full((n,), v, device=dev.device)
-
-
 def backward(P, G, sv, d_out):
     """Gradients of sum_k <d_out[k], out[k]> w.r.t. every parameter, accumulated into G."""
     B, N, nb = sv["B"], sv["N"], sv["num_blocks"]
