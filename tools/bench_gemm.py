@@ -87,6 +87,12 @@ SHAPES = [
     ("lat t5 1024x320x320", 1024, 320, 320, True, True, 5, 1),
     ("lat t2 1024x960x320", 1024, 960, 320, True, True, 2, 1),
     ("lat t5 1024x960x320", 1024, 960, 320, True, True, 5, 1),
+    ("kk K=32", 3840, 320, 32, True, True, 2, 1),
+    ("kk K=64", 3840, 320, 64, True, True, 2, 1),
+    ("kk K=160", 3840, 320, 160, True, True, 2, 1),
+    ("kk K=320", 3840, 320, 320, True, True, 2, 1),
+    ("kk K=640", 3840, 320, 640, True, True, 2, 1),
+    ("kk K=1280", 3840, 320, 1280, True, True, 2, 1),
     ("n5 NT 3840x320x320 t5", 3840, 320, 320, True, True, 5, 1),
     ("n5 NT 3840x320x320 t2", 3840, 320, 320, True, True, 2, 1),
     ("n5 NN 3840x320x320 t5", 3840, 320, 320, True, False, 5, 1),
