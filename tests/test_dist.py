@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, emu_path=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
@@ -32,8 +32,16 @@ def _worker(rank, world, port, q):
     torch.manual_seed(100 + rank)                     # ranks start different ...
     model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
     fdist.broadcast_params(model)                     # ... and are made identical
-    flat = fdist.FlatGrads(model.parameters())
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    if emu_path is None:
+        flat = fdist.FlatGrads(model.parameters())
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    else:
+        # bench.py's configuration: FlatAdam owns parameters, gradients and moments as flat buffers (its kernel runs
+        # under the host interpreter here)
+        from se3_diffusion_amd import hip
+        from se3_diffusion_amd.optim import FlatAdam
+        hip._TEST_OVERRIDE = hip.FdLib(emu_path)
+        opt = flat = FlatAdam(model.parameters(), lr=1e-2)
     g = torch.Generator().manual_seed(7)
     X = torch.randn(8, 6, generator=g)
     Y = torch.randn(8, 3, generator=g)
@@ -42,7 +50,8 @@ def _worker(rank, world, port, q):
         flat.zero()
         loss = ((model(X[idx]) - Y[idx]) ** 2).mean()
         loss.backward()
-        assert all(p.grad.data_ptr() >= flat.flat.data_ptr() for p in model.parameters())  # grads live in the flat buffer
+        base = (flat.flat if emu_path is None else flat.flat_g).data_ptr()
+        assert all(p.grad.data_ptr() >= base for p in model.parameters())  # grads live in the flat buffer
         flat.all_reduce_mean()
         opt.step()
     q.put((rank, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).double().tolist()))
@@ -66,11 +75,19 @@ def _single():
     return torch.cat([p.detach().reshape(-1) for p in model.parameters()])
 
 
+def test_flat_adam_data_parallel_matches_single_process(emu_lib):
+    _dp_check(emu_lib.path)
+
+
 def test_flat_grad_allreduce_matches_single_process():
+    _dp_check(None)
+
+
+def _dp_check(emu_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, emu_path)) for r in range(2)]
     for p in procs:
         p.start()
     res = {r: torch.tensor(v, dtype=torch.float64).float() for r, v in (q.get(timeout=240) for _ in range(2))}
