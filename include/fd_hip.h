@@ -151,6 +151,12 @@ typedef struct FdHeadConst {
   double exp_max_sigma, exp_min_sigma;
   float min_b, max_b;
   int L;                 /* IGSO(3) truncation (1000) */
+  /* so3.use_cached_score=True (config/icml_published.yaml; so3_diffuser.py:293-299): device table [ng, n_omega] of
+   * score norms + its omega grid [n_omega]; the rotation score is then the bucketised lookup instead of the series
+   * (and carries no gradient through the lookup, like torch.gather of a constant).  NULL = series. */
+  const double* score_norms;
+  const double* omega_grid;
+  int n_omega;
 } FdHeadConst;
 int fd_heads_fwd(const float* rig0, const float* quatF, const float* transF, const float* upsi,
                  const float* gt_psi, long gt_stride, const float* fixed, const float* mask, const float* t,
@@ -176,9 +182,10 @@ int fd_igso3_tables(const double* sigma, const double* omega, int ns, int no, in
 int fd_sample_ref(const double* z_axis, const double* u, const double* z_trans, const double* cdf_row,
                   const double* omega, int no, double coord_scale, float* out, long n, void* stream);
 int fd_forward_marginal(const float* rig0, const double* z_axis, const double* u, const double* z_trans,
-                        const double* cdf_row, const double* omega, int no, double sigma, double beta,
-                        double coord_scale, int L, const float* mask, float* rig_t, double* rot_score,
-                        double* trans_score, long n, void* stream);
+                        const double* cdf_row, const double* omega, int no,
+                        const double* score_row /* optional: this sigma's score_norms row (use_cached_score) */,
+                        double sigma, double beta, double coord_scale, int L, const float* mask, float* rig_t,
+                        double* rot_score, double* trans_score, long n, void* stream);
 int fd_se3_reverse_step(const float* rig_t, const double* rot_score, const double* trans_score,
                         const double* z_rot, const double* z_trans, const float* mask, int B, int N, double g_rot,
                         double b_t, const double* tparams /* optional device {g_rot, b_t}: overrides the scalars,

@@ -394,8 +394,35 @@ def igso3_series(omega, sigma, L=1000):
     return f, df
 
 
+def so3_score_norms(conf=CONF, L=1000):
+    """so3_diffuser.py:131-180: the cached table score_norms[num_sigma, num_omega] = f'/(f + 1e-4) on the
+    discrete_omega = linspace(0, pi, num_omega + 1)[1:] grid (numpy float64, as precompute does)."""
+    omega = np.linspace(0, np.pi, conf["num_omega"] + 1)[1:]
+    sig = so3_discrete_sigma(conf)
+    rows = []
+    for i in range(0, len(sig), 20):                       # [20, num_omega, L] float64 temporaries
+        f, df = igso3_series(torch.tensor(omega)[None, :], torch.tensor(sig[i:i + 20])[:, None], L)
+        rows.append((df / (f + 1e-4)).numpy())
+    return np.concatenate(rows, 0), omega
+
+
+def so3_torch_score_cached(vec, t, score_norms, discrete_omega, conf=CONF, eps=1e-6):
+    """so3_diffuser.py:293-299,305 (use_cached_score=True, config/icml_published.yaml): the score norm is
+    score_norms[t_to_idx(t), bucketize(omega, discrete_omega[:-1])]; the lookup is a constant for autograd, so
+    the gradient only flows through vec / (omega + eps)."""
+    omega = torch.linalg.norm(vec, dim=-1) + eps
+    rows = torch.tensor(np.asarray(score_norms)[so3_t_to_idx(t.detach().cpu().numpy(), conf)])
+    rows = rows.reshape(rows.shape[0], -1)
+    idx = torch.bucketize(omega.detach(), torch.tensor(np.asarray(discrete_omega)[:-1]))
+    scal = torch.gather(rows, 1, idx.reshape(rows.shape[0], -1)).reshape(omega.shape)
+    return scal[..., None] * vec / (omega[..., None] + eps)
+
+
 def so3_torch_score(vec, t, conf=CONF, eps=1e-6):
-    """so3_diffuser.py:274-305, non-cached branch. vec [B,N,3]; t [B] -> float64 [B,N,3]."""
+    """so3_diffuser.py:274-305. vec [B,N,3]; t [B] -> float64 [B,N,3].  conf["score_norms"] /
+    conf["discrete_omega"] select the cached branch."""
+    if conf.get("score_norms") is not None:
+        return so3_torch_score_cached(vec, t, conf["score_norms"], conf["discrete_omega"], conf, eps)
     omega = torch.linalg.norm(vec, dim=-1) + eps
     sig = so3_discrete_sigma(conf)[so3_t_to_idx(t.detach().cpu().numpy(), conf)]
     sig = torch.tensor(sig, dtype=torch.float64)[:, None]

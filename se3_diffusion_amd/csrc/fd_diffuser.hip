@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void sample_ref_kernel(const double* __restric
 __global__ __launch_bounds__(256) void forward_marginal_kernel(
     const float* __restrict__ rig0, const double* __restrict__ z_axis, const double* __restrict__ u,
     const double* __restrict__ z_trans, const double* __restrict__ cdf_row, const double* __restrict__ omega, int no,
-    double sigma, double beta, double cs, int L, const float* __restrict__ mask, float* __restrict__ rig_t,
+    const double* __restrict__ score_row, double sigma, double beta, double cs, int L, const float* __restrict__ mask,
+    float* __restrict__ rig_t,
     double* __restrict__ rot_score, double* __restrict__ trans_score, long n) {
   const double e1 = exp(-0.5 * beta), cv = 1.0 - exp(-beta), sd = sqrt(cv);
   for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < n; r += (long)gridDim.x * 256) {
@@ -144,9 +145,21 @@ __global__ __launch_bounds__(256) void forward_marginal_kernel(
     // score of the SAMPLED rotation vector (so3_diffuser.py:324 -> :274-305 with float64 vec)
     const double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
     const double om = vn + 1e-6;
-    double f, df;
-    igso3_f_df(om, sigma, L, &f, &df);
-    const double sc = df / (f + 1e-4) / (om + 1e-6);
+    double g;
+    if (score_row) {
+      // use_cached_score (so3_diffuser.py:293-299): bucketize(om, omega[:-1]) into this sigma's score_norms row
+      int lo = 0, hi = no - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (omega[mid] < om) lo = mid + 1; else hi = mid;
+      }
+      g = score_row[lo];
+    } else {
+      double f, df;
+      igso3_f_df(om, sigma, L, &f, &df);
+      g = df / (f + 1e-4);
+    }
+    const double sc = g / (om + 1e-6);
     rotvec_to_quat(v, qe);
     quat_normalize(q0);
     quat_mul(q0, qe, qt);          // right multiply: R_0 Exp(v)
@@ -251,14 +264,14 @@ extern "C" int fd_sample_ref(const double* z_axis, const double* u, const double
 }
 
 extern "C" int fd_forward_marginal(const float* rig0, const double* z_axis, const double* u, const double* z_trans,
-                                   const double* cdf_row, const double* omega, int no, double sigma, double beta,
-                                   double coord_scale, int L, const float* mask, float* rig_t, double* rot_score,
-                                   double* trans_score, long n, void* stream) {
+                                   const double* cdf_row, const double* omega, int no, const double* score_row,
+                                   double sigma, double beta, double coord_scale, int L, const float* mask,
+                                   float* rig_t, double* rot_score, double* trans_score, long n, void* stream) {
   if (n == 0) return FD_OK;
   long g = (n + 255) / 256;
   hipLaunchKernelGGL(forward_marginal_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0,
-                     (hipStream_t)stream, rig0, z_axis, u, z_trans, cdf_row, omega, no, sigma, beta, coord_scale, L,
-                     mask, rig_t, rot_score, trans_score, n);
+                     (hipStream_t)stream, rig0, z_axis, u, z_trans, cdf_row, omega, no, score_row, sigma, beta,
+                     coord_scale, L, mask, rig_t, rot_score, trans_score, n);
   FD_CHECK_LAUNCH("fd_forward_marginal");
   return FD_OK;
 }

@@ -216,9 +216,9 @@ __device__ __forceinline__ void igso3_series(double om, double sg, int L, double
   *f = F; *df = D; *d2f = D2;
 }
 
-// sigma(t) = log(t e^{max} + (1-t) e^{min}); discrete value = grid[digitize(sigma) - 1]
-__device__ __forceinline__ double discrete_sigma(double t, const double* __restrict__ grid, int ng, double emax,
-                                                 double emin) {
+// sigma(t) = log(t e^{max} + (1-t) e^{min}); bin = digitize(sigma) - 1 (so3_diffuser.py:188-215 t_to_idx)
+__device__ __forceinline__ int sigma_index(double t, const double* __restrict__ grid, int ng, double emax,
+                                           double emin) {
   double s = log(t * emax + (1.0 - t) * emin);
   s *= (1.0 + 4.5e-16);  // x == grid[k] must land in bin k whatever the last ulp of log() does
   int lo = 0, hi = ng;   // count of grid entries <= s
@@ -228,7 +228,19 @@ __device__ __forceinline__ double discrete_sigma(double t, const double* __restr
   }
   int idx = lo - 1;
   if (idx < 0) idx = ng - 1;  // numpy negative indexing (t < 0 is rejected upstream)
-  return grid[idx];
+  return idx;
+}
+
+// d/dw log IGSO3 at (w, sigma-bin si): g = f'/(f + 1e-4) and its derivative gp.  With a cached table
+// (use_cached_score, so3_diffuser.py:293-299) g = score_norms[si, bucketize(w, omega[:-1])] and the lookup carries
+// no gradient (torch.gather of a constant), so gp = 0.
+__device__ __forceinline__ int omega_bucket(double om, const double* __restrict__ grid, int no) {
+  int lo = 0, hi = no - 1;  // count of grid[0 .. no-2] < om  (torch.bucketize, right=False)
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (grid[mid] < om) lo = mid + 1; else hi = mid;
+  }
+  return lo;
 }
 
 struct HeadConst {
@@ -239,7 +251,25 @@ struct HeadConst {
   double exp_max_sigma, exp_min_sigma;
   float min_b, max_b;
   int L;
+  const double* score_norms;  // [ng, n_omega] or null
+  const double* omega_grid;   // [n_omega]
+  int n_omega;
 };
+
+__device__ __forceinline__ void igso3_score(float omega, float tb, const double* __restrict__ sigma_grid, int ng,
+                                            const HeadConst& hc, double* g, double* gp) {
+  const int si = sigma_index((double)tb, sigma_grid, ng, hc.exp_max_sigma, hc.exp_min_sigma);
+  if (hc.score_norms) {
+    *g = hc.score_norms[(long)si * hc.n_omega + omega_bucket((double)omega, hc.omega_grid, hc.n_omega)];
+    *gp = 0.0;
+    return;
+  }
+  double f, df, d2f;
+  igso3_series((double)omega, sigma_grid[si], hc.L, &f, &df, &d2f);
+  const double fe = f + 1e-4;
+  *g = df / fe;
+  *gp = d2f / fe - df * df / (fe * fe);
+}
 
 // thread per residue
 __global__ __launch_bounds__(128) void heads_fwd_kernel(
@@ -269,10 +299,9 @@ __global__ __launch_bounds__(128) void heads_fwd_kernel(
     const float sc = ang <= 1e-3f ? 2.f + a2 / 12.f + 7.f * a2 * a2 / 2880.f : ang / sinf(ang / 2.f + 1e-6f);
     const float vx = sc * px, vy = sc * py, vz = sc * pz;
     const float omega = sqrtf(vx * vx + vy * vy + vz * vz) + 1e-6f;
-    const double sg = discrete_sigma((double)tb, sigma_grid, ng, hc.exp_max_sigma, hc.exp_min_sigma);
-    double f, df, d2f;
-    igso3_series((double)omega, sg, hc.L, &f, &df, &d2f);
-    const double scal = df / (f + 1e-4) / (double)(omega + 1e-6f) * (double)m;
+    double g, gp;
+    igso3_score(omega, tb, sigma_grid, ng, hc, &g, &gp);
+    const double scal = g / (double)(omega + 1e-6f) * (double)m;
     rot_score[r * 3 + 0] = scal * (double)vx;
     rot_score[r * 3 + 1] = scal * (double)vy;
     rot_score[r * 3 + 2] = scal * (double)vz;
@@ -386,11 +415,8 @@ __global__ __launch_bounds__(128) void heads_bwd_kernel(
       const float vx = sc * px, vy = sc * py, vz = sc * pz;
       const float vn = sqrtf(vx * vx + vy * vy + vz * vz);
       const float omega = vn + 1e-6f;
-      const double sg = discrete_sigma((double)tb, sigma_grid, ng, hc.exp_max_sigma, hc.exp_min_sigma);
-      double f, df, d2f;
-      igso3_series((double)omega, sg, hc.L, &f, &df, &d2f);
-      const double fe = f + 1e-4;
-      const double g = df / fe, gp = d2f / fe - df * df / (fe * fe);
+      double g, gp;
+      igso3_score(omega, tb, sigma_grid, ng, hc, &g, &gp);
       const double den = (double)(omega + 1e-6f);
       const double gx = d_rot[r * 3] * (double)m, gy = d_rot[r * 3 + 1] * (double)m, gz = d_rot[r * 3 + 2] * (double)m;
       // s = g(w) v / den ; w = |v| + eps ; den = w + eps
@@ -541,6 +567,9 @@ static HeadConst make_hc(const FdHeadConst* c) {
   hc.min_b = c->min_b;
   hc.max_b = c->max_b;
   hc.L = c->L;
+  hc.score_norms = c->score_norms;
+  hc.omega_grid = c->omega_grid;
+  hc.n_omega = c->n_omega;
   return hc;
 }
 
@@ -550,6 +579,7 @@ extern "C" int fd_heads_fwd(const float* rig0, const float* quatF, const float* 
                             double* rot_score, float* trans_score, float* rigids, float* psi_out, float* atom37,
                             float* atom14, int B, int N, void* stream) {
   FD_CHECK_ARG(c != nullptr, "fd_heads_fwd: null constants");
+  FD_CHECK_ARG(!c->score_norms || (c->omega_grid && c->n_omega > 1), "fd_heads_fwd: cached score table without its grid");
   const long R_ = (long)B * N;
   if (R_ == 0) return FD_OK;
   long g = (R_ + 127) / 128;
@@ -567,6 +597,7 @@ extern "C" int fd_heads_bwd(const float* rig0, const float* quatF, const float* 
                             const float* d_atom37, float* dquatF, float* dtransF, float* dupsi, int B, int N,
                             void* stream) {
   FD_CHECK_ARG(c != nullptr, "fd_heads_bwd: null constants");
+  FD_CHECK_ARG(!c->score_norms || (c->omega_grid && c->n_omega > 1), "fd_heads_bwd: cached score table without its grid");
   const long R_ = (long)B * N;
   if (R_ == 0) return FD_OK;
   long g = (R_ + 127) / 128;

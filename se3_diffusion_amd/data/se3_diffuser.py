@@ -94,12 +94,20 @@ class SE3Diffuser:
         ts = torch.empty((n, 3), dtype=torch.float64, device=dev)
         mask = None if diffuse_mask is None else torch.as_tensor(np.asarray(diffuse_mask), dtype=torch.float32, device=dev).reshape(n).contiguous()
         hip.get_lib().call("fd_forward_marginal", r0, _f64(z_axis, dev), _f64(u, dev), _f64(z_trans.reshape(n, 3), dev),
-                           (cdf, idx * cdf.shape[1]), omega, omega.numel(), float(so3.discrete_sigma[idx]),
-                           float(r3.marginal_b_t(t)), float(r3._r3_conf.coordinate_scaling), 1000, mask, rt, rs, ts, n)
+                           (cdf, idx * cdf.shape[1]), omega, omega.numel(), self._score_row(dev, idx),
+                           float(so3.discrete_sigma[idx]), float(r3.marginal_b_t(t)), float(r3._r3_conf.coordinate_scaling), 1000, mask, rt, rs, ts, n)
         rt = rt.view(shp + (7,))
         out = rt if as_tensor_7 else ru.Rigid.from_tensor_7(rt)
         return {'rigids_t': out, 'trans_score': ts.view(shp + (3,)).cpu().numpy(), 'rot_score': rs.view(shp + (3,)).cpu().numpy(),
                 'trans_score_scaling': r3.score_scaling(t), 'rot_score_scaling': so3.score_scaling(t)}
+
+    def _score_row(self, dev, idx):
+        """use_cached_score: (device score_norms table, element offset of sigma-bin idx); None = series in the kernel."""
+        so3 = self._so3_diffuser
+        if not so3.use_cached_score:
+            return None
+        tab = so3.device_score_norms(dev)
+        return (tab, idx * tab.shape[1])
 
     def forward_marginal_batch(self, rigids_0, t, diffuse_mask=None, noise=None, generator=None):
         """Device-side training-batch generation: the reference noises every example in DataLoader workers
@@ -131,8 +139,8 @@ class SE3Diffuser:
         for b in range(B):
             idx = int(so3.t_to_idx(float(t[b])))
             lib.call("fd_forward_marginal", (r0, b * N * 7), (z_axis, b * N * 3), (u, b * N), (z_trans, b * N * 3),
-                     (cdf, idx * cdf.shape[1]), omega, omega.numel(), float(so3.discrete_sigma[idx]),
-                     float(r3.marginal_b_t(float(t[b]))), float(r3._r3_conf.coordinate_scaling), 1000,
+                     (cdf, idx * cdf.shape[1]), omega, omega.numel(), self._score_row(dev, idx),
+                     float(so3.discrete_sigma[idx]), float(r3.marginal_b_t(float(t[b]))), float(r3._r3_conf.coordinate_scaling), 1000,
                      None if mask is None else (mask, b * N), (rt, b * N * 7), (rs, b * N * 3), (ts, b * N * 3), N)
         f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
         return {'rigids_t': rt, 'rot_score': rs.to(torch.float32), 'trans_score': ts.to(torch.float32),

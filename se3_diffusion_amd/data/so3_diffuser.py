@@ -156,6 +156,13 @@ class SO3Diffuser:
                                      torch.tensor(self.discrete_omega, dtype=torch.float64, device=device))
         return self._dev_tables[key]
 
+    def device_score_norms(self, device):
+        """score_norms [ns, no] float64 on `device` (the use_cached_score lookup table of the score kernels)."""
+        key = ("score_norms", str(device))
+        if key not in self._dev_tables:
+            self._dev_tables[key] = torch.tensor(self._score_norms, dtype=torch.float64, device=device)
+        return self._dev_tables[key]
+
     def sample_igso3(self, t: float, n_samples: float = 1):
         """Inverse-CDF sample of the rotation angle at time t."""
         if not np.isscalar(t):

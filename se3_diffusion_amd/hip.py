@@ -53,6 +53,7 @@ class FdHeadConst(Structure):
         ("exp_max_sigma", c_double), ("exp_min_sigma", c_double),
         ("min_b", c_float), ("max_b", c_float),
         ("L", c_int),
+        ("score_norms", c_void_p), ("omega_grid", c_void_p), ("n_omega", c_int),
     ]
 
 
@@ -114,7 +115,7 @@ _SIGS = {
     "fd_backbone_atoms": "ppSppls",
     "fd_igso3_tables": "ppiiippps",
     "fd_sample_ref": "pppppidpls",
-    "fd_forward_marginal": "ppppppidddipppp" + "ls",
+    "fd_forward_marginal": "ppppppipdddipppp" + "ls",
     "fd_se3_reverse_step": "ppppppiiddpdddiiips",
     "fd_dsm_loss": "Ss",
     "fd_adam_step": "pppplffffffs",

@@ -135,7 +135,5 @@ def _diffuser_consts(model_conf, diffuser):
     max_b = float(getattr(r3, "max_b", 20.0))
     min_s = float(getattr(so3, "min_sigma", 0.1))
     max_s = float(getattr(so3, "max_sigma", 1.5))
-    if so3 is not None and getattr(so3, "use_cached_score", False):
-        raise NotImplementedError("use_cached_score=True (the reference's bucketised table lookup) is not built; "
-                                  "config/base.yaml uses the series path")
-    return (cs, min_b, max_b, min_s, max_s, 1000)
+    cached = so3 if getattr(so3, "use_cached_score", False) else None   # icml_published.yaml: table lookup
+    return (cs, min_b, max_b, min_s, max_s, 1000, cached, int(getattr(so3, "num_sigma", 1000)))

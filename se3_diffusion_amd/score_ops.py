@@ -16,7 +16,8 @@ def _dconf(se3=None, so3=None, r3=None):
     r3 = r3 if r3 is not None else getattr(se3, "_r3_diffuser", None)
     cs = float(getattr(getattr(r3, "_r3_conf", None), "coordinate_scaling", 0.1))
     return (cs, float(getattr(r3, "min_b", 0.1)), float(getattr(r3, "max_b", 20.0)),
-            float(getattr(so3, "min_sigma", 0.1)), float(getattr(so3, "max_sigma", 1.5)), 1000)
+            float(getattr(so3, "min_sigma", 0.1)), float(getattr(so3, "max_sigma", 1.5)), 1000,
+            so3 if getattr(so3, "use_cached_score", False) else None, int(getattr(so3, "num_sigma", 1000)))
 
 
 class _RotScoreFn(torch.autograd.Function):
@@ -38,8 +39,7 @@ class _RotScoreFn(torch.autograd.Function):
         tt = t.to(torch.float32).reshape(-1).contiguous()
         if tt.numel() == 1 and B > 1:
             tt = tt.expand(B).contiguous()
-        hc = trunk.head_const(dconf)
-        sg = trunk.sigma_grid(dev.device, dconf[3], dconf[4], 1000)
+        hc, sg = trunk.head_tables(dconf, dev.device)
         rot = torch.empty((B, N, 3), device=dev.device, dtype=torch.float64)
         junk = [torch.empty((R, k), device=dev.device) for k in (3, 7, 2, 111, 42)]
         hip.get_lib().call("fd_heads_fwd", rig0, qf, z3, u, (gt, 4), 14, zeros, ones, tt, sg, sg.numel(), hc,

@@ -127,10 +127,17 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
 _HC = {}
 
 
-def head_const(conf_key=(0.1, 0.1, 20.0, 0.1, 1.5, 1000)):
-    """FdHeadConst from the reference constants (residue_constants.py:127-133, 769-781, 819-824)."""
+def head_const(conf_key=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), device=None):
+    """FdHeadConst from the reference constants (residue_constants.py:127-133, 769-781, 819-824).
+
+    conf_key = (coordinate_scaling, min_b, max_b, min_sigma, max_sigma, L[, so3, num_sigma]): a 7th entry that is an
+    SO3Diffuser with use_cached_score=True makes the rotation score the bucketised lookup in its score_norms table
+    (so3_diffuser.py:293-299), uploaded once per device."""
+    so3 = conf_key[6] if len(conf_key) > 6 else None
+    cached = so3 is not None and device is not None
+    conf_key = tuple(conf_key[:6]) + ((id(so3), str(device)) if cached else ())
     if conf_key not in _HC:
-        cs, min_b, max_b, min_s, max_s, L = conf_key
+        cs, min_b, max_b, min_s, max_s, L = conf_key[:6]
         n = np.array([-0.525, 1.363, 0.000]); ca = np.zeros(3); c = np.array([1.526, -0.000, -0.000])
         cb = np.array([-0.529, -0.774, -1.205]); o = np.array([0.627, 1.062, 0.000])
         ex = c - ca
@@ -151,11 +158,22 @@ def head_const(conf_key=(0.1, 0.1, 20.0, 0.1, 1.5, 1000)):
         hc.exp_max_sigma = float(np.exp(max_s))
         hc.exp_min_sigma = float(np.exp(min_s))
         hc.min_b, hc.max_b, hc.L = min_b, max_b, L
+        if cached:
+            tab, om = so3.device_score_norms(device), so3.device_tables(device)[1]
+            assert tab.shape[1] == om.numel()
+            hc.score_norms, hc.omega_grid, hc.n_omega = tab.data_ptr(), om.data_ptr(), om.numel()
+            hc._tables = (tab, om)            # keeps the device buffers alive as long as the struct
         _HC[conf_key] = hc
     return _HC[conf_key]
 
 
 _SG = {}
+
+
+def head_tables(dconf, device):
+    """(FdHeadConst, sigma grid) of a diffuser configuration on `device`."""
+    num_sigma = dconf[7] if len(dconf) > 7 else 1000
+    return head_const(dconf, device), sigma_grid(device, dconf[3], dconf[4], num_sigma)
 
 
 def sigma_grid(device, min_sigma=0.1, max_sigma=1.5, num_sigma=1000):
@@ -177,8 +195,7 @@ def heads_fwd(P, node, quat, trans, feats, B, N, dconf):
     ops.linear(mv(node), mv(P[f"{tp}.linear_1.weight"]), P[f"{tp}.linear_1.bias"], mv(h1), R, CS, CS, relu=True)
     ops.linear(mv(h1), mv(P[f"{tp}.linear_2.weight"]), P[f"{tp}.linear_2.bias"], mv(h2), R, CS, CS, resid=mv(node))
     ops.linear(mv(h2), mv(P[f"{tp}.linear_final.weight"]), P[f"{tp}.linear_final.bias"], mv(u), R, 2, CS)
-    hc = head_const(dconf)
-    sg = sigma_grid(dev.device, dconf[3], dconf[4], 1000)
+    hc, sg = head_tables(dconf, dev.device)
     rot = empty((B, N, 3), dev, torch.float64); ts = empty((B, N, 3), dev); rig = empty((B, N, 7), dev)
     psi = empty((B, N, 2), dev); a37 = empty((B, N, 37, 3), dev); a14 = empty((B, N, 14, 3), dev)
     gt = feats["torsion_angles_sin_cos"]

@@ -162,7 +162,7 @@ def _fm_kernel(diff, dev):
     ts = torch.empty((n, 3), dtype=torch.float64, device=dev)
     f64 = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
     hip.get_lib().call("fd_forward_marginal", r0, f64(G["fm_randn"]), f64(G["fm_rand"]), f64(G["fm_normal"]),
-                       (cdf, idx * cdf.shape[1]), omega, omega.numel(), float(so3.discrete_sigma[idx]),
+                       (cdf, idx * cdf.shape[1]), omega, omega.numel(), None, float(so3.discrete_sigma[idx]),
                        float(r3.marginal_b_t(t)), 0.1, 1000, None, rt, rs, ts, n)
     _check_fm(dict(rigids_t=rt, trans_score=ts.cpu().numpy(), rot_score=rs.cpu().numpy(),
                    trans_score_scaling=r3.score_scaling(t), rot_score_scaling=so3.score_scaling(t)))
