@@ -193,7 +193,7 @@ int fd_se3_reverse_step(const float* rig_t, const double* rot_score, const doubl
                         double coord_scale, int center, int diffuse_rot, int diffuse_trans, float* out, void* stream);
 
 /* ---- training loss (the step next to the hot path): experiments/train_se3_diffusion.py:524-693 ----
- * Experiment.loss_fn, separate_rot_loss branch: translation score / x0 loss, rotation axis + angle loss,
+ * Experiment.loss_fn, both rotation branches: translation score / x0 loss, rotation axis + angle (or joint MSE) loss,
  * backbone-atom loss and the 5N x 5N distance-matrix loss with their per-example normalisers and t filters, value AND
  * gradient w.r.t. the network outputs in three launches.  loss[0] = sum_b final_b / #non-empty examples.
  * terms[b] = {trans_score_loss, trans_x0_loss, axis_loss, angle_loss (weighted), bb_atom_loss (weighted),
@@ -222,6 +222,8 @@ typedef struct FdLossDesc {
   float* terms;                     /* [B,8] */
   float* loss;                      /* [1] */
   float* scratch;
+  int joint_rot_loss;               /* 0: separate_rot_loss=True (axis + angle, base.yaml); 1: joint rot-score MSE
+                                       (train_se3_diffusion.py:597-604, icml_published.yaml), reported in terms[:,3] */
 } FdLossDesc;
 
 int fd_dsm_loss(const FdLossDesc* desc, void* stream);

@@ -1,7 +1,8 @@
 // fd_dsm_loss: the denoising-score-matching training loss of FrameDiff and its gradient, fused.
 //
-// Replaces the arithmetic of Experiment.loss_fn (experiments/train_se3_diffusion.py:524-693, the
-// separate_rot_loss branch of config/base.yaml) -- translation score / x0 loss, rotation axis + angle loss,
+// Replaces the arithmetic of Experiment.loss_fn (experiments/train_se3_diffusion.py:524-693; both rotation
+// branches: separate_rot_loss of config/base.yaml = axis + angle terms, and the joint rot-score MSE of
+// config/icml_published.yaml, desc.joint_rot_loss) -- translation score / x0 loss, rotation loss,
 // backbone-atom loss, 5N x 5N distance-matrix loss, per-example normalisation and t filters -- which the reference
 // evaluates as ~150 elementwise / reduction launches over materialised [B,5N,5N] tensors (1.7 ms of a 39 ms step
 // here).  Forward value and the gradient w.r.t. the network outputs come out of the same pass:
@@ -80,8 +81,16 @@ __global__ __launch_bounds__(LT) void dsm_residue_kernel(FdLossDesc d) {
       const double u = g[c] / (ga + 1e-6) - p[c] / (pa + 1e-6);
       ax += u * u;
     }
-    s_axis += ax * (double)lm;
-    s_angle += (ga - pa) * (ga - pa) * (double)lm / (rss * rss);
+    if (d.joint_rot_loss) {
+      // :597-604  rot_mse = (gt - pred)^2 / scaling^2 (reported in the angle slot; no axis term)
+      double e2r = 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) e2r += (g[c] - p[c]) * (g[c] - p[c]);
+      s_angle += e2r * (double)lm / (rss * rss);
+    } else {
+      s_axis += ax * (double)lm;
+      s_angle += (ga - pa) * (ga - pa) * (double)lm / (rss * rss);
+    }
     for (int a = 0; a < 5; ++a) {
       const float* gp = d.gt_atom37 + (r * 37 + a) * 3;
       const float* pp = d.atom37 + (r * 37 + a) * 3;
@@ -155,7 +164,8 @@ __global__ __launch_bounds__(LT) void dsm_residue_kernel(FdLossDesc d) {
       const double dn = pa > 0.0 ? p[c] / pa : 0.0;
       const double axis_g = 2.0 * (u[c] / (pa + 1e-6) - dotup * dn / ((pa + 1e-6) * (pa + 1e-6)));
       const double angle_g = -2.0 * (ga - pa) * dn / (rss * rss) * (double)w_rot;
-      d.d_rot_score[r * 3 + c] = g_rot * (double)lm * (axis_g + angle_g) * (double)dm;
+      const double joint_g = -2.0 * (g[c] - p[c]) / (rss * rss) * (double)w_rot;
+      d.d_rot_score[r * 3 + c] = g_rot * (double)lm * (d.joint_rot_loss ? joint_g : axis_g + angle_g) * (double)dm;
     }
     for (int a = 0; a < 37; ++a) {
       float* o = d.d_atom37 + (r * 37 + a) * 3;

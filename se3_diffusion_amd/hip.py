@@ -71,6 +71,7 @@ class FdLossDesc(Structure):
         ("dist_mat_loss_weight", c_float), ("dist_mat_loss_t_filter", c_float),
         ("d_rot_score", c_void_p), ("d_trans_score", c_void_p), ("d_rigids", c_void_p), ("d_atom37", c_void_p),
         ("terms", c_void_p), ("loss", c_void_p), ("scratch", c_void_p),
+        ("joint_rot_loss", c_int),
     ]
 
 

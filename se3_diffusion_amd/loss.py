@@ -1,5 +1,5 @@
 """Fused DSM training loss (fd_dsm_loss): the arithmetic of ``Experiment.loss_fn``
-(experiments/train_se3_diffusion.py:524-693, ``separate_rot_loss`` branch) -- value and gradient w.r.t. the network
+(experiments/train_se3_diffusion.py:524-693, both ``separate_rot_loss`` branches) -- value and gradient w.r.t. the network
 outputs in three HIP launches instead of ~150 torch kernels over materialised [B,5N,5N] tensors.
 
     loss, aux = dsm_loss(batch, model_out, gt_atom37)        # same arguments as train_step.dsm_loss
@@ -43,6 +43,7 @@ class _DsmLossFn(torch.autograd.Function):
                   "rot_loss_t_threshold", "bb_atom_loss_weight", "bb_atom_loss_t_filter", "aux_loss_weight",
                   "dist_mat_loss_weight", "dist_mat_loss_t_filter"):
             setattr(d, k, float(getattr(exp, k)))
+        d.joint_rot_loss = 0 if getattr(exp, "separate_rot_loss", True) else 1
         if lib.is_device and not trans_score.is_cuda:
             raise hip.FdError("fd_dsm_loss: the outputs are not on the GPU; the hot path has no CPU fallback")
         lib.call("fd_dsm_loss", d)
@@ -60,10 +61,10 @@ class _DsmLossFn(torch.autograd.Function):
 
 def dsm_loss(batch, out, gt_atom37, exp=EXP, with_terms=False):
     """Same arguments and value as ``train_step.dsm_loss``; differentiable w.r.t. the four network outputs."""
-    assert getattr(exp, "separate_rot_loss", True), "only the separate_rot_loss branch (config/base.yaml) is built"
     loss, terms = _DsmLossFn.apply(out["rot_score"], out["trans_score"], out["rigids"], out["atom37"], batch,
                                    gt_atom37, exp)
     if with_terms:
+        # separate_rot_loss=False: axis_loss is 0 and the angle_loss slot carries the joint rot-score MSE
         names = ("trans_score_loss", "trans_x0_loss", "axis_loss", "angle_loss", "bb_atom_loss", "dist_mat_loss",
                  "final", "loss_mask_sum")
         return loss, {n: terms[:, i] for i, n in enumerate(names)}

@@ -92,7 +92,7 @@ def synthetic_batch(B, N, device, seed=0):
 
 
 def dsm_loss(batch, out, gt_atom37, exp=EXP):
-    """Experiment.loss_fn arithmetic (train_se3_diffusion.py:538-666), separate_rot_loss branch."""
+    """Experiment.loss_fn arithmetic (train_se3_diffusion.py:538-666), both rotation-loss branches."""
     bb_mask = batch["res_mask"]
     diffuse_mask = 1 - batch["fixed_mask"]
     loss_mask = bb_mask * diffuse_mask
@@ -117,6 +117,10 @@ def dsm_loss(batch, out, gt_atom37, exp=EXP):
                   / batch["rot_score_scaling"][:, None, None] ** 2).sum(dim=(-1, -2)) / denom
     angle_loss = angle_loss * exp.rot_loss_weight * (t > exp.rot_loss_t_threshold)
     rot_loss = angle_loss + axis_loss
+    if not getattr(exp, "separate_rot_loss", True):            # :597-604 (config/icml_published.yaml)
+        rot_loss = (((batch["rot_score"] - pred_rot) ** 2 * loss_mask[..., None])
+                    / batch["rot_score_scaling"][:, None, None] ** 2).sum(dim=(-1, -2)) / denom
+        rot_loss = rot_loss * exp.rot_loss_weight * (t > exp.rot_loss_t_threshold)
     pred_atoms = out["atom37"][:, :, :5]
     gt_atoms = gt_atom37[:, :, :5]
     atom_mask = torch.any(gt_atoms != 0, dim=-1).to(pred_atoms.dtype) * loss_mask[..., None]
