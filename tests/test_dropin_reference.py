@@ -5,7 +5,8 @@ subprocess because the reference's top-level module names (model, data, openfold
 generic.  Inside: oracle/ref_loader stubs the reference's missing non-arithmetic imports (hydra, wandb,
 ...), se3_diffusion_amd.dropin.install() binds model.score_network / data.se3_diffuser / ... to the HIP
 implementations (SIMT-interpreter build on this GPU-less box), then experiments.train_se3_diffusion.
-Experiment is constructed and its loss_fn / update_fn / inference_fn are driven directly."""
+Experiment is constructed and its loss_fn / update_fn / inference_fn are driven directly, then
+experiments.inference_se3_diffusion.Sampler.sample on top of it."""
 import os
 import subprocess
 import sys
@@ -65,6 +66,17 @@ feats = dict(res_mask=torch.ones(N), fixed_mask=torch.zeros(N), seq_idx=torch.ar
 feats = {k: v[None] for k, v in feats.items()}
 out = exp.inference_fn(feats, num_t=3, min_t=0.01, aux_traj=True, noise_scale=0.1)
 assert out["prot_traj"].shape == (3, 1, N, 37, 3) and np.isfinite(out["prot_traj"]).all()
+# the reference's inference script: Sampler.sample (inference_se3_diffusion.py:418-459) on the same experiment.
+# Sampler.__init__ (ESMFold download, output directories, checkpoint file) is bypassed; sample() only reads these.
+for n in ("biotite.sequence", "biotite.sequence.io"):
+    rl._stub(n)
+from experiments import inference_se3_diffusion as inf
+smp = object.__new__(inf.Sampler)
+smp.exp, smp.diffuser, smp.device = exp, exp.diffuser, "cpu"
+smp._diff_conf = ns(dict(num_t=3, min_t=0.01, noise_scale=0.1))
+so = smp.sample(N)
+assert so["prot_traj"].shape == (3, N, 37, 3) and np.isfinite(so["prot_traj"]).all(), so["prot_traj"].shape
+assert so["rigid_traj"].shape[1:] == (N, 7) and np.isfinite(so["rigid_traj"]).all()
 print("DROPIN_OK", float(loss), float(l2), bound)
 '''
 
