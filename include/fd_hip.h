@@ -186,6 +186,14 @@ int fd_forward_marginal(const float* rig0, const double* z_axis, const double* u
                         const double* score_row /* optional: this sigma's score_norms row (use_cached_score) */,
                         double sigma, double beta, double coord_scale, int L, const float* mask, float* rig_t,
                         double* rot_score, double* trans_score, long n, void* stream);
+/* a training batch in one launch (pdb_data_loader.py:240-262 calls forward_marginal once per example, each with its
+ * own t): cdf / score_norms are the full [ns, no] tables, tparams [B,3] (device, fp64) = {sigma bin = t_to_idx(t_b),
+ * discrete sigma of that bin, marginal_b_t(t_b)}; everything else is [B,N,...] as above. */
+int fd_forward_marginal_batch(const float* rig0, const double* z_axis, const double* u, const double* z_trans,
+                              const double* cdf, const double* omega, int no,
+                              const double* score_norms /* optional, use_cached_score */, const double* tparams,
+                              double coord_scale, int L, const float* mask, float* rig_t, double* rot_score,
+                              double* trans_score, int B, int N, void* stream);
 int fd_se3_reverse_step(const float* rig_t, const double* rot_score, const double* trans_score,
                         const double* z_rot, const double* z_trans, const float* mask, int B, int N, double g_rot,
                         double b_t, const double* tparams /* optional device {g_rot, b_t}: overrides the scalars,

@@ -130,6 +130,51 @@ __global__ __launch_bounds__(256) void sample_ref_kernel(const double* __restric
   }
 }
 
+// one residue of forward_marginal at (sigma, beta): sampled rotation, noised frame, DSM targets
+__device__ __forceinline__ void forward_marginal_one(
+    long r, const float* __restrict__ rig0, const double* __restrict__ z_axis, const double* __restrict__ u,
+    const double* __restrict__ z_trans, const double* __restrict__ cdf_row, const double* __restrict__ omega, int no,
+    const double* __restrict__ score_row, double sigma, double e1, double cv, double sd, double cs, int L,
+    const float* __restrict__ mask, float* __restrict__ rig_t, double* __restrict__ rot_score,
+    double* __restrict__ trans_score) {
+  const float* q0f = rig0 + r * 7;
+  const double m = mask ? (double)mask[r] : 1.0;
+  double v[3], qe[4], q0[4] = {q0f[0], q0f[1], q0f[2], q0f[3]}, qt[4];
+  sample_rotvec(z_axis + r * 3, u[r], cdf_row, omega, no, v);
+  // score of the SAMPLED rotation vector (so3_diffuser.py:324 -> :274-305 with float64 vec)
+  const double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const double om = vn + 1e-6;
+  double g;
+  if (score_row) {
+    // use_cached_score (so3_diffuser.py:293-299): bucketize(om, omega[:-1]) into this sigma's score_norms row
+    int lo = 0, hi = no - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (omega[mid] < om) lo = mid + 1; else hi = mid;
+    }
+    g = score_row[lo];
+  } else {
+    double f, df;
+    igso3_f_df(om, sigma, L, &f, &df);
+    g = df / (f + 1e-4);
+  }
+  const double sc = g / (om + 1e-6);
+  rotvec_to_quat(v, qe);
+  quat_normalize(q0);
+  quat_mul(q0, qe, qt);          // right multiply: R_0 Exp(v)
+  quat_normalize(qt);
+  float* o = rig_t + r * 7;
+  const bool diff = m > 0.5;
+  for (int k = 0; k < 4; ++k) o[k] = diff ? (float)qt[k] : q0f[k];
+  for (int k = 0; k < 3; ++k) {
+    rot_score[r * 3 + k] = diff ? sc * v[k] : 0.0;
+    const double x0 = (double)q0f[4 + k] * cs;
+    const double xt = e1 * x0 + sd * z_trans[r * 3 + k];
+    trans_score[r * 3 + k] = diff ? -(xt - e1 * x0) / cv : 0.0;
+    o[4 + k] = diff ? (float)(xt / cs) : q0f[4 + k];
+  }
+}
+
 __global__ __launch_bounds__(256) void forward_marginal_kernel(
     const float* __restrict__ rig0, const double* __restrict__ z_axis, const double* __restrict__ u,
     const double* __restrict__ z_trans, const double* __restrict__ cdf_row, const double* __restrict__ omega, int no,
@@ -137,44 +182,26 @@ __global__ __launch_bounds__(256) void forward_marginal_kernel(
     float* __restrict__ rig_t,
     double* __restrict__ rot_score, double* __restrict__ trans_score, long n) {
   const double e1 = exp(-0.5 * beta), cv = 1.0 - exp(-beta), sd = sqrt(cv);
-  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < n; r += (long)gridDim.x * 256) {
-    const float* q0f = rig0 + r * 7;
-    const double m = mask ? (double)mask[r] : 1.0;
-    double v[3], qe[4], q0[4] = {q0f[0], q0f[1], q0f[2], q0f[3]}, qt[4];
-    sample_rotvec(z_axis + r * 3, u[r], cdf_row, omega, no, v);
-    // score of the SAMPLED rotation vector (so3_diffuser.py:324 -> :274-305 with float64 vec)
-    const double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    const double om = vn + 1e-6;
-    double g;
-    if (score_row) {
-      // use_cached_score (so3_diffuser.py:293-299): bucketize(om, omega[:-1]) into this sigma's score_norms row
-      int lo = 0, hi = no - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (omega[mid] < om) lo = mid + 1; else hi = mid;
-      }
-      g = score_row[lo];
-    } else {
-      double f, df;
-      igso3_f_df(om, sigma, L, &f, &df);
-      g = df / (f + 1e-4);
-    }
-    const double sc = g / (om + 1e-6);
-    rotvec_to_quat(v, qe);
-    quat_normalize(q0);
-    quat_mul(q0, qe, qt);          // right multiply: R_0 Exp(v)
-    quat_normalize(qt);
-    float* o = rig_t + r * 7;
-    const bool diff = m > 0.5;
-    for (int k = 0; k < 4; ++k) o[k] = diff ? (float)qt[k] : q0f[k];
-    for (int k = 0; k < 3; ++k) {
-      rot_score[r * 3 + k] = diff ? sc * v[k] : 0.0;
-      const double x0 = (double)q0f[4 + k] * cs;
-      const double xt = e1 * x0 + sd * z_trans[r * 3 + k];
-      trans_score[r * 3 + k] = diff ? -(xt - e1 * x0) / cv : 0.0;
-      o[4 + k] = diff ? (float)(xt / cs) : q0f[4 + k];
-    }
-  }
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < n; r += (long)gridDim.x * 256)
+    forward_marginal_one(r, rig0, z_axis, u, z_trans, cdf_row, omega, no, score_row, sigma, e1, cv, sd, cs, L, mask,
+                         rig_t, rot_score, trans_score);
+}
+
+// a training batch: example b = blockIdx.y has its own time, i.e. its own (sigma bin, sigma, marginal beta) triple
+__global__ __launch_bounds__(256) void forward_marginal_batch_kernel(
+    const float* __restrict__ rig0, const double* __restrict__ z_axis, const double* __restrict__ u,
+    const double* __restrict__ z_trans, const double* __restrict__ cdf, const double* __restrict__ omega, int no,
+    const double* __restrict__ score_norms, const double* __restrict__ tparams, double cs, int L,
+    const float* __restrict__ mask, float* __restrict__ rig_t, double* __restrict__ rot_score,
+    double* __restrict__ trans_score, int N) {
+  const int b = (int)blockIdx.y;
+  const long row = (long)tparams[b * 3 + 0];
+  const double sigma = tparams[b * 3 + 1], beta = tparams[b * 3 + 2];
+  const double e1 = exp(-0.5 * beta), cv = 1.0 - exp(-beta), sd = sqrt(cv);
+  for (int n = (int)(blockIdx.x * 256 + threadIdx.x); n < N; n += (int)gridDim.x * 256)
+    forward_marginal_one((long)b * N + n, rig0, z_axis, u, z_trans, cdf + row * no, omega, no,
+                         score_norms ? score_norms + row * no : nullptr, sigma, e1, cv, sd, cs, L, mask, rig_t,
+                         rot_score, trans_score);
 }
 
 // one block per batch element (centering needs the mean over its N residues)
@@ -273,6 +300,20 @@ extern "C" int fd_forward_marginal(const float* rig0, const double* z_axis, cons
                      (hipStream_t)stream, rig0, z_axis, u, z_trans, cdf_row, omega, no, score_row, sigma, beta,
                      coord_scale, L, mask, rig_t, rot_score, trans_score, n);
   FD_CHECK_LAUNCH("fd_forward_marginal");
+  return FD_OK;
+}
+
+extern "C" int fd_forward_marginal_batch(const float* rig0, const double* z_axis, const double* u,
+                                         const double* z_trans, const double* cdf, const double* omega, int no,
+                                         const double* score_norms, const double* tparams, double coord_scale, int L,
+                                         const float* mask, float* rig_t, double* rot_score, double* trans_score,
+                                         int B, int N, void* stream) {
+  if (B == 0 || N == 0) return FD_OK;
+  FD_CHECK_ARG(tparams != nullptr, "fd_forward_marginal_batch: null per-example parameters");
+  hipLaunchKernelGGL(forward_marginal_batch_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, rig0, z_axis, u, z_trans, cdf, omega, no, score_norms, tparams, coord_scale,
+                     L, mask, rig_t, rot_score, trans_score, N);
+  FD_CHECK_LAUNCH("fd_forward_marginal_batch");
   return FD_OK;
 }
 

@@ -112,7 +112,7 @@ class SE3Diffuser:
     def forward_marginal_batch(self, rigids_0, t, diffuse_mask=None, noise=None, generator=None):
         """Device-side training-batch generation: the reference noises every example in DataLoader workers
         with scipy (pdb_data_loader.py:240-262 -> forward_marginal per example); here a whole batch
-        rigids_0 [B,N,7] (device) with per-example times t [B] is noised by fd_forward_marginal, one launch per example,
+        rigids_0 [B,N,7] (device) with per-example times t [B] is noised by one fd_forward_marginal_batch launch
         and everything stays on the device.  noise = (z_axis [B,N,3], u [B,N], z_trans [B,N,3]) float64 injects the draws
         (parity tests); by default they are drawn on the device in the reference's order (rotation axis, angle, then
         translation).  Returns the training-batch entries rigids_t [B,N,7] f32, rot_score / trans_score [B,N,3] f32,
@@ -135,13 +135,12 @@ class SE3Diffuser:
         rs = torch.empty((B, N, 3), dtype=torch.float64, device=dev)
         ts = torch.empty((B, N, 3), dtype=torch.float64, device=dev)
         mask = None if diffuse_mask is None else torch.as_tensor(diffuse_mask, dtype=torch.float32, device=dev).contiguous()
-        lib = hip.get_lib()
-        for b in range(B):
-            idx = int(so3.t_to_idx(float(t[b])))
-            lib.call("fd_forward_marginal", (r0, b * N * 7), (z_axis, b * N * 3), (u, b * N), (z_trans, b * N * 3),
-                     (cdf, idx * cdf.shape[1]), omega, omega.numel(), self._score_row(dev, idx),
-                     float(so3.discrete_sigma[idx]), float(r3.marginal_b_t(float(t[b]))), float(r3._r3_conf.coordinate_scaling), 1000,
-                     None if mask is None else (mask, b * N), (rt, b * N * 7), (rs, b * N * 3), (ts, b * N * 3), N)
+        idx = np.asarray(so3.t_to_idx(t)).reshape(B)
+        tparams = torch.tensor(np.stack([idx.astype(np.float64), so3.discrete_sigma[idx], r3.marginal_b_t(t)], 1),
+                               dtype=torch.float64, device=dev)              # per example: sigma bin, sigma, marginal beta
+        hip.get_lib().call("fd_forward_marginal_batch", r0, z_axis, u, z_trans, cdf, omega, omega.numel(),
+                           so3.device_score_norms(dev) if so3.use_cached_score else None, tparams,
+                           float(r3._r3_conf.coordinate_scaling), 1000, mask, rt, rs, ts, B, N)
         f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
         return {'rigids_t': rt, 'rot_score': rs.to(torch.float32), 'trans_score': ts.to(torch.float32),
                 'rot_score_scaling': f32([so3.score_scaling(float(x)) for x in t]),

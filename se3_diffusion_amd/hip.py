@@ -117,6 +117,7 @@ _SIGS = {
     "fd_igso3_tables": "ppiiippps",
     "fd_sample_ref": "pppppidpls",
     "fd_forward_marginal": "ppppppipdddipppp" + "ls",
+    "fd_forward_marginal_batch": "ppppppippdipppp" + "iis",
     "fd_se3_reverse_step": "ppppppiiddpdddiiips",
     "fd_dsm_loss": "Ss",
     "fd_adam_step": "pppplffffffs",
