@@ -79,6 +79,9 @@ int fd_gemm(const FdGemmDesc* desc, void* stream);
 int fd_gemm_plan(const FdGemmDesc* desc);
 /* exact != 0: every later fd_gemm runs on the fp32-MFMA kernels (as FD_GEMM_EXACT_F32=1); returns the previous mode */
 int fd_gemm_set_exact_f32(int exact);
+/* the split-bf16 kernel runs as `blocks` persistent blocks (default 256 = one per MI355X CU) that walk the output
+ * tiles whenever a launch has at least 2 * blocks tiles; 0 = one fresh block per tile.  Returns the previous value. */
+int fd_gemm_set_persistent_blocks(int blocks);
 
 /* ---- LayerNorm / reductions (HBM-bound) -------------------------------
  * torch.nn.LayerNorm (eps 1e-5, biased variance) at score_network.py:73,85,

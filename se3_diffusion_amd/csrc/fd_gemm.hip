@@ -509,6 +509,14 @@ bool bx3_layout_ok(const FdGemmDesc& d) {
   return a_kc || (!a_kc && !b_kc);
 }
 
+// persistent blocks of the split kernel: one per CU (0 = fresh block per tile; FD_GEMM_NOPERSIST=1 or
+// fd_gemm_set_persistent_blocks)
+int g_persist_blocks = -1;
+int persist_blocks() {
+  if (g_persist_blocks < 0) g_persist_blocks = getenv("FD_GEMM_NOPERSIST") ? 0 : 256;   // MI355X: 256 CUs
+  return g_persist_blocks;
+}
+
 template <int BM>
 int launch_bx3(const FdGemmDesc& d, hipStream_t stream) {
   GemmArgs g;
@@ -526,6 +534,17 @@ int launch_bx3(const FdGemmDesc& d, hipStream_t stream) {
   // the 256-row shape without split-K accumulates transposed and stores float4s straight from registers
   static const bool no_trans = getenv("FD_GEMM_NOTRANS") != nullptr;   // (A/B measurements)
   const bool trans = BM == 256 && g.ksplit == 1 && a_kc && !no_trans;
+  // >= 2 tiles per CU: one persistent block per CU walks them with the next tile's prologue under the epilogue
+  const int kCUs = persist_blocks();
+  if (trans && kCUs > 0 && g.nblk_m * g.nblk_n >= 2 * kCUs) {
+    dim3 pgrid(kCUs, nb, 1);
+    if (b_kc)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3p_kernel<true>), pgrid, block, 0, stream, g);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3p_kernel<false>), pgrid, block, 0, stream, g);
+    FD_CHECK_LAUNCH("fd_gemm(split-bf16, persistent)");
+    return FD_OK;
+  }
   if (a_kc && b_kc) {
     if (trans)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_bx3_kernel<BM, true, true, BM == 256>), grid, block, 0, stream, g);
@@ -635,6 +654,12 @@ int launch_cfg(const FdGemmDesc& d, hipStream_t stream) {
 extern "C" int fd_gemm_set_exact_f32(int exact) {
   const int was = split_enabled() ? 0 : 1;
   g_split_mode = exact ? 0 : 1;
+  return was;
+}
+
+extern "C" int fd_gemm_set_persistent_blocks(int blocks) {
+  const int was = persist_blocks();
+  g_persist_blocks = blocks > 0 ? blocks : 0;
   return was;
 }
 

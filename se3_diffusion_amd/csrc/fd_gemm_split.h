@@ -162,25 +162,41 @@ struct SplitStager {
   int lofs[NS];   // LDS byte offset of the slot (plane 0)
   long kstep, cs;
 
+  // slot i of producer thread tid -> (row inside the tile, k group)
+  static __device__ __forceinline__ void slot(int tid, int i, int& row, int& kg) {
+    const int f = tid + NPROD * i;   // tid = producer thread index
+    // KC: two lanes cover the 64 contiguous bytes a row contributes to a stage; the four rows of an 8-lane
+    // ds_write_b128 group are taken 2 apart (2 * 112 B = 96 mod 128: the group tiles one 32-bank window)
+    const int q = f >> 1;
+    row = KC ? ((q & ~7) | ((q & 3) << 1) | ((q & 7) >> 2)) : (f % ROWS);
+    kg = KC ? (f & 1) : (f / ROWS);
+  }
+
+  // point the slots at rows row0.. of the operand, first k = k0 (the persistent kernel calls this once per tile)
+  __device__ __forceinline__ void target(const float* __restrict__ b, long rs_, int row0, int nrows, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      int row, kg;
+      slot(tid, i, row, kg);
+      // rows past the end are CLAMPED, not zero-filled: an output row/column depends only on its own operand
+      // row, and the epilogue never stores rows >= M or columns >= N
+      const int grow = (row0 + row < nrows) ? row0 + row : nrows - 1;
+      p[i] = b + (long)grow * rs_ + (long)(k0 + 8 * kg) * cs;
+    }
+  }
+
   __device__ __forceinline__ void init(const float* __restrict__ b, long rs_, long cs_, int row0, int nrows, int k0,
                                        int tid) {
     cs = cs_;
     kstep = (long)XBK * cs_;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      const int f = tid + NPROD * i;   // tid = producer thread index
-      // KC: two lanes cover the 64 contiguous bytes a row contributes to a stage; the four rows of an 8-lane
-      // ds_write_b128 group are taken 2 apart (2 * 112 B = 96 mod 128: the group tiles one 32-bank window)
-      const int q = f >> 1;
-      const int row = KC ? ((q & ~7) | ((q & 3) << 1) | ((q & 7) >> 2)) : (f % ROWS);
-      const int kg = KC ? (f & 1) : (f / ROWS);
+      int row, kg;
+      slot(tid, i, row, kg);
       kofs[i] = 8 * kg;
       lofs[i] = row * XROWB + kg * 16;
-      // rows past the end are CLAMPED, not zero-filled: an output row/column depends only on its own operand
-      // row, and the epilogue never stores rows >= M or columns >= N
-      const int grow = (row0 + row < nrows) ? row0 + row : nrows - 1;
-      p[i] = b + (long)grow * rs_ + (long)(k0 + 8 * kg) * cs_;
     }
+    target(b, rs_, row0, nrows, k0, tid);
   }
 
   __device__ __forceinline__ void load(float (&r)[NS][8], int k0, int K) {
@@ -415,4 +431,150 @@ __global__ __launch_bounds__(SplitCfg<BM>::NTHR, SplitCfg<BM>::BLOCKS_PER_CU) vo
     store_tile_vec<BM, BN, TM, TN, NCONS>(d, C, acc, reinterpret_cast<float*>(lds), m0, n0, wm, wn, h, l31, tid);
   else
     store_tile<TM, TN>(d, C, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, h, l31, g.ksplit > 1);
+}
+
+
+// Persistent form of the 256 x 128 TRANS kernel (A k-contiguous, no split-K): gridDim.x = one block per CU, block b
+// walks the tiles b, b + gridDim.x, ...  The producers treat the (tile, k stage) sequence as ONE stream, so while the
+// consumers store a finished tile the producers already have the next tile's first stages in the ring (and two more
+// in registers): the global-load latency of a tile's prologue, the block launch and the descriptor setup no longer
+// sit between two MFMA loops.  Measured on the fresh-block kernel: 10.5 us of un-overlapped prologue + epilogue per tile
+// against 29 us of MFMA loop at K = 384 (52 % of a K = 128 launch).  The consumers keep no fragment alive across
+// the epilogue (stage 0 of the next tile is read from the ring after it), so the register budget is the fresh-block kernel's.
+template <bool B_KC>
+__global__ __launch_bounds__(SplitCfg<XBM>::NTHR, 1) void gemm_bx3p_kernel(GemmArgs g) {
+  using Cfg = SplitCfg<XBM>;
+  constexpr int BM = XBM, BN = XBN, TM = 2, TN = 2;
+  constexpr int NCONS = Cfg::NCONS, NPROD = Cfg::NPROD, STAGE = Cfg::STAGE, RING = 3;
+  constexpr int A_BYTES = BM * XROWB;
+  static_assert(Cfg::RING == 3, "ring");
+  __shared__ __attribute__((aligned(16))) char lds[RING * STAGE];
+
+  const FdGemmDesc& d = g.d;
+  const int tid = (int)threadIdx.x;
+  const int nblk = g.nblk_m * g.nblk_n;
+  const int G = (int)gridDim.x, first = (int)blockIdx.x;       // G <= nblk
+  const int ntiles = (nblk - first + G - 1) / G;
+  const int z = (int)blockIdx.y;
+  const int zo = z / d.bdiv, zi = z % d.bdiv;
+  const int nk = (d.K + XBK - 1) / XBK;
+  const int total = ntiles * nk;
+
+  if (tid >= NCONS) {
+    const int ptid = tid - NCONS;
+    fd::raise_wave_priority();
+    const float* __restrict__ A = d.A + zo * d.a_so + zi * d.a_si;
+    const float* __restrict__ B = d.B + zo * d.b_so + zi * d.b_si;
+    SplitStager<BM, true, NPROD> sa;
+    SplitStager<BN, B_KC, NPROD> sb;
+    constexpr int NSA = SplitStager<BM, true, NPROD>::NS, NSB = SplitStager<BN, B_KC, NPROD>::NS;
+    constexpr int NSET = 2;
+    float ra[NSET][NSA][8], rb[NSET][NSB][8];
+    int lt = first, lk = 0;   // tile and k stage of the next global load
+    {
+      const int lid = fd_xcd_swizzle(lt, nblk);
+      sa.init(A, d.a_rs, d.a_cs, (lid / g.nblk_n) * BM, d.M, 0, ptid);
+      sb.init(B, d.b_cs, d.b_rs, (lid % g.nblk_n) * BN, d.N, 0, ptid);
+    }
+    auto issue = [&](float (&xa)[NSA][8], float (&xb)[NSB][8]) {
+      sa.load(xa, lk * XBK, d.K);
+      sb.load(xb, lk * XBK, d.K);
+      if (++lk == nk) {
+        lk = 0;
+        lt += G;
+        if (lt < nblk) {
+          const int lid = fd_xcd_swizzle(lt, nblk);
+          sa.target(A, d.a_rs, (lid / g.nblk_n) * BM, d.M, 0, ptid);
+          sb.target(B, d.b_cs, (lid % g.nblk_n) * BN, d.N, 0, ptid);
+        }
+      }
+    };
+    int wbuf = 0;
+    auto put = [&](float (&xa)[NSA][8], float (&xb)[NSB][8]) {
+      char* dst = lds + wbuf * STAGE;
+      sa.store(xa, dst);
+      sb.store(xb, dst + A_BYTES);
+      wbuf = (wbuf == RING - 1) ? 0 : wbuf + 1;
+    };
+    constexpr int AHEAD = RING - 1;
+#pragma unroll
+    for (int u = 0; u < NSET; ++u)
+      if (u < total) issue(ra[u], rb[u]);
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u)
+      if (u < total) {
+        put(ra[u], rb[u]);
+        if (u + NSET < total) issue(ra[u], rb[u]);
+      }
+    __syncthreads();
+    auto step = [&](int it, float (&xa)[NSA][8], float (&xb)[NSB][8]) {
+      if (it + AHEAD < total) {
+        put(xa, xb);
+        if (it + AHEAD + NSET < total) issue(xa, xb);
+      }
+      __syncthreads();
+    };
+    for (int it = 0; it < total; it += NSET) {
+#pragma unroll
+      for (int u = 0; u < NSET; ++u)
+        if (it + u < total) step(it + u, ra[(AHEAD + u) % NSET], rb[(AHEAD + u) % NSET]);
+    }
+    return;
+  }
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* __restrict__ C = d.C + zo * d.c_so + zi * d.c_si;
+  const int a_frag = ((wm * TM) * 32 + l31) * XROWB + h * 16;
+  const int b_frag = A_BYTES + ((wn * TN) * 32 + l31) * XROWB + h * 16;
+  int rbuf = 0;
+  __syncthreads();   // the first stages are in the ring
+  for (int ti = 0; ti < ntiles; ++ti) {
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    uint4 fa[2][TM][3], fb[2][TN][3];
+    auto read_frags = [&](uint4 (&xa)[TM][3], uint4 (&xb)[TN][3]) {
+      const char* st = lds + rbuf * STAGE;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          xa[i][s] = *reinterpret_cast<const uint4*>(st + a_frag + i * 32 * XROWB + s * 2 * XBK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          xb[j][s] = *reinterpret_cast<const uint4*>(st + b_frag + j * 32 * XROWB + s * 2 * XBK);
+      }
+      rbuf = (rbuf == RING - 1) ? 0 : rbuf + 1;
+    };
+    auto mfmas = [&](uint4 (&xa)[TM][3], uint4 (&xb)[TN][3]) {
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+        constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = fd::mfma_32x32x16_bf16(xb[j][PB[p]], xa[i][PA[p]], acc[i][j]);
+      }
+    };
+    auto step = [&](int it, uint4 (&ca)[TM][3], uint4 (&cb)[TN][3], uint4 (&na)[TM][3], uint4 (&nb)[TN][3]) {
+      if (it + 1 < nk) read_frags(na, nb);
+      mfmas(ca, cb);
+      fd::block_barrier_nofence();
+    };
+    read_frags(fa[0], fb[0]);
+    for (int it = 0; it < nk; it += 2) {
+      step(it, fa[0], fb[0], fa[1], fb[1]);
+      if (it + 1 < nk) step(it + 1, fa[1], fb[1], fa[0], fb[0]);
+    }
+    const int lid = fd_xcd_swizzle(first + ti * G, nblk);
+    store_tile_t<TM, TN>(d, C, acc, (lid / g.nblk_n) * BM + wm * TM * 32, (lid % g.nblk_n) * BN + wn * TN * 32, h, l31,
+                         g.epi_vec != 0);
+  }
 }

@@ -90,6 +90,7 @@ _SIGS = {
     "fd_gemm": "Ss",
     "fd_gemm_plan": "S",
     "fd_gemm_set_exact_f32": "i",
+    "fd_gemm_set_persistent_blocks": "i",
     "fd_layernorm_fwd": "plpppplpplifs",
     "fd_layernorm_bwd": "plplpppppl" + "ipplis",
     "fd_colsum_acc": "pllips",

@@ -167,6 +167,42 @@ def test_gemm_split_epilogue_emu(emu_lib):
     assert _run(emu_lib, "cpu", 300, 132, 72, True, False, 4, epi=True) < 2e-6
 
 
+def _persistent(lib, dev, blocks, cases):
+    """persistent blocks of the split kernel (several tiles per block, ragged edges, odd stage counts, k tails, fused
+    epilogue) == the fresh-block kernel bit for bit (same per-tile arithmetic), and right against fp64"""
+    was = lib.cdll.fd_gemm_set_persistent_blocks(blocks)
+    try:
+        for (M, N, K, b_kc, epi) in cases:
+            assert lib.cdll.fd_gemm_set_persistent_blocks(blocks) == blocks
+            e1 = _run(lib, dev, M, N, K, True, b_kc, 4, epi=epi, seed=3)
+            assert e1 < 2e-6, (M, N, K, e1)
+    finally:
+        lib.cdll.fd_gemm_set_persistent_blocks(was)
+
+
+def test_gemm_split_persistent_emu(emu_lib):
+    # 3 x 3 and 4 x 2 tiles over 3 persistent blocks: 3, 3, 3 and 3, 3, 2 tiles per block
+    _persistent(emu_lib, "cpu", 3, [(700, 300, 40, True, False), (1000, 200, 72, False, True), (520, 260, 16, True, True)])
+
+
+@pytest.mark.gpu
+def test_gemm_split_persistent_gpu(hip_lib):
+    _persistent(hip_lib, "cuda", 256, [(256 * 40 + 17, 128 * 13 + 4, 200, True, True), (256 * 70, 1024, 72, False, True)])
+    _persistent(hip_lib, "cuda", 5, [(700, 300, 40, True, False), (1000, 200, 72, False, True)])
+    # identical to the fresh-block kernel
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 256 * 64, 1152, 384
+    A = torch.randn(M, K, generator=g).cuda(); W = torch.randn(N, K, generator=g).cuda()
+    outs = []
+    for blocks in (256, 0):
+        was = hip_lib.cdll.fd_gemm_set_persistent_blocks(blocks)
+        C = torch.zeros(M, N, device="cuda")
+        hip_lib.gemm(A, W, C, M, N, K, (K, 1), (1, K), N, tile=4)
+        hip_lib.cdll.fd_gemm_set_persistent_blocks(was)
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+
+
 def _split_accuracy(lib, dev, M, N, K):
     """the split path carries fp32 accuracy: its error against fp64 is of the size of the fmaf-chain kernel's"""
     g = torch.Generator().manual_seed(9)

@@ -118,6 +118,12 @@ SHAPES = [
     ("t2 dWks 144 (128x128)", 128, 128, P, False, False, 2, 144),
     ("t2 dWks 288 (128x128)", 128, 128, P, False, False, 2, 288),
     ("t2 dWks 576 (128x128)", 128, 128, P, False, False, 2, 576),
+    ("ov K=64", P, 384, 64, True, True, 4, 1),
+    ("ov K=128", P, 384, 128, True, True, 4, 1),
+    ("ov K=256", P, 384, 256, True, True, 4, 1),
+    ("ov K=384", P, 384, 384, True, True, 4, 1),
+    ("ov K=768", P, 384, 768, True, True, 4, 1),
+    ("ov K=1536", P, 384, 1536, True, True, 4, 1),
     ("x3 sample edge W2 N=128", 16384, 384, 384, True, True, 4, 1),
     ("x3 sample edge W2 N=256", 65536, 384, 384, True, True, 4, 1),
     ("x3 square 4096 NT", 4096, 4096, 4096, True, True, 4, 1),
