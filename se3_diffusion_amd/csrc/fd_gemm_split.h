@@ -439,8 +439,12 @@ __global__ __launch_bounds__(SplitCfg<BM>::NTHR, SplitCfg<BM>::BLOCKS_PER_CU) vo
 // consumers store a finished tile the producers already have the next tile's first stages in the ring (and two more
 // in registers): the global-load latency of a tile's prologue, the block launch and the descriptor setup no longer
 // sit between two MFMA loops.  Measured on the fresh-block kernel: 10.5 us of un-overlapped prologue + epilogue per tile
-// against 29 us of MFMA loop at K = 384 (52 % of a K = 128 launch).  The consumers keep no fragment alive across
-// the epilogue (stage 0 of the next tile is read from the ring after it), so the register budget is the fresh-block kernel's.
+// against 29 us of MFMA loop at K = 384 (52 % of a K = 128 launch); persistent: 9.3 us.  What remains is the epilogue
+// itself (no epilogue: ~0; the same bytes as lane-contiguous 1 KB stores: -2.7 us): a store instruction of the
+// transposed layout touches 32 different lines (a lane owns a row) and the CU retires about one line per clock.
+// Re-transposing through a wave-private LDS scratch to store whole lines was measured and gives the 2.7 us back to
+// the LDS round trip.  The consumers keep no fragment alive across the epilogue (stage 0 of the next tile is read from
+// the ring after it), so the register budget is the fresh-block kernel's (166 VGPRs, no spills).
 template <bool B_KC>
 __global__ __launch_bounds__(SplitCfg<XBM>::NTHR, 1) void gemm_bx3p_kernel(GemmArgs g) {
   using Cfg = SplitCfg<XBM>;
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(SplitCfg<XBM>::NTHR, 1) void gemm_bx3p_kernel(GemmA
       if (it + 1 < nk) step(it + 1, fa[1], fb[1], fa[0], fb[0]);
     }
     const int lid = fd_xcd_swizzle(first + ti * G, nblk);
-    store_tile_t<TM, TN>(d, C, acc, (lid / g.nblk_n) * BM + wm * TM * 32, (lid % g.nblk_n) * BN + wn * TN * 32, h, l31,
-                         g.epi_vec != 0);
+    const int mb = (lid / g.nblk_n) * BM + wm * TM * 32, nb = (lid % g.nblk_n) * BN + wn * TN * 32;
+    store_tile_t<TM, TN>(d, C, acc, mb, nb, h, l31, g.epi_vec != 0);
   }
 }

@@ -103,6 +103,7 @@ static inline void block_barrier_nofence() { hipemu::barrier(); }
 
 static inline void sched_fence() {}
 
+
 static inline int lane_id() { return hipemu::g_cur->lane; }
 static inline int wave_id() { return hipemu::g_cur->wave; }
 
