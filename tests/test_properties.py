@@ -7,6 +7,8 @@ oracle is too slow to be the checker (gfx950 only, -m gpu):
   * batch independence: an example's outputs do not depend on its batch mates;
   * GEMM checksums at the pair-level size (M = 491,520): column sums of C against (column sums of A) W^T in float64, and
     linearity in W, through the persistent split-bf16 kernel and the fp32-MFMA kernel;
+  * backward at full size: the directional derivative of the training loss along a random parameter direction, by
+    central differences of the forward pass, against <grad, direction> from the hand-written backward;
   * diffuser round trips: x_0 recovered from (trans_score, x_t, t) (r3_diffuser.py:45-50) and the rotation score of
     forward_marginal aligned with the rotation it applied.
 
@@ -97,6 +99,42 @@ def test_batch_independence_full_size(hip_lib):
     # tensor 1 - mask as src_key_padding_mask, which the training path adds to the logits (+1 on padded keys) instead of
     # masking them, so padded residues take part in the sequence attention (the oracle restates exactly that:
     # tfmr_mask_mode="additive"; with 4 padded residues its outputs move by 7-40 %).
+
+
+def test_directional_derivative_full_size(hip_lib):
+    """fwd + fused DSM loss + bwd of the B=30 x N=128 training step (the bench.py workload)"""
+    from se3_diffusion_amd import loss as floss
+    from se3_diffusion_amd import train_step as ts
+    from se3_diffusion_amd.model.score_network import ScoreNetwork
+    B, N = 30, 128
+    m = ScoreNetwork(ts.base_model_conf(4), diffuser=None)
+    m.load_state_dict(fo.synth_params(seed=2, conf=dict(fo.CONF, num_blocks=4)), strict=True)
+    m = m.cuda().train()
+    batch = ts.synthetic_batch(B, N, "cuda", seed=7)
+    gt37, _ = ts.backbone_atoms(batch["rigids_0"], batch["torsion_angles_sin_cos"][..., 2, :])
+    loss = floss.dsm_loss(batch, m(batch), gt37)
+    loss.backward()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    params = [p for p in m.parameters() if p.grad is not None]
+    dirs = [torch.randn(p.shape, device="cuda", generator=g) * p.detach().abs().mean() for p in params]
+    analytic = sum(float((p.grad.double() * d.double()).sum()) for p, d in zip(params, dirs))
+
+    def loss_at(eps):
+        with torch.no_grad():
+            for p, d in zip(params, dirs):
+                p.add_(d, alpha=eps)
+            v = float(floss.dsm_loss(batch, m(batch), gt37))
+            for p, d in zip(params, dirs):
+                p.sub_(d, alpha=eps)
+        return v
+
+    # the step is chosen so that the loss moves by ~1e-3 of its value: far above fp32 forward noise, small enough for
+    # the second-order term of a central difference
+    lv = float(loss.detach())
+    eps = 1e-3 * abs(lv) / (abs(analytic) + 1e-12)
+    eps = min(max(eps, 1e-4), 5e-2)
+    fd = (loss_at(eps) - loss_at(-eps)) / (2 * eps)
+    assert abs(fd - analytic) < 3e-2 * abs(analytic) + 1e-6, (fd, analytic, eps, lv)
 
 
 @pytest.mark.parametrize("tile", [0, 1])
