@@ -129,10 +129,19 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
     dev = z
     R, Pn = B * N, B * N * N
     proj = empty((R, LDP), dev)
-    ops.linear(s, mv(P[f"{pre}.linear_q.weight"]), P[f"{pre}.linear_q.bias"], (proj, 0, LDP), R, H * C, CS)
-    ops.linear(s, mv(P[f"{pre}.linear_kv.weight"]), P[f"{pre}.linear_kv.bias"], (proj, 2048, LDP), R, 2 * H * C, CS)
-    ops.linear(s, mv(P[f"{pre}.linear_q_points.weight"]), P[f"{pre}.linear_q_points.bias"], (proj, 6144, LDP), R, 192, CS)
-    ops.linear(s, mv(P[f"{pre}.linear_kv_points.weight"]), P[f"{pre}.linear_kv_points.bias"], (proj, 6336, LDP), R, 480, CS)
+    names = ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")     # column blocks 0, 2048, 6144, 6336
+    if cache is not None:
+        # static weights (sampling): the four projections of s are one GEMM over the row-concatenated weight
+        if ("Wproj", pre) not in cache:
+            cache[("Wproj", pre)] = (torch.cat([P[f"{pre}.{n}.weight"] for n in names], 0).contiguous(),
+                                     torch.cat([P[f"{pre}.{n}.bias"] for n in names], 0).contiguous())
+        Wp, bp = cache[("Wproj", pre)]
+        ops.linear(s, mv(Wp), bp, mv(proj), R, LDP, CS)
+    else:
+        ops.linear(s, mv(P[f"{pre}.linear_q.weight"]), P[f"{pre}.linear_q.bias"], (proj, 0, LDP), R, H * C, CS)
+        ops.linear(s, mv(P[f"{pre}.linear_kv.weight"]), P[f"{pre}.linear_kv.bias"], (proj, 2048, LDP), R, 2 * H * C, CS)
+        ops.linear(s, mv(P[f"{pre}.linear_q_points.weight"]), P[f"{pre}.linear_q_points.bias"], (proj, 6144, LDP), R, 192, CS)
+        ops.linear(s, mv(P[f"{pre}.linear_kv_points.weight"]), P[f"{pre}.linear_kv_points.bias"], (proj, 6336, LDP), R, 480, CS)
     qp = empty((R, H, PQ * 3), dev); kp = empty((R, H, PQ * 3), dev); vp = empty((R, H, PV * 3), dev)
     lib().call("fd_ipa_points_fwd", proj, quat, trans, qp, kp, vp, R, H, C, PQ, PV)
     if cache is not None and ("W40", pre) in cache:
