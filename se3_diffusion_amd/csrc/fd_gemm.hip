@@ -509,11 +509,14 @@ bool bx3_layout_ok(const FdGemmDesc& d) {
   return a_kc || (!a_kc && !b_kc);
 }
 
-// persistent blocks of the split kernel: one per CU (0 = fresh block per tile; FD_GEMM_NOPERSIST=1 or
-// fd_gemm_set_persistent_blocks)
+// persistent blocks of the split kernel: one per CU (0 = fresh block per tile; FD_GEMM_NOPERSIST=1,
+// FD_GEMM_PERSIST_BLOCKS=n or fd_gemm_set_persistent_blocks)
 int g_persist_blocks = -1;
 int persist_blocks() {
-  if (g_persist_blocks < 0) g_persist_blocks = getenv("FD_GEMM_NOPERSIST") ? 0 : 256;   // MI355X: 256 CUs
+  if (g_persist_blocks < 0) {
+    const char* e = getenv("FD_GEMM_PERSIST_BLOCKS");
+    g_persist_blocks = getenv("FD_GEMM_NOPERSIST") ? 0 : (e && atoi(e) >= 0 ? atoi(e) : 256);   // MI355X: 256 CUs
+  }
   return g_persist_blocks;
 }
 
