@@ -1,0 +1,155 @@
+"""TEST INFRASTRUCTURE -- golden fixtures at the sizes the product SHIPS at (BASELINE.json configs 2/3/5), generated
+from the UNMODIFIED reference (model/score_network.py:170-215, experiments/train_se3_diffusion.py:746-781):
+
+    fwd_n128_b2   full depth (4 blocks), B=2 x N=128: outputs + gradient signatures of all 282 parameters
+    fwd_n256_b1   full depth, B=1 x N=256: outputs + gradient signatures
+    fwd_n512_b1   full depth, B=1 x N=512: outputs (forward only, eval/no-grad and train mode)
+    traj_n128     5 reverse-diffusion steps of Experiment.inference_fn's loop at N=128, full depth, injected noise
+
+Run in the build container only (needs /root/reference):  python oracle/make_golden_full.py
+The oracle (oracle/framediff_oracle.py) is pinned against the same runs (PINNING_REPORT_FULL.txt).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_loader as rl  # noqa: E402
+from oracle import framediff_oracle as fo  # noqa: E402
+from oracle.make_golden import maxrel, quat_sign_align  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+CACHE = os.environ.get("FD_IGSO3_CACHE", "/tmp/fd_igso3_cache")
+OUT_KEYS = ["rot_score", "trans_score", "rigids", "atom37", "psi"]
+
+
+def main():
+    rl.install()
+    from data import se3_diffuser, utils as du  # reference modules
+    from model import score_network
+    from openfold.utils import rigid_utils as ru
+
+    torch.set_num_threads(int(os.environ.get("FD_GOLDEN_THREADS", "8")))
+    conf = rl.base_conf(CACHE)
+    diff = se3_diffuser.SE3Diffuser(conf.diffuser)
+    report = {}
+    cases = [
+        dict(name="fwd_n128_b2", B=2, N=128, seed=31, n_pad=3, n_fixed=2, blocks=4, grad=True),
+        dict(name="fwd_n256_b1", B=1, N=256, seed=32, n_pad=0, n_fixed=0, blocks=4, grad=True),
+        dict(name="fwd_n512_b1", B=1, N=512, seed=33, n_pad=0, n_fixed=0, blocks=4, grad=False),
+    ]
+    only = os.environ.get("FD_GOLDEN_ONLY")
+    for c in cases:
+        if only and c["name"] not in only.split(","):
+            continue
+        mconf = rl.base_conf(CACHE, num_blocks=c["blocks"]).model
+        oconf = dict(fo.CONF, num_blocks=c["blocks"])
+        model = score_network.ScoreNetwork(mconf, diff)
+        P = fo.synth_params(seed=c["seed"], conf=oconf)
+        model.load_state_dict(P, strict=True)
+        feats = fo.synth_feats(c["B"], c["N"], seed=c["seed"], n_pad=c["n_pad"], n_fixed=c["n_fixed"])
+        save = dict(B=c["B"], N=c["N"], seed=c["seed"], n_pad=c["n_pad"], n_fixed=c["n_fixed"], blocks=c["blocks"])
+        rep = {}
+        model.train()
+        t0 = time.time()
+        if c["grad"]:
+            out = model({k: v.clone() for k, v in feats.items()})
+            rs = np.random.RandomState(77 + c["seed"])
+            wts = {k: torch.tensor(rs.standard_normal(tuple(out[k].shape))).to(out[k].dtype) for k in OUT_KEYS}
+            loss = sum((out[k] * wts[k]).sum() for k in wts)
+            loss.backward()
+            rep["t_ref_s"] = time.time() - t0
+            grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+            Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+            t0 = time.time()
+            oo = fo.score_network_forward(Po, feats, oconf, tfmr_mask_mode="additive")
+            lo = sum((oo[k] * wts[k]).sum() for k in wts)
+            lo.backward()
+            rep["t_oracle_s"] = time.time() - t0
+            gerr = {}
+            for n, g in grads.items():
+                go = Po[n].grad
+                gerr[n] = float((go.double() - g.double()).abs().max() / (g.double().abs().max() + 1e-12)) if go is not None else 1.0
+            rep["grad_worst"] = sorted(gerr.items(), key=lambda kv: -kv[1])[:6]
+            rep["loss"] = (float(loss), float(lo))
+            save["w_seed"] = 77 + c["seed"]              # the loss weights are regenerated from the seed (RandomState stream)
+            save["loss"] = float(loss)
+            for n, g in grads.items():
+                if g.numel() <= 512:
+                    save["grad/" + n] = g.numpy()
+                else:
+                    save["gsig/" + n] = np.array([g.double().sum(), g.double().abs().sum(), g.double().norm()])
+        else:
+            with torch.enable_grad():
+                out = model({k: v.clone() for k, v in feats.items()})   # train mode + grad enabled: additive tfmr mask
+            rep["t_ref_s"] = time.time() - t0
+            with torch.no_grad():
+                oo = fo.score_network_forward(P, feats, oconf, tfmr_mask_mode="additive")
+        for k in ["psi", "rot_score", "trans_score", "atom37", "atom14"]:
+            rep[k] = maxrel(oo[k].detach(), out[k].detach())
+        rep["rigids"] = maxrel(quat_sign_align(oo["rigids"].detach(), out["rigids"].detach()), out["rigids"].detach())
+        for k, v in out.items():
+            a = v.detach().numpy()
+            if k in ("atom37", "atom14"):
+                a = a[:, :, :5]                                          # only the backbone slots are non-zero
+            save["out_" + k] = a
+        report[c["name"]] = rep
+        print(c["name"], {k: (v if not isinstance(v, float) else f"{v:.2e}") for k, v in rep.items()}, flush=True)
+        np.savez_compressed(os.path.join(GOLD, c["name"] + ".npz"), **save)
+
+    # ---------------- trajectory at N=128, full depth, injected noise ----------------
+    if not only or "traj_n128" in only.split(","):
+        tconf = rl.base_conf(CACHE, num_blocks=4).model
+        tmodel = score_network.ScoreNetwork(tconf, diff)
+        tmodel.load_state_dict(fo.synth_params(seed=41, conf=dict(fo.CONF, num_blocks=4)), strict=True)
+        tmodel.eval()
+        Bt, Nt, num_t, min_t, ns_ = 1, 128, 5, 0.01, 0.1
+        np.random.seed(4242)
+        zr = np.random.randn(Bt * Nt, 3); ur = np.random.rand(Bt * Nt); zt = np.random.normal(size=(Bt * Nt, 3))
+        np.random.seed(4242)
+        rig_init = diff.sample_ref(n_samples=Bt * Nt, as_tensor_7=True)["rigids_t"].reshape(Bt, Nt, 7)
+        feats_t = dict(res_mask=torch.ones(Bt, Nt), fixed_mask=torch.zeros(Bt, Nt),
+                       seq_idx=torch.arange(1, Nt + 1)[None].repeat(Bt, 1), torsion_angles_sin_cos=torch.zeros(Bt, Nt, 7, 2),
+                       sc_ca_t=torch.zeros(Bt, Nt, 3), rigids_t=rig_init.clone(), t=torch.ones(Bt))
+        steps = np.linspace(min_t, 1.0, num_t)[::-1]
+        noises, per_step = [], []
+        with torch.no_grad():
+            feats_t["t"] = steps[0] * torch.ones(Bt)
+            feats_t["sc_ca_t"] = tmodel(feats_t)["rigids"][..., 4:]
+            for t_ in steps:
+                if t_ > min_t:
+                    feats_t["t"] = t_ * torch.ones(Bt)
+                    mo = tmodel(feats_t)
+                    feats_t["sc_ca_t"] = mo["rigids"][..., 4:]
+                    st = np.random.get_state()
+                    z1 = np.random.normal(size=(Bt, Nt, 3)); z2 = np.random.normal(size=(Bt, Nt, 3))
+                    np.random.set_state(st)
+                    noises.append((z1, z2))
+                    rg = diff.reverse(rigid_t=ru.Rigid.from_tensor_7(feats_t["rigids_t"]), rot_score=du.move_to_np(mo["rot_score"]),
+                                      trans_score=du.move_to_np(mo["trans_score"]), diffuse_mask=np.ones((Bt, Nt)), t=t_,
+                                      dt=1 / num_t, center=True, noise_scale=ns_)
+                else:
+                    mo = tmodel(feats_t)
+                    rg = ru.Rigid.from_tensor_7(mo["rigids"])
+                feats_t["rigids_t"] = rg.to_tensor_7()
+                per_step.append(feats_t["rigids_t"].numpy().copy())
+        np.savez_compressed(os.path.join(GOLD, "traj_n128.npz"), B=Bt, N=Nt, num_t=num_t, min_t=min_t, noise_scale=ns_, seed=41,
+                            blocks=4, init_randn=zr, init_rand=ur, init_normal=zt, rig_init=rig_init.numpy(),
+                            z_rot=np.stack([n[0] for n in noises]), z_trans=np.stack([n[1] for n in noises]),
+                            final_rigids=feats_t["rigids_t"].numpy(), final_psi=mo["psi"].numpy(), step_rigids=np.stack(per_step))
+        print("trajectory golden (N=128) written", flush=True)
+
+    with open(os.path.join(GOLD, "PINNING_REPORT_FULL.txt"), "a" if only else "w") as f:
+        f.write("oracle/framediff_oracle.py vs the unmodified reference at shipped sizes (max |a-b| / max |b|)\n")
+        f.write(f"torch {torch.__version__} numpy {np.__version__}\n")
+        for k, v in report.items():
+            f.write(f"{k}: {v}\n")
+    print("wrote", GOLD)
+
+
+if __name__ == "__main__":
+    main()

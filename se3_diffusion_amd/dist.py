@@ -41,15 +41,35 @@ class FlatGrads:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        off = 0
+        self.offsets, off = [], 0
         for p in self.params:
+            self.offsets.append(off)
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
 
+    def rebind(self):
+        """p.grad must stay a view of the flat buffer: model.zero_grad() (set_to_none=True by default) or
+        module.to() replace it, after which autograd would fill fresh tensors and the all-reduce would ship zeros.
+        A stray gradient is added into its view, then the view is bound again."""
+        base = self.flat.data_ptr()
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None:
+                p.grad = self.flat[o:o + p.numel()].view_as(p)
+            elif p.grad.data_ptr() != base + 4 * o:
+                view = self.flat[o:o + p.numel()].view_as(p)
+                view.add_(p.grad.to(view.dtype))
+                p.grad = view
+
     def zero(self):
         self.flat.zero_()
+        base, end = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.flat.numel()
+        for p in self.params:
+            if p.grad is not None and not (base <= p.grad.data_ptr() < end):
+                p.grad = None
+        self.rebind()
 
     def all_reduce_mean(self):
+        self.rebind()
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())

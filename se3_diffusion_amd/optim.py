@@ -40,19 +40,43 @@ class FlatAdam:
             p.grad = self.flat_g[o:o + p.numel()].view_as(p)
         self.t = 0
 
+    def rebind(self):
+        """Make every p.data / p.grad a view of the flat buffers again.  Anything that replaces them behind the
+        optimiser's back -- model.zero_grad() (set_to_none=True by default), module.to() / _apply -- would otherwise
+        leave flat_g all-zero while autograd fills fresh tensors: the step would run on zeros without an error.
+        A stray gradient / parameter value is copied into its view first, so nothing is lost."""
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            if p.data.data_ptr() != self.flat_p.data_ptr() + 4 * o:
+                view = self.flat_p[o:o + n].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+            if p.grad is None:
+                p.grad = self.flat_g[o:o + n].view_as(p)
+            elif p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                view = self.flat_g[o:o + n].view_as(p)
+                view.add_(p.grad.to(view.dtype))
+                p.grad = view
+
     # -- gradient buffer (dist.FlatGrads interface) ------------------------------------------------------------
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
+        for p in self.params:          # a stray gradient (see rebind) is dropped with the rest
+            if p.grad is not None and not (self.flat_g.data_ptr() <= p.grad.data_ptr() < self.flat_g.data_ptr() + 4 * self.numel):
+                p.grad = None
+        self.rebind()
 
     zero = zero_grad
 
     def all_reduce_mean(self):
+        self.rebind()
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
             self.flat_g.div_(dist.get_world_size())
 
     # -- update ------------------------------------------------------------------------------------------------------
     def step(self):
+        self.rebind()
         self.t += 1
         b1, b2 = self.betas
         hip.get_lib().call("fd_adam_step", self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.numel,

@@ -80,9 +80,13 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
             z_rot.copy_(_f64(zr, dev))
             z_trans.copy_(_f64(zt, dev))
 
+    # reference quirk kept (train_se3_diffusion.py:753-756 vs :763-765): `self_condition` gates only the initial extra
+    # forward; the per-step sc_ca_t update depends on the MODEL's embed_self_conditioning flag alone
+    embed_sc = bool(getattr(getattr(getattr(model, "_model_conf", None), "embed", None), "embed_self_conditioning", True))
+
     def step_body():
         out = model(st)
-        if self_condition:
+        if embed_sc:
             st["sc_ca_t"].copy_(out["rigids"][..., 4:])
         psi.copy_(out["psi"])
         diffuser.reverse_device(st["rigids_t"], out["rot_score"], out["trans_score"], 0.5, dt, diffuse_mask=diffuse_mask,
@@ -90,47 +94,50 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
                                 out=new_rig)
         st["rigids_t"].copy_(new_rig)
 
-    traj = []
-    if self_condition:
-        set_t(steps[0])
-        st["sc_ca_t"].copy_(model(st)["rigids"][..., 4:])
-    graph = None
-    n_rev = int(np.sum(steps > min_t))
-    if use_graph and lib.is_device and n_rev > 3:
-        # warm up on a side stream (allocator, lazily-built constant tables), then capture one step
-        saved = {k: st[k].clone() for k in ("rigids_t", "sc_ca_t")}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+    try:
+        traj = []
+        if embed_sc and self_condition:
             set_t(steps[0])
-            for _ in range(2):
+            st["sc_ca_t"].copy_(model(st)["rigids"][..., 4:])
+        graph = None
+        n_rev = int(np.sum(steps > min_t))
+        if use_graph and lib.is_device and n_rev > 3:
+            # warm up on a side stream (allocator, lazily-built constant tables), then capture one step
+            saved = {k: st[k].clone() for k in ("rigids_t", "sc_ca_t")}
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                set_t(steps[0])
+                for _ in range(2):
+                    step_body()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
                 step_body()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step_body()
-        for k, v in saved.items():
-            st[k].copy_(v)
-    out = None
-    for i, t in enumerate(steps):
-        if t > min_t:
-            set_t(t)
-            draw(i)
-            if graph is not None:
-                graph.replay()
+            for k, v in saved.items():
+                st[k].copy_(v)
+        out = None
+        for i, t in enumerate(steps):
+            if t > min_t:
+                set_t(t)
+                draw(i)
+                if graph is not None:
+                    graph.replay()
+                else:
+                    step_body()
             else:
-                step_body()
-        else:
-            # reference quirk kept: the final forward still carries the previous step's t (train_se3_diffusion.py:778-779)
-            out = model(st)
-            st["rigids_t"].copy_(out["rigids"])
-            psi.copy_(out["psi"])
-        if return_traj:
-            traj.append(st["rigids_t"].clone())
-    del model._fd_static
-    if was_training:
-        model.train()
-    lib.gemm_profile = saved_prof
+                # reference quirk kept: the final forward still carries the previous step's t (train_se3_diffusion.py:778-779)
+                out = model(st)
+                st["rigids_t"].copy_(out["rigids"])
+                psi.copy_(out["psi"])
+            if return_traj:
+                traj.append(st["rigids_t"].clone())
+    finally:
+        # an exception mid-trajectory must not leave the weight-derived cache, eval mode or the profiling switch behind
+        model.__dict__.pop("_fd_static", None)
+        if was_training:
+            model.train()
+        lib.gemm_profile = saved_prof
     from . import train_step as ts
     atom37, _ = ts.backbone_atoms(st["rigids_t"], psi)
     res = dict(rigids=st["rigids_t"], atom37=atom37, psi=psi)

@@ -135,8 +135,11 @@ def head_const(conf_key=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), device=None):
     (so3_diffuser.py:293-299), uploaded once per device."""
     so3 = conf_key[6] if len(conf_key) > 6 else None
     cached = so3 is not None and device is not None
-    conf_key = tuple(conf_key[:6]) + ((id(so3), str(device)) if cached else ())
-    if conf_key not in _HC:
+    conf_key = tuple(conf_key[:6]) + ((str(device),) if cached else ())
+    # the table-carrying constants live ON the diffuser (a cache keyed by id(so3) could hand a new diffuser the stale
+    # device table of a garbage-collected one); the table-free ones are keyed by their six scalars
+    store = so3.__dict__.setdefault("_fd_head_const", {}) if cached else _HC
+    if conf_key not in store:
         cs, min_b, max_b, min_s, max_s, L = conf_key[:6]
         n = np.array([-0.525, 1.363, 0.000]); ca = np.zeros(3); c = np.array([1.526, -0.000, -0.000])
         cb = np.array([-0.529, -0.774, -1.205]); o = np.array([0.627, 1.062, 0.000])
@@ -163,8 +166,8 @@ def head_const(conf_key=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), device=None):
             assert tab.shape[1] == om.numel()
             hc.score_norms, hc.omega_grid, hc.n_omega = tab.data_ptr(), om.data_ptr(), om.numel()
             hc._tables = (tab, om)            # keeps the device buffers alive as long as the struct
-        _HC[conf_key] = hc
-    return _HC[conf_key]
+        store[conf_key] = hc
+    return store[conf_key]
 
 
 _SG = {}

@@ -63,3 +63,28 @@ def test_flat_adam_checkpoint_roundtrip_emu(use_emu):
 @pytest.mark.gpu
 def test_flat_adam_gpu(hip_lib):
     _run("cuda", steps=5)
+
+
+def test_flat_adam_survives_zero_grad_emu(use_emu):
+    """nn.Module.zero_grad() (set_to_none=True by default) and fresh autograd gradients between steps: FlatAdam
+    re-binds its views, so the step never runs on a stale all-zero flat buffer."""
+    ref = _params("cpu", 3)
+    mine = _params("cpu", 3)
+    topt = torch.optim.Adam(ref, lr=1e-2)
+    fopt = FlatAdam(mine, lr=1e-2)
+    g = torch.Generator().manual_seed(4)
+    for it in range(3):
+        grads = [torch.randn(*a.shape, generator=g) for a in ref]
+        for b in mine:
+            b.grad = None                          # what model.zero_grad() does
+        for a, b, gr in zip(ref, mine, grads):
+            a.grad = gr.clone()
+            b.grad = gr.clone()                    # what autograd does when .grad is None: a fresh tensor
+        topt.step()
+        fopt.step()
+        for b, o in zip(mine, fopt.offsets):       # bound to the flat buffer again
+            assert b.grad.data_ptr() == fopt.flat_g.data_ptr() + 4 * o
+        fopt.zero_grad()
+        assert float(fopt.flat_g.abs().max()) == 0.0
+    for a, b in zip(ref, mine):
+        assert (a.detach() - b.detach()).abs().max() < 2e-6 * (1 + a.detach().abs().max())

@@ -1,0 +1,207 @@
+"""Parity at the sizes the product ships at (BASELINE.json configs 2 / 3 / 5), gfx950 only (-m gpu).
+
+Two checkers, both at FULL depth (4 blocks):
+  * the oracle (oracle/framediff_oracle.py) run on the GPU box's host cores on the same seeded inputs -- outputs and all
+    282 parameter gradients at B=2 x N=128 and B=1 x N=256, outputs at B=1 x N=512;
+  * fixtures written by the UNMODIFIED reference in the build container (oracle/make_golden_full.py):
+    tests/golden/fwd_n128_b2.npz, fwd_n256_b1.npz (outputs + gradient signatures), fwd_n512_b1.npz (outputs),
+    traj_n128.npz (5 reverse steps of Experiment.inference_fn at N=128 with the reference's numpy draws injected).
+
+Every case runs three times: with the shipped GEMM selection, with the persistent split-bf16 kernel forced on
+(fd_gemm_set_persistent_blocks(8): the B=30 configuration's kernel at a size the oracle can check; at N=256 the
+M >= 65536 weight-gradient tiles 4/6 engage by themselves) and with FD_GEMM_EXACT_F32 (every GEMM a bitwise fp32
+fmaf chain).
+
+Tolerances (fp32, the table in DESIGN.md "Numerics"): outputs 2e-4 of the tensor's max magnitude (rot_score 1e-3),
+parameter gradients 2e-3 of the tensor's max magnitude + 2e-5 absolute (analytically-zero gradients).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import framediff_oracle as fo  # noqa: E402
+from se3_diffusion_amd import trunk  # noqa: E402
+from test_network import relerr, quat_align  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+OUT_KEYS = ["rot_score", "trans_score", "rigids", "atom37", "psi"]
+TOL_OUT, TOL_ROT, TOL_GRAD, ABS_GRAD = 2e-4, 1e-3, 2e-3, 2e-5
+MODES = ("shipped", "persistent", "exact_f32")
+
+
+class gemm_mode:
+    """shipped | persistent (8 persistent blocks: engages gemm_bx3p_kernel from 16 tiles up) | exact_f32"""
+
+    def __init__(self, lib, mode):
+        self.lib, self.mode = lib, mode
+
+    def __enter__(self):
+        c = self.lib.cdll
+        self.was_p = c.fd_gemm_set_persistent_blocks(8 if self.mode == "persistent" else 256)
+        self.was_e = c.fd_gemm_set_exact_f32(1 if self.mode == "exact_f32" else 0)
+
+    def __exit__(self, *a):
+        self.lib.cdll.fd_gemm_set_persistent_blocks(self.was_p)     # the setters return the previous value
+        self.lib.cdll.fd_gemm_set_exact_f32(self.was_e)
+
+
+def _check_outputs(out, ref):
+    errs = {}
+    for k in ["psi", "trans_score", "atom37", "atom14"]:
+        errs[k] = relerr(out[k], ref[k])
+        assert errs[k] < TOL_OUT, (k, errs)
+    errs["rot_score"] = relerr(out["rot_score"], ref["rot_score"])
+    assert errs["rot_score"] < TOL_ROT, errs
+    rr = torch.as_tensor(ref["rigids"]).detach()
+    errs["rigids"] = relerr(quat_align(out["rigids"].cpu(), rr), rr)
+    assert errs["rigids"] < TOL_OUT, errs
+    return errs
+
+
+_ORACLE = {}
+
+
+def _oracle(B, N, seed, n_pad, n_fixed, grad):
+    """oracle outputs (+ gradients of the fixed random projection) on the host, once per case"""
+    key = (B, N, seed, n_pad, n_fixed, grad)
+    if key not in _ORACLE:
+        conf = dict(fo.CONF, num_blocks=4)
+        P = fo.synth_params(seed=seed, conf=conf)
+        feats = fo.synth_feats(B, N, seed=seed, n_pad=n_pad, n_fixed=n_fixed)
+        torch.set_num_threads(min(32, os.cpu_count() or 8))
+        if grad:
+            Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+            ref = fo.score_network_forward(Po, feats, conf, tfmr_mask_mode="additive")
+            rs = np.random.RandomState(77 + seed)
+            wts = {k: torch.tensor(rs.standard_normal(tuple(ref[k].shape))).to(ref[k].dtype) for k in OUT_KEYS}
+            sum((ref[k] * wts[k]).sum() for k in wts).backward()
+            grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Po.items()}
+            ref = {k: v.detach() for k, v in ref.items()}
+        else:
+            with torch.no_grad():
+                ref = fo.score_network_forward(P, feats, conf, tfmr_mask_mode="additive")
+            wts, grads = None, None
+        _ORACLE[key] = (P, feats, ref, wts, grads)
+    return _ORACLE[key]
+
+
+def _run_vs_oracle(lib, mode, B, N, seed, n_pad=0, n_fixed=0, grad=True):
+    P, feats, ref, wts, grads = _oracle(B, N, seed, n_pad, n_fixed, grad)
+    Pd = {k: v.cuda() for k, v in P.items()}
+    fd = {k: v.cuda() for k, v in feats.items()}
+    with gemm_mode(lib, mode):
+        out, sv = trunk.forward(Pd, fd, 4, save=grad)
+        _check_outputs(out, ref)
+        if not grad:
+            return
+        G = {k: torch.zeros_like(v) for k, v in Pd.items()}
+        trunk.backward(Pd, G, sv, {k: v.cuda() for k, v in wts.items()})
+    bad = []
+    for k, g_ref in grads.items():
+        scale = float(g_ref.abs().max())
+        err = float((G[k].cpu().double() - g_ref.double()).abs().max())
+        if err > TOL_GRAD * scale + ABS_GRAD:
+            bad.append((k, err, scale))
+    assert not bad, (mode, bad[:10])
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_oracle_n128_b2_full_depth(hip_lib, mode):
+    """config 2's kernel selection at an oracle-checkable batch: forward + all 282 gradients"""
+    _run_vs_oracle(hip_lib, mode, B=2, N=128, seed=51, n_pad=4, n_fixed=3)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_oracle_n256_b1_full_depth(hip_lib, mode):
+    """config 3's size: forward + all gradients (M = 65536 pair rows: split-bf16 dW tiles 4 / 6 engage)"""
+    _run_vs_oracle(hip_lib, mode, B=1, N=256, seed=52)
+
+
+@pytest.mark.parametrize("mode", ("shipped", "exact_f32"))
+def test_oracle_n512_b1_forward(hip_lib, mode):
+    """config 5's length: forward"""
+    _run_vs_oracle(hip_lib, mode, B=1, N=512, seed=53, n_pad=9, grad=False)
+
+
+def _golden_full(lib, name, mode):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    B, N, seed = int(g["B"]), int(g["N"]), int(g["seed"])
+    conf = dict(fo.CONF, num_blocks=int(g["blocks"]))
+    P = {k: v.cuda() for k, v in fo.synth_params(seed=seed, conf=conf).items()}
+    feats = {k: v.cuda() for k, v in fo.synth_feats(B, N, seed=seed, n_pad=int(g["n_pad"]), n_fixed=int(g["n_fixed"])).items()}
+    has_grad = "w_seed" in g.files
+    with gemm_mode(lib, mode):
+        out, sv = trunk.forward(P, feats, int(g["blocks"]), save=has_grad)
+        ref = {k: torch.tensor(g["out_" + k]) for k in ["psi", "rot_score", "trans_score", "rigids"]}
+        got = dict(out)
+        for k in ("atom37", "atom14"):
+            ref[k] = torch.tensor(g["out_" + k])
+            got[k] = out[k][:, :, :5]
+            if k == "atom37":
+                assert float(out[k][:, :, 5:].abs().max()) == 0.0
+        _check_outputs(got, ref)
+        if not has_grad:
+            return
+        rs = np.random.RandomState(int(g["w_seed"]))
+        wts = {}
+        for k in OUT_KEYS:
+            shp = tuple(out[k].shape)
+            wts[k] = torch.tensor(rs.standard_normal(shp)).to(out[k].dtype).cuda()
+        G = {k: torch.zeros_like(v) for k, v in P.items()}
+        trunk.backward(P, G, sv, wts)
+    for key in g.files:
+        if key.startswith("grad/"):
+            n = key[5:]
+            r = torch.tensor(g[key])
+            err = float((G[n].cpu().double() - r.double()).abs().max())
+            assert err < TOL_GRAD * float(r.abs().max()) + ABS_GRAD, (n, err)
+        elif key.startswith("gsig/"):
+            n = key[5:]
+            s, a, l2 = g[key]
+            gg = G[n].cpu().double()
+            assert abs(float(gg.norm()) - l2) < TOL_GRAD * l2 + 1e-6, (n, float(gg.norm()), l2)
+            assert abs(float(gg.sum()) - s) < TOL_GRAD * a + 1e-6, n
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["fwd_n128_b2", "fwd_n256_b1"])
+def test_reference_golden_full_depth(hip_lib, name, mode):
+    """outputs + gradient signatures of the unmodified reference at N=128 (B=2) and N=256"""
+    _golden_full(hip_lib, name, mode)
+
+
+def test_reference_golden_n512(hip_lib):
+    _golden_full(hip_lib, "fwd_n512_b1", "shipped")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_reference_trajectory_n128(hip_lib, use_graph):
+    """5 reverse steps of the reference's inference loop at N=128, full depth, reference noise injected
+    (experiments/train_se3_diffusion.py:746-781)"""
+    from se3_diffusion_amd import sampler, train_step as ts
+    from se3_diffusion_amd.data import se3_diffuser, utils as du
+    from se3_diffusion_amd.model.score_network import ScoreNetwork
+    from test_diffuser import conf as dconf
+    T = np.load(os.path.join(GOLD, "traj_n128.npz"))
+    diff = se3_diffuser.SE3Diffuser(dconf())
+    blocks = int(T["blocks"])
+    m = ScoreNetwork(ts.base_model_conf(blocks), diff)
+    m.load_state_dict(fo.synth_params(seed=int(T["seed"]), conf=dict(fo.CONF, num_blocks=blocks)), strict=True)
+    m = m.cuda().eval()
+    B, N = int(T["B"]), int(T["N"])
+    feats = sampler.init_feats(diff, B, N, "cuda", noise=(T["init_randn"], T["init_rand"], T["init_normal"]))
+    zr, zt = T["z_rot"], T["z_trans"]
+    out = sampler.sample(m, diff, feats, num_t=int(T["num_t"]), min_t=float(T["min_t"]), noise_scale=float(T["noise_scale"]),
+                         noise_fn=lambda i, shp: (zr[i], zt[i]), return_traj=True, use_graph=use_graph)
+    rm = lambda q: du.quat_wxyz_to_matrix(np.asarray(q)[..., :4].astype(np.float64))
+    for i, (got, ref) in enumerate(zip(out["rigid_traj"], T["step_rigids"])):
+        got = got.cpu().numpy()
+        assert np.abs(rm(got) - rm(ref)).max() < 1e-3, i
+        assert np.abs(got[..., 4:] - ref[..., 4:]).max() < 1e-2, i          # Angstrom (coordinates of +-30 A)
+    assert np.abs(out["psi"].cpu().numpy() - T["final_psi"]).max() < 2e-3
