@@ -102,6 +102,48 @@ int fd_axpby(float* y, const float* x, float a, float b, long n, void* stream);
 int fd_add2d(float* dst, long ldd, const float* src, long lds, long rows, int cols, float a, void* stream);
 int fd_rowscale(const float* x, long ldx, const float* rs, float* y, long ldy, long rows, int C, void* stream);
 
+/* ---- edge transition, fused (model/ipa_pytorch.py:194-233 EdgeTransition.forward :218-233 and its autograd) ----
+ * One kernel per direction for the whole 128 -> 384 -> 384 -> 128 chain of a pair row (se3_diffusion_amd/csrc/
+ * fd_edge_mlp.hip): the hidden activations stay in the registers of the wave that owns the row, the weights stream
+ * through LDS from a pre-packed bf16-plane image (fd_edge_mlp_pack, once per optimiser step, FD_EDGE_MLP_IMAGE_BYTES).
+ * Split-bf16 arithmetic (fp32-accurate, as fd_gemm tile 4).
+ *   forward : h1 = relu(A1 x + p1[b,i] + q1[b,j]); h2 = relu(A2 h1 + bias2); y = A3 x + A4 h2 + pf[b,i] + qf[b,j];
+ *             out = rowscale * LayerNorm(y; gamma, beta, eps).  Optional saves for the backward: save1 = h1, save2 = h2,
+ *             y, mean, rstd.
+ *   backward: x = dy; d2 = [gate1 > 0] (A1 x); d1 = [gate2 > 0] (A2 d2); out = A3 x + A4 d1, with the image packed
+ *             from the TRANSPOSED weights (A1 = Wf^T, A2 = W2^T, A3 = Wfz^T, A4 = W1z^T; gate1 = h2, gate2 = h1);
+ *             save1 = d2, save2 = d1 (operands of the weight-gradient GEMMs).
+ * A1 [384,128], A2 [384,384], A3 [128,128], A4 [128,384] are given as (pointer, row stride, column stride). */
+#define FD_EDGE_MLP_IMAGE_BYTES (128 * 12288)
+int fd_edge_mlp_pack(const float* A1, long rs1, long cs1, const float* A2, long rs2, long cs2, const float* A3,
+                     long rs3, long cs3, const float* A4, long rs4, long cs4, void* image, void* stream);
+typedef struct FdEdgeMlpDesc {
+  const float* x;        /* [rows,128] */
+  const void* img;       /* weight image of fd_edge_mlp_pack */
+  const float* p1;       /* forward: [B*nres,384] term of residue i */
+  const float* q1;       /* forward: [B*nres,384] term of residue j (carries the layer-1 bias) */
+  const float* bias2;    /* forward: [384] */
+  const float* gate1;    /* backward: [rows,384] h2 */
+  const float* gate2;    /* backward: [rows,384] h1 */
+  float* save1;          /* optional [rows,384] */
+  float* save2;          /* optional [rows,384] */
+  const float* pf;       /* forward: [B*nres,128] */
+  const float* qf;       /* forward: [B*nres,128] (carries the final bias) */
+  const float* gamma;    /* forward: LayerNorm weight [128] */
+  const float* beta;     /* forward: LayerNorm bias [128] */
+  const float* rowscale; /* forward, optional: [rows] pair mask */
+  float* y;              /* forward, optional: [rows,128] pre-LayerNorm values */
+  float* mean;           /* forward, optional: [rows] */
+  float* rstd;           /* forward, optional: [rows] */
+  float* out;            /* [rows,128] */
+  long rows;             /* B * nres * nres */
+  int nres;
+  int backward;
+  float eps;
+  int blocks;            /* 0 = one persistent block per CU (256) */
+} FdEdgeMlpDesc;
+int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream);
+
 /* ---- embedder features: score_network.py:14-47,97-148; data/utils.py:570-580 ----
  * tscaled = (t*1e4) as fp32 [B]; tfreq[16], idenom[16], dg_lower[22], dg_upper[22] are the
  * host-computed tables of the reference's own op sequence. */

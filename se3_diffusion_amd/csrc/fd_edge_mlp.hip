@@ -1,0 +1,407 @@
+// Edge transition (model/ipa_pytorch.py:194-233) as ONE kernel per direction: the 128 -> 384 -> 384 -> 128 chain of a
+// pair row never leaves the CU.
+//
+//   forward :  h1 = relu(W1z z + P1_i + Q1_j)      h2 = relu(W2 h1 + b2)      y = Wf h2 + Wfz z + Pf_i + Qf_j
+//              z' = mask * LayerNorm(y)                          (P/Q: the node halves of W [z | e_i | e_j], trunk.py)
+//   backward:  d2 = [h2 > 0] Wf^T dy               d1 = [h1 > 0] W2^T d2      dz = Wfz^T dy + W1z^T d1
+//              (the same dataflow with transposed weights and ReLU gates instead of bias + ReLU)
+//
+// Arithmetic: the split-bf16 scheme of fd_gemm_split.h -- every fp32 operand is three exact bf16 terms, six
+// v_mfma_f32_32x32x16_bf16 products per 16-k step, fp32 accumulation: fp32-accurate (not bitwise an fmaf chain).
+//
+// Register-chained layout.  A wave owns 32 pair rows for the whole chain and accumulates TRANSPOSED
+// (D[n][m] = sum_k W[n][k] x[m][k]: the weights are the MFMA's row operand), so lane (m = l & 31, h = l >> 5) ends up
+// with 16 hidden units n = 32 nb + 8 q + 4 h + e of ITS OWN row per 32-unit block.  Those registers are exactly a
+// B-operand fragment of the next GEMM if the next layer's weights are stored with the k order permuted to match
+// (slot (h, e') <-> k = 8 (e' >> 2) + 4 h + (e' & 3) inside a 16-k step): activations go accumulator -> relu ->
+// bf16 split -> MFMA operand without touching LDS, without a barrier, without leaving the wave.  LDS only streams
+// the weights, which are packed ONCE per optimiser step (fd_edge_mlp_pack) into bf16-plane fragments in the exact
+// order the kernel consumes them, so staging is a straight LDS-DMA copy (global_load_lds_dwordx4, no VGPRs, no VALU)
+// and every fragment read is a conflict-free ds_read_b128 of a lane-linear 1 KB piece.
+//
+// Block = 4 waves (one per SIMD, up to 512 registers each: the 32 x 384 fp32 accumulator of layer 2 alone is 192) x
+// 32 rows = 128-row tiles, persistent (one block per CU walks the tiles).  Per tile the weight stream is 128 units of
+// 12 KB (4 n-blocks x one 16-k step x 3 planes), grouped in 32 stages of 48 KB through a two-stage LDS ring; stage s+1
+// is in flight while stage s (96 MFMAs per wave, ~3k cycles) is multiplied:
+//     for c in 0..2:   8 units  W1z[n in chunk c]        (layer 1, K = 128)      -> h1 chunk c (64 registers)
+//                     24 units  W2[all n][k in chunk c]  (layer 2, partial K)    -> acc2 += ...
+//     8 units Wfz, 24 units Wf                           (layer 3, K = 128 + 384)
+// Algorithmic HBM bytes per pair row: 512 read + 512 written (+ h1, h2, y saved for the backward in training).
+#include "fd_common.h"
+#include "../../include/fd_hip.h"
+
+namespace {
+
+constexpr int EM_ROWS = 128;               // rows per block tile (4 waves x 32)
+constexpr int EM_PIECE = 1024;             // one fragment: 64 lanes x 16 B
+constexpr int EM_UNIT = 12 * EM_PIECE;     // 4 n-blocks x 3 planes
+constexpr int EM_UPS = 4;                  // units per stage
+constexpr int EM_STAGE = EM_UPS * EM_UNIT; // 48 KB
+constexpr int EM_UNITS = 128;              // units per tile
+constexpr int EM_NSTAGE = EM_UNITS / EM_UPS;
+constexpr int EM_H = 384, EM_C = 128;
+
+__device__ __forceinline__ void em_split8(const float (&x)[8], uint4& s0, uint4& s1, uint4& s2) {
+  unsigned t0[4], t1[4], t2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float u = x[2 * j], v = x[2 * j + 1];
+    const unsigned hh = fd::pack_bf16(u, v);
+    const float ru = u - fd::bf16lo_f32(hh), rv = v - fd::bf16hi_f32(hh);
+    const unsigned mm = fd::pack_bf16(ru, rv);
+    const float qu = ru - fd::bf16lo_f32(mm), qv = rv - fd::bf16hi_f32(mm);
+    t0[j] = hh;
+    t1[j] = mm;
+    t2[j] = fd::pack_bf16(qu, qv);
+  }
+  s0 = make_uint4(t0[0], t0[1], t0[2], t0[3]);
+  s1 = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+  s2 = make_uint4(t2[0], t2[1], t2[2], t2[3]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight image: 128 units in consumption order; a unit = [4 n-blocks][3 planes][64 lanes] x 16 B, the fragment of lane
+// (l31 = n, h) holding slots e' = 0..7 of a 16-k step.  natural k order (operand loaded from memory):
+// k = k0 + 8 h + e'; chained k order (operand = the previous layer's accumulator): k = k0 + 8 (e' >> 2) + 4 h + (e' & 3).
+struct EmMat {
+  const float* p;
+  long rs, cs;
+};
+
+__global__ __launch_bounds__(256) void edge_mlp_pack_kernel(EmMat A1, EmMat A2, EmMat A3, EmMat A4, char* __restrict__ img) {
+  const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x);   // (unit, n-block, lane)
+  if (gid >= EM_UNITS * 4 * 64) return;
+  const int lane = gid & 63, i = (gid >> 6) & 3, u = gid >> 8;
+  const int l31 = lane & 31, h = lane >> 5;
+  EmMat M;
+  int n, k0;
+  bool chained;
+  if (u < 96) {
+    const int c = u / 32, r = u % 32;
+    if (r < 8) {                    // layer 1: rows of chunk c, k-step r
+      M = A1; n = 128 * c + 32 * i + l31; k0 = 16 * r; chained = false;
+    } else {                        // layer 2: all rows (group g), k-step ks of chunk c
+      const int r2 = r - 8, ks = r2 / 3, g = r2 % 3;
+      M = A2; n = 32 * (4 * g + i) + l31; k0 = 128 * c + 16 * ks; chained = true;
+    }
+  } else if (u < 104) {             // layer 3, x part
+    M = A3; n = 32 * i + l31; k0 = 16 * (u - 96); chained = false;
+  } else {                          // layer 3, hidden part
+    M = A4; n = 32 * i + l31; k0 = 16 * (u - 104); chained = true;
+  }
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = chained ? k0 + 8 * (e >> 2) + 4 * h + (e & 3) : k0 + 8 * h + e;
+    x[e] = M.p[(long)n * M.rs + (long)k * M.cs];
+  }
+  uint4 s0, s1, s2;
+  em_split8(x, s0, s1, s2);
+  char* dst = img + (long)u * EM_UNIT + (i * 3) * EM_PIECE + lane * 16;
+  *reinterpret_cast<uint4*>(dst) = s0;
+  *reinterpret_cast<uint4*>(dst + EM_PIECE) = s1;
+  *reinterpret_cast<uint4*>(dst + 2 * EM_PIECE) = s2;
+}
+
+// one unit: 4 n-blocks x one 16-k step.  u = LDS address of the unit + 16 * lane; b = the activation planes.
+__device__ __forceinline__ void em_unit(f32x16& a0, f32x16& a1, f32x16& a2, f32x16& a3, const uint4 (&b)[3],
+                                        const char* __restrict__ u) {
+  // products (weight plane, activation plane) with i + j <= 2, smallest first
+  constexpr int PW[6] = {2, 1, 0, 1, 0, 0};
+  constexpr int PX[6] = {0, 1, 2, 0, 1, 0};
+  uint4 w[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) w[i][s] = *reinterpret_cast<const uint4*>(u + (i * 3 + s) * EM_PIECE);
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+    a0 = fd::mfma_32x32x16_bf16(w[0][PW[p]], b[PX[p]], a0);
+    a1 = fd::mfma_32x32x16_bf16(w[1][PW[p]], b[PX[p]], a1);
+    a2 = fd::mfma_32x32x16_bf16(w[2][PW[p]], b[PX[p]], a2);
+    a3 = fd::mfma_32x32x16_bf16(w[3][PW[p]], b[PX[p]], a3);
+  }
+}
+
+__device__ __forceinline__ void em_zero(f32x16& a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256, 1) void edge_mlp_kernel(FdEdgeMlpDesc d) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * EM_STAGE];
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const long rows = d.rows;
+  const int ntiles = (int)((rows + EM_ROWS - 1) / EM_ROWS);
+  const int G = (int)gridDim.x, first = (int)blockIdx.x;
+  if (first >= ntiles) return;
+  const int nmine = (ntiles - first + G - 1) / G;
+  const int total_stages = nmine * EM_NSTAGE;
+
+  // ---- weight stream: every wave copies a quarter (12 pieces) of each stage ----
+  const char* __restrict__ img_lane = static_cast<const char*>(d.img) + wave * (EM_STAGE / 4) + lane * 16;
+  char* const lds_wave = lds + wave * (EM_STAGE / 4);
+  int issued = 0;      // stages whose copy has been issued
+  int consumed = 0;    // stages whose multiplication has begun
+  auto issue_stage = [&]() {
+    const char* src = img_lane + (long)(issued % EM_NSTAGE) * EM_STAGE;
+    char* dst = lds_wave + (issued & 1) * EM_STAGE;
+#pragma unroll
+    for (int p = 0; p < EM_STAGE / 4 / EM_PIECE; ++p) fd::glds16(src + p * EM_PIECE, dst + p * EM_PIECE);
+    ++issued;
+  };
+  // begin stage `consumed`: its copy (issued one stage ago) has landed and is visible to the block; every wave is done
+  // with the previous stage, so the other buffer takes the next copy.  Returns the stage's LDS address + 16 * lane.
+  auto stage_begin = [&]() -> const char* {
+    __syncthreads();
+    if (issued < total_stages) issue_stage();
+    const char* cur = lds + (consumed & 1) * EM_STAGE + lane * 16;
+    ++consumed;
+    return cur;
+  };
+  issue_stage();
+
+  for (int ti = 0; ti < nmine; ++ti) {
+    const long row0 = ((long)first + (long)ti * G) * EM_ROWS + wave * 32;
+    const long row = row0 + l31;
+    const bool rok = row < rows;
+    const long rc = rok ? row : rows - 1;         // rows past the end are clamped on load, masked on store
+    const long qi = rc / d.nres;                  // (b, i)
+    const long qj = (qi / d.nres) * d.nres + (rc - qi * d.nres);   // (b, j)
+
+    // x in B-operand layout: k = 16 ks + 8 h + e
+    float xr[8][8];
+    {
+      const float* xp = d.x + rc * EM_C + 8 * h;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const float4 v = *reinterpret_cast<const float4*>(xp + 16 * ks);
+        const float4 w = *reinterpret_cast<const float4*>(xp + 16 * ks + 4);
+        xr[ks][0] = v.x; xr[ks][1] = v.y; xr[ks][2] = v.z; xr[ks][3] = v.w;
+        xr[ks][4] = w.x; xr[ks][5] = w.y; xr[ks][6] = w.z; xr[ks][7] = w.w;
+      }
+    }
+
+    f32x16 acc2[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) em_zero(acc2[i]);
+
+    for (int c = 0; c < 3; ++c) {
+      // ---- layer 1, chunk c: 128 hidden units x K = 128 ----
+      f32x16 acc1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) em_zero(acc1[i]);
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg) {
+        const char* st = stage_begin();
+#pragma unroll
+        for (int uu = 0; uu < EM_UPS; ++uu) {
+          uint4 b[3];
+          em_split8(xr[4 * sg + uu], b[0], b[1], b[2]);
+          em_unit(acc1[0], acc1[1], acc1[2], acc1[3], b, st + uu * EM_UNIT);
+        }
+      }
+      // epilogue 1: forward  h1 = relu(acc + P1_i + Q1_j);  backward  d2 = acc gated by h2 > 0
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 128 * c + 32 * nb + 8 * q + 4 * h;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc1[nb][4 * q + e];
+          if (!BWD) {
+            const float4 a = *reinterpret_cast<const float4*>(d.p1 + qi * EM_H + col);
+            const float4 bq = *reinterpret_cast<const float4*>(d.q1 + qj * EM_H + col);
+            v[0] += a.x + bq.x; v[1] += a.y + bq.y; v[2] += a.z + bq.z; v[3] += a.w + bq.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          } else {
+            const float4 g = *reinterpret_cast<const float4*>(d.gate1 + rc * EM_H + col);
+            v[0] = g.x > 0.f ? v[0] : 0.f; v[1] = g.y > 0.f ? v[1] : 0.f;
+            v[2] = g.z > 0.f ? v[2] : 0.f; v[3] = g.w > 0.f ? v[3] : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc1[nb][4 * q + e] = v[e];
+          if (d.save1 != nullptr && rok)
+            *reinterpret_cast<float4*>(d.save1 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      // ---- layer 2, k in chunk c: 24 units (k-step ks, row group g) = 6 stages ----
+#pragma unroll
+      for (int sg = 0; sg < 6; ++sg) {
+        const char* st = stage_begin();
+        uint4 b[3];
+#pragma unroll
+        for (int uu = 0; uu < EM_UPS; ++uu) {
+          const int u2 = 4 * sg + uu, ks = u2 / 3, g = u2 % 3;
+          if (g == 0 || uu == 0) {
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = acc1[ks >> 1][8 * (ks & 1) + e];
+            em_split8(t, b[0], b[1], b[2]);
+          }
+          em_unit(acc2[4 * g + 0], acc2[4 * g + 1], acc2[4 * g + 2], acc2[4 * g + 3], b, st + uu * EM_UNIT);
+        }
+      }
+    }
+
+    // epilogue 2: forward  h2 = relu(acc2 + b2);  backward  d1 = acc2 gated by h1 > 0
+#pragma unroll
+    for (int nb = 0; nb < 12; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = 32 * nb + 8 * q + 4 * h;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc2[nb][4 * q + e];
+        if (!BWD) {
+          const float4 a = *reinterpret_cast<const float4*>(d.bias2 + col);
+          v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        } else {
+          const float4 g = *reinterpret_cast<const float4*>(d.gate2 + rc * EM_H + col);
+          v[0] = g.x > 0.f ? v[0] : 0.f; v[1] = g.y > 0.f ? v[1] : 0.f;
+          v[2] = g.z > 0.f ? v[2] : 0.f; v[3] = g.w > 0.f ? v[3] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc2[nb][4 * q + e] = v[e];
+        if (d.save2 != nullptr && rok)
+          *reinterpret_cast<float4*>(d.save2 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+
+    // ---- layer 3: 128 outputs x (K = 128 of x, then K = 384 of the hidden layer) ----
+    f32x16 acc3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) em_zero(acc3[i]);
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const char* st = stage_begin();
+#pragma unroll
+      for (int uu = 0; uu < EM_UPS; ++uu) {
+        uint4 b[3];
+        em_split8(xr[4 * sg + uu], b[0], b[1], b[2]);
+        em_unit(acc3[0], acc3[1], acc3[2], acc3[3], b, st + uu * EM_UNIT);
+      }
+    }
+#pragma unroll
+    for (int sg = 0; sg < 6; ++sg) {
+      const char* st = stage_begin();
+#pragma unroll
+      for (int uu = 0; uu < EM_UPS; ++uu) {
+        const int v = 4 * sg + uu, kb = v >> 1, t2 = v & 1;
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = acc2[kb][8 * t2 + e];
+        uint4 b[3];
+        em_split8(t, b[0], b[1], b[2]);
+        em_unit(acc3[0], acc3[1], acc3[2], acc3[3], b, st + uu * EM_UNIT);
+      }
+    }
+
+    // ---- final epilogue ----
+    if (!BWD) {
+      // y = acc + Pf_i + Qf_j ; z' = rowscale * LayerNorm(y).  A row's 128 values sit in two lanes (l, l ^ 32).
+      float s = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 32 * nb + 8 * q + 4 * h;
+          const float4 a = *reinterpret_cast<const float4*>(d.pf + qi * EM_C + col);
+          const float4 bq = *reinterpret_cast<const float4*>(d.qf + qj * EM_C + col);
+          acc3[nb][4 * q + 0] += a.x + bq.x; acc3[nb][4 * q + 1] += a.y + bq.y;
+          acc3[nb][4 * q + 2] += a.z + bq.z; acc3[nb][4 * q + 3] += a.w + bq.w;
+          s += (acc3[nb][4 * q + 0] + acc3[nb][4 * q + 1]) + (acc3[nb][4 * q + 2] + acc3[nb][4 * q + 3]);
+          if (d.y != nullptr && rok)
+            *reinterpret_cast<float4*>(d.y + row * EM_C + col) =
+                make_float4(acc3[nb][4 * q + 0], acc3[nb][4 * q + 1], acc3[nb][4 * q + 2], acc3[nb][4 * q + 3]);
+        }
+      s += __shfl_xor(s, 32);
+      const float mean = s * (1.0f / 128.0f);
+      float vs = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dlt = acc3[nb][r] - mean;
+          acc3[nb][r] = dlt;
+          vs += dlt * dlt;
+        }
+      vs += __shfl_xor(vs, 32);
+      const float rstd = 1.0f / sqrtf(vs * (1.0f / 128.0f) + d.eps);
+      const float rs = d.rowscale != nullptr ? d.rowscale[rc] : 1.f;
+      if (rok && h == 0) {
+        if (d.mean != nullptr) d.mean[row] = mean;
+        if (d.rstd != nullptr) d.rstd[row] = rstd;
+      }
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 32 * nb + 8 * q + 4 * h;
+          const float4 gm = *reinterpret_cast<const float4*>(d.gamma + col);
+          const float4 bt = *reinterpret_cast<const float4*>(d.beta + col);
+          float4 o;
+          o.x = (acc3[nb][4 * q + 0] * rstd * gm.x + bt.x) * rs;
+          o.y = (acc3[nb][4 * q + 1] * rstd * gm.y + bt.y) * rs;
+          o.z = (acc3[nb][4 * q + 2] * rstd * gm.z + bt.z) * rs;
+          o.w = (acc3[nb][4 * q + 3] * rstd * gm.w + bt.w) * rs;
+          if (rok) *reinterpret_cast<float4*>(d.out + row * EM_C + col) = o;
+        }
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 32 * nb + 8 * q + 4 * h;
+          if (rok)
+            *reinterpret_cast<float4*>(d.out + row * EM_C + col) =
+                make_float4(acc3[nb][4 * q + 0], acc3[nb][4 * q + 1], acc3[nb][4 * q + 2], acc3[nb][4 * q + 3]);
+        }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int fd_edge_mlp_pack(const float* A1, long rs1, long cs1, const float* A2, long rs2, long cs2,
+                                const float* A3, long rs3, long cs3, const float* A4, long rs4, long cs4, void* img,
+                                void* stream) {
+  FD_CHECK_ARG(A1 && A2 && A3 && A4 && img, "fd_edge_mlp_pack: null operand");
+  FD_CHECK_ARG(fd_aligned16(img), "fd_edge_mlp_pack: image must be 16-byte aligned");
+  EmMat m1{A1, rs1, cs1}, m2{A2, rs2, cs2}, m3{A3, rs3, cs3}, m4{A4, rs4, cs4};
+  hipLaunchKernelGGL(edge_mlp_pack_kernel, dim3(EM_UNITS * 4 * 64 / 256), dim3(256), 0, (hipStream_t)stream, m1, m2, m3,
+                     m4, static_cast<char*>(img));
+  FD_CHECK_LAUNCH("fd_edge_mlp_pack");
+  return FD_OK;
+}
+
+extern "C" int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream) {
+  FD_CHECK_ARG(desc != nullptr, "fd_edge_mlp: null descriptor");
+  const FdEdgeMlpDesc& d = *desc;
+  FD_CHECK_ARG(d.x && d.img && d.out, "fd_edge_mlp: x / img / out are required");
+  FD_CHECK_ARG(d.nres > 0 && d.rows >= 0, "fd_edge_mlp: bad extents");
+  if (d.backward) {
+    FD_CHECK_ARG(d.gate1 && d.gate2, "fd_edge_mlp(backward): the saved activations h2 (gate1) and h1 (gate2) are required");
+  } else {
+    FD_CHECK_ARG(d.p1 && d.q1 && d.bias2 && d.pf && d.qf && d.gamma && d.beta,
+                 "fd_edge_mlp(forward): p1 / q1 / bias2 / pf / qf / gamma / beta are required");
+  }
+  const void* ptrs[] = {d.x, d.img, d.out, d.p1, d.q1, d.bias2, d.gate1, d.gate2, d.save1, d.save2, d.pf, d.qf,
+                        d.gamma, d.beta, d.y};
+  for (const void* p : ptrs) FD_CHECK_ARG(fd_aligned16(p), "fd_edge_mlp: operands must be 16-byte aligned");
+  if (d.rows == 0) return FD_OK;
+  const long ntiles = (d.rows + EM_ROWS - 1) / EM_ROWS;
+  const int blocks = d.blocks > 0 ? d.blocks : 256;   // MI355X: one persistent block per CU
+  const int grid = (int)(ntiles < blocks ? ntiles : blocks);
+  if (d.backward)
+    hipLaunchKernelGGL(edge_mlp_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d);
+  else
+    hipLaunchKernelGGL(edge_mlp_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d);
+  FD_CHECK_LAUNCH("fd_edge_mlp");
+  return FD_OK;
+}

@@ -37,6 +37,14 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 __device__ __forceinline__ float bf16lo_f32(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf16hi_f32(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 
+// LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane straight from global memory into LDS, no VGPR round trip.
+// The LDS destination is WAVE-UNIFORM base + lane * 16 (not a per-lane scatter); the source address is per lane.
+// Completion is tracked by vmcnt like any load: __syncthreads() (vmcnt(0) + barrier) publishes it to the block.
+__device__ __forceinline__ void glds16(const void* g_lane, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 // s_setprio 3: this wave wins instruction arbitration on its SIMD
 __device__ __forceinline__ void raise_wave_priority() { __builtin_amdgcn_s_setprio(3); }
 

@@ -75,6 +75,19 @@ class FdLossDesc(Structure):
     ]
 
 
+class FdEdgeMlpDesc(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("img", c_void_p), ("p1", c_void_p), ("q1", c_void_p), ("bias2", c_void_p),
+        ("gate1", c_void_p), ("gate2", c_void_p), ("save1", c_void_p), ("save2", c_void_p),
+        ("pf", c_void_p), ("qf", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("rowscale", c_void_p),
+        ("y", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("out", c_void_p),
+        ("rows", c_long), ("nres", c_int), ("backward", c_int), ("eps", c_float), ("blocks", c_int),
+    ]
+
+
+EDGE_MLP_IMAGE_BYTES = 128 * 12288
+
+
 def _ptr(t, off=0):
     """Raw address of a tensor (plus an element offset)."""
     if t is None:
@@ -91,6 +104,8 @@ _SIGS = {
     "fd_gemm_plan": "S",
     "fd_gemm_set_exact_f32": "i",
     "fd_gemm_set_persistent_blocks": "i",
+    "fd_edge_mlp_pack": "pllpllpllpllps",
+    "fd_edge_mlp": "Ss",
     "fd_layernorm_fwd": "plpppplpplifs",
     "fd_layernorm_bwd": "plplpppppl" + "ipplis",
     "fd_colsum_acc": "pllips",

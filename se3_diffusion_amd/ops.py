@@ -185,3 +185,36 @@ def feature_tables(device, index_embed_size=32, num_bins=22, min_bin=1e-5, max_b
         upper = torch.cat([lower[1:], lower.new_tensor([1e8])])
         _TABLES[key] = tuple(t.contiguous().to(device) for t in (tfreq, idenom, lower, upper))
     return _TABLES[key]
+
+
+# ---------------------------------------------------------------------------
+# fused edge transition (csrc/fd_edge_mlp.hip)
+# ---------------------------------------------------------------------------
+def edge_mlp_pack(W1, W2, Wf, backward=False, out=None):
+    """Pack the edge-transition weights (trunk.0 [384,384], trunk.2 [384,384], final_layer [128,384]) into the bf16-plane
+    image fd_edge_mlp streams.  backward=True packs the transposes (dX chain)."""
+    img = out if out is not None else torch.empty(hip.EDGE_MLP_IMAGE_BYTES, dtype=torch.uint8, device=W1.device)
+    ld = 384
+    if not backward:
+        # A1 = W1[:, :128], A2 = W2, A3 = Wf[:, :128], A4 = Wf
+        lib().call("fd_edge_mlp_pack", W1, ld, 1, W2, ld, 1, Wf, ld, 1, Wf, ld, 1, img)
+    else:
+        # A1 = Wf^T [384,128], A2 = W2^T, A3 = Wf[:, :128]^T, A4 = W1[:, :128]^T [128,384]
+        lib().call("fd_edge_mlp_pack", Wf, 1, ld, W2, 1, ld, Wf, 1, ld, W1, 1, ld, img)
+    return img
+
+
+def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, qf=None, gamma=None, beta=None,
+             rowscale=None, gate1=None, gate2=None, save1=None, save2=None, y=None, mean=None, rstd=None,
+             backward=False, blocks=0):
+    d = hip.FdEdgeMlpDesc()
+    tens = []
+    for name, t in (("x", x), ("img", img), ("p1", p1), ("q1", q1), ("bias2", bias2), ("gate1", gate1), ("gate2", gate2),
+                    ("save1", save1), ("save2", save2), ("pf", pf), ("qf", qf), ("gamma", gamma), ("beta", beta),
+                    ("rowscale", rowscale), ("y", y), ("mean", mean), ("rstd", rstd), ("out", out)):
+        setattr(d, name, None if t is None else t.data_ptr())
+        if t is not None:
+            tens.append(t)
+    d.rows, d.nres, d.backward, d.eps, d.blocks = int(rows), int(nres), int(bool(backward)), 1e-5, int(blocks)
+    L = lib()
+    L._check(L.cdll.fd_edge_mlp(hip.ctypes.byref(d), L._stream(tens)), "fd_edge_mlp")

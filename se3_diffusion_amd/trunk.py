@@ -3,6 +3,7 @@ whole-network forward / backward drivers.  See network.py for conventions."""
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -44,7 +45,54 @@ def bb_update_bwd(P, G, b, sv, dq2, dt2, dframe, dn3):
 
 
 # --------------------------------------------------------------------------- edge transition
-def edge_transition_fwd(P, b, n3, z, emask, B, N):
+def _edge_mlp_image(P, pre, cache, backward=False):
+    """bf16-plane weight image of the fused kernel: packed once per forward in training (the weights change every
+    step), once per trajectory in sampling (cache)."""
+    key = ("et_img", pre, backward)
+    if cache is not None and key in cache:
+        return cache[key]
+    img = ops.edge_mlp_pack(P[f"{pre}.trunk.0.weight"], P[f"{pre}.trunk.2.weight"], P[f"{pre}.final_layer.weight"],
+                            backward=backward)
+    if cache is not None:
+        cache[key] = img
+    return img
+
+
+FUSED_EDGE = os.environ.get("FD_EDGE_FUSED", "1") != "0"
+
+
+def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None):
+    """z' = emask * LN(W_f (relu(W_2 relu(W_1 x)) + x) + b_f), x = [z | e_i | e_j], e = W_init n3 -- the whole pair-level
+    chain in ONE launch (fd_edge_mlp): h1 / h2 never reach HBM unless the backward needs them (save)."""
+    if not FUSED_EDGE:
+        return edge_transition_fwd_unfused(P, b, n3, z, emask, B, N)
+    pre = f"score_model.trunk.edge_transition_{b}"
+    dev = z
+    R, Pn = B * N, B * N * N
+    W1, Wf = P[f"{pre}.trunk.0.weight"], P[f"{pre}.final_layer.weight"]
+    e = empty((R, CE), dev)
+    ops.linear(mv(n3), mv(P[f"{pre}.initial_embed.weight"]), P[f"{pre}.initial_embed.bias"], mv(e), R, CE, CS)
+    # node halves of the two concat-linears: W [z | e_i | e_j] = W_z z + (W_i e)_i + (W_j e)_j
+    P1 = empty((R, EH), dev); Q1 = empty((R, EH), dev); Pf = empty((R, CZ), dev); Qf = empty((R, CZ), dev)
+    ops.linear(mv(e), (W1, CZ, EH), None, mv(P1), R, EH, CE)
+    ops.linear(mv(e), (W1, CZ + CE, EH), P[f"{pre}.trunk.0.bias"], mv(Q1), R, EH, CE)
+    ops.linear(mv(e), (Wf, CZ, EH), None, mv(Pf), R, CZ, CE)
+    ops.linear(mv(e), (Wf, CZ + CE, EH), P[f"{pre}.final_layer.bias"], mv(Qf), R, CZ, CE)
+    img = _edge_mlp_image(P, pre, cache)
+    z2 = empty((Pn, CZ), dev)
+    kw = {}
+    if save:
+        h1 = empty((Pn, EH), dev); h2 = empty((Pn, EH), dev); y = empty((Pn, CZ), dev)
+        mean = empty((Pn,), dev); rstd = empty((Pn,), dev)
+        kw = dict(save1=h1, save2=h2, y=y, mean=mean, rstd=rstd)
+    ops.edge_mlp(z, img, z2, Pn, N, p1=P1, q1=Q1, bias2=P[f"{pre}.trunk.2.bias"], pf=Pf, qf=Qf,
+                 gamma=P[f"{pre}.layer_norm.weight"], beta=P[f"{pre}.layer_norm.bias"], rowscale=emask, **kw)
+    if not save:
+        return z2, None
+    return z2, dict(n3=n3, z=z, e=e, h1=h1, h2=h2, y=y, mean=mean, rstd=rstd, emask=emask, B=B, N=N)
+
+
+def edge_transition_fwd_unfused(P, b, n3, z, emask, B, N):
     """z' = emask * LN(W_f (relu(W_2 relu(W_1 x)) + x) + b_f), x = [z | e_i | e_j], e = W_init n3.
     The concat is never materialised: W x = W[:, :128] z + (W[:,128:256] e)_i + (W[:,256:] e)_j."""
     pre = f"score_model.trunk.edge_transition_{b}"
@@ -313,7 +361,7 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
         q2, t2, sv_bb = bb_update_fwd(P, b, n3, dmask.view(-1), quat, trans, R)
         sv_et = None
         if b < num_blocks - 1:
-            z, sv_et = edge_transition_fwd(P, b, n3, z, emask, B, N)
+            z, sv_et = edge_transition_fwd(P, b, n3, z, emask, B, N, save=save, cache=cache)
         stages.append(dict(ipa=sv_ipa, ln=sv_ln, tfmr=sv_t, pn=sv_pn, bb=sv_bb, et=sv_et))
         node, quat, trans = n3, q2, t2
         if not save:

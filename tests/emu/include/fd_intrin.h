@@ -97,6 +97,11 @@ static inline f32x16 mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) {
   return d;
 }
 
+// LDS-DMA: lane l copies 16 bytes from its own global address to (wave-uniform base) + 16 l
+static inline void glds16(const void* g_lane, void* lds_wave_base) {
+  memcpy(static_cast<char*>(lds_wave_base) + 16 * hipemu::g_cur->lane, g_lane, 16);
+}
+
 static inline void raise_wave_priority() {}
 
 static inline void block_barrier_nofence() { hipemu::barrier(); }

@@ -1,0 +1,82 @@
+"""Fused edge transition (csrc/fd_edge_mlp.hip) against a float64 restatement of EdgeTransition.forward
+(model/ipa_pytorch.py:218-233, split into the z / e_i / e_j parts as trunk.edge_transition_fwd does) and of its dX chain.
+
+Tolerance: split-bf16 arithmetic is fp32-accurate -- 5e-6 of the tensor maximum for the hidden activations and the
+pre-LayerNorm output, 2e-5 for the LayerNorm output."""
+import numpy as np
+import pytest
+import torch
+
+from se3_diffusion_amd import ops
+
+
+def _case(dev, B, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    R, P = B * N, B * N * N
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc)
+    t = dict(z=rn(P, 128), P1=rn(R, 384, sc=0.5), Q1=rn(R, 384, sc=0.5), b2=rn(384, sc=0.3), Pf=rn(R, 128, sc=0.5),
+             Qf=rn(R, 128, sc=0.5), W1=rn(384, 384, sc=0.08), W2=rn(384, 384, sc=0.08), Wf=rn(128, 384, sc=0.08),
+             gamma=1 + rn(128, sc=0.2), beta=rn(128, sc=0.2), emask=(torch.rand(P, generator=g) > 0.2).float(),
+             dy=rn(P, 128))
+    return {k: v.to(dev) for k, v in t.items()}
+
+
+def _ref_fwd(t, B, N):
+    d = {k: v.double().cpu() for k, v in t.items()}
+    R = B * N
+    qi = torch.arange(B * N * N) // N
+    qj = (qi // N) * N + torch.arange(B * N * N) % N
+    h1 = torch.relu(d["z"] @ d["W1"][:, :128].T + d["P1"][qi] + d["Q1"][qj])
+    h2 = torch.relu(h1 @ d["W2"].T + d["b2"])
+    y = h2 @ d["Wf"].T + d["z"] @ d["Wf"][:, :128].T + d["Pf"][qi] + d["Qf"][qj]
+    mean = y.mean(-1, keepdim=True)
+    var = ((y - mean) ** 2).mean(-1, keepdim=True)
+    out = ((y - mean) / torch.sqrt(var + 1e-5) * d["gamma"] + d["beta"]) * d["emask"][:, None]
+    return h1, h2, y, out, mean[:, 0], 1 / torch.sqrt(var + 1e-5)[:, 0]
+
+
+def rel(a, b):
+    return float((a.double().cpu() - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _run(dev, B, N, seed=0, blocks=0):
+    t = _case(dev, B, N, seed)
+    P = B * N * N
+    img = ops.edge_mlp_pack(t["W1"], t["W2"], t["Wf"])
+    e = lambda *s: torch.empty(*s, device=dev)
+    out, h1, h2, y, mean, rstd = e(P, 128), e(P, 384), e(P, 384), e(P, 128), e(P), e(P)
+    ops.edge_mlp(t["z"], img, out, P, N, p1=t["P1"], q1=t["Q1"], bias2=t["b2"], pf=t["Pf"], qf=t["Qf"], gamma=t["gamma"],
+                 beta=t["beta"], rowscale=t["emask"], save1=h1, save2=h2, y=y, mean=mean, rstd=rstd, blocks=blocks)
+    rh1, rh2, ry, rout, rmean, rrstd = _ref_fwd(t, B, N)
+    assert rel(h1, rh1) < 5e-6 and rel(h2, rh2) < 5e-6 and rel(y, ry) < 5e-6
+    assert rel(out, rout) < 2e-5 and rel(mean, rmean) < 5e-6 and rel(rstd, rrstd) < 2e-5
+    # without the optional outputs (sampling)
+    out2 = e(P, 128)
+    ops.edge_mlp(t["z"], img, out2, P, N, p1=t["P1"], q1=t["Q1"], bias2=t["b2"], pf=t["Pf"], qf=t["Qf"], gamma=t["gamma"],
+                 beta=t["beta"], rowscale=t["emask"], blocks=blocks)
+    assert torch.equal(out, out2)
+    # backward chain: d2 = [h2 > 0] dy Wf ; d1 = [h1 > 0] d2 W2 ; dz = dy Wf[:, :128] + d1 W1[:, :128]
+    imgT = ops.edge_mlp_pack(t["W1"], t["W2"], t["Wf"], backward=True)
+    dz, d2, d1 = e(P, 128), e(P, 384), e(P, 384)
+    ops.edge_mlp(t["dy"], imgT, dz, P, N, gate1=h2, gate2=h1, save1=d2, save2=d1, backward=True, blocks=blocks)
+    dd = {k: v.double().cpu() for k, v in t.items()}
+    rd2 = (dd["dy"] @ dd["Wf"]) * (rh2 > 0)
+    rd1 = (rd2 @ dd["W2"]) * (rh1 > 0)
+    rdz = dd["dy"] @ dd["Wf"][:, :128] + rd1 @ dd["W1"][:, :128]
+    # (gates are taken from the kernel's own h1 / h2: a unit whose fp64 pre-activation is within round-off of zero may flip)
+    flip = float(((h2.cpu() > 0) != (rh2 > 0)).float().mean() + ((h1.cpu() > 0) != (rh1 > 0)).float().mean())
+    assert flip < 1e-4
+    if flip == 0:
+        assert rel(d2, rd2) < 5e-6 and rel(d1, rd1) < 5e-6 and rel(dz, rdz) < 5e-6
+
+
+def test_edge_mlp_emu(use_emu):
+    _run("cpu", B=1, N=12)            # 144 rows: one full tile + a ragged one
+
+
+@pytest.mark.gpu
+def test_edge_mlp_gpu(hip_lib):
+    _run("cuda", B=1, N=12)
+    _run("cuda", B=2, N=50, seed=1)
+    _run("cuda", B=3, N=128, seed=2)               # 384 tiles: persistent blocks walk several tiles
+    _run("cuda", B=1, N=67, seed=3, blocks=5)      # few blocks, many tiles each, ragged tail

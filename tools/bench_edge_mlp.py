@@ -1,0 +1,66 @@
+"""Microbenchmark: fused edge transition (fd_edge_mlp) vs the unfused launch sequence of trunk.edge_transition_fwd."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from se3_diffusion_amd import ops, trunk  # noqa: E402
+from oracle import framediff_oracle as fo  # noqa: E402  (parameter shapes only)
+
+
+def timeit(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="30x128,1x256,8x128,1x128,1x512")
+    ap.add_argument("--blocks", type=int, default=0)
+    a = ap.parse_args()
+    dev = "cuda"
+    P = {k: v.to(dev) for k, v in fo.synth_params(seed=0, conf=dict(fo.CONF, num_blocks=2)).items()}
+    pre = "score_model.trunk.edge_transition_0"
+    W1, W2, Wf = P[f"{pre}.trunk.0.weight"], P[f"{pre}.trunk.2.weight"], P[f"{pre}.final_layer.weight"]
+    for shp in a.shapes.split(","):
+        B, N = (int(x) for x in shp.split("x"))
+        R, Pn = B * N, B * N * N
+        g = torch.Generator(device=dev).manual_seed(1)
+        z = torch.randn(Pn, 128, device=dev, generator=g)
+        n3 = torch.randn(R, 256, device=dev, generator=g)
+        emask = torch.ones(Pn, device=dev)
+        flops = 2.0 * Pn * (128 * 384 + 384 * 384 + 384 * 128 + 128 * 128)
+        t_unf = timeit(lambda: trunk.edge_transition_fwd_unfused(P, 0, n3, z, emask, B, N))
+        img = ops.edge_mlp_pack(W1, W2, Wf)
+        imgT = ops.edge_mlp_pack(W1, W2, Wf, backward=True)
+        t_pack = timeit(lambda: ops.edge_mlp_pack(W1, W2, Wf, out=img))
+        e = lambda *s: torch.empty(*s, device=dev)
+        P1, Q1, Pf, Qf = e(R, 384).normal_(), e(R, 384).normal_(), e(R, 128).normal_(), e(R, 128).normal_()
+        out, h1, h2, y, mean, rstd = e(Pn, 128), e(Pn, 384), e(Pn, 384), e(Pn, 128), e(Pn), e(Pn)
+        b2, gm, bt = P[f"{pre}.trunk.2.bias"], P[f"{pre}.layer_norm.weight"], P[f"{pre}.layer_norm.bias"]
+        kw = dict(p1=P1, q1=Q1, bias2=b2, pf=Pf, qf=Qf, gamma=gm, beta=bt, rowscale=emask, blocks=a.blocks)
+        t_inf = timeit(lambda: ops.edge_mlp(z, img, out, Pn, N, **kw))
+        t_trn = timeit(lambda: ops.edge_mlp(z, img, out, Pn, N, save1=h1, save2=h2, y=y, mean=mean, rstd=rstd, **kw))
+        dz, d2, d1 = e(Pn, 128), e(Pn, 384), e(Pn, 384)
+        t_bwd = timeit(lambda: ops.edge_mlp(y, imgT, dz, Pn, N, gate1=h2, gate2=h1, save1=d2, save2=d1, backward=True,
+                                            blocks=a.blocks))
+        t_bwd_ns = timeit(lambda: ops.edge_mlp(y, imgT, dz, Pn, N, gate1=h2, gate2=h1, backward=True, blocks=a.blocks))
+        tf = lambda ms: flops / ms / 1e9
+        print(f"B={B} N={N} rows={Pn}: unfused fwd {t_unf:.3f} ms ({tf(t_unf):.0f} TF) | fused fwd(no save) {t_inf:.3f} ms "
+              f"({tf(t_inf):.0f} TF) | fused fwd(+h1,h2,y) {t_trn:.3f} ms ({tf(t_trn):.0f} TF) | fused bwd chain(+d2,d1) "
+              f"{t_bwd:.3f} ms ({tf(t_bwd):.0f} TF) | bwd chain no save {t_bwd_ns:.3f} ms | pack {t_pack * 1e3:.1f} us",
+              flush=True)
+
+
+if __name__ == "__main__":
+    main()
