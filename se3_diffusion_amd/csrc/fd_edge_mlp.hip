@@ -103,29 +103,44 @@ __global__ __launch_bounds__(256) void edge_mlp_pack_kernel(EmMat A1, EmMat A2, 
   *reinterpret_cast<uint4*>(dst + 2 * EM_PIECE) = s2;
 }
 
-// one unit: 4 n-blocks x one 16-k step.  u = LDS address of the unit + 16 * lane; b = the activation planes.
-__device__ __forceinline__ void em_unit(f32x16& a0, f32x16& a1, f32x16& a2, f32x16& a3, const uint4 (&b)[3],
-                                        const char* __restrict__ u) {
+// Half a unit = 2 n-blocks x one 16-k step: 6 fragments (24 registers), 12 MFMAs.  The kernel is software-pipelined at
+// this granularity: while half-unit i is multiplied out of one fragment set, the fragments of half-unit i+1 are read
+// into the other (prefetch distance 12 MFMAs = 384 cycles, LDS latency ~130).
+struct EmHalf {
+  uint4 w[2][3];
+};
+
+__device__ __forceinline__ void em_read_half(EmHalf& f, const char* __restrict__ u) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) f.w[i][s] = *reinterpret_cast<const uint4*>(u + (i * 3 + s) * EM_PIECE);
+}
+
+__device__ __forceinline__ void em_mma_half(f32x16& a0, f32x16& a1, const EmHalf& f, const uint4 (&b)[3]) {
   // products (weight plane, activation plane) with i + j <= 2, smallest first
   constexpr int PW[6] = {2, 1, 0, 1, 0, 0};
   constexpr int PX[6] = {0, 1, 2, 0, 1, 0};
-  uint4 w[4][3];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int s = 0; s < 3; ++s) w[i][s] = *reinterpret_cast<const uint4*>(u + (i * 3 + s) * EM_PIECE);
 #pragma unroll
   for (int p = 0; p < 6; ++p) {
-    a0 = fd::mfma_32x32x16_bf16(w[0][PW[p]], b[PX[p]], a0);
-    a1 = fd::mfma_32x32x16_bf16(w[1][PW[p]], b[PX[p]], a1);
-    a2 = fd::mfma_32x32x16_bf16(w[2][PW[p]], b[PX[p]], a2);
-    a3 = fd::mfma_32x32x16_bf16(w[3][PW[p]], b[PX[p]], a3);
+    a0 = fd::mfma_32x32x16_bf16(f.w[0][PW[p]], b[PX[p]], a0);
+    a1 = fd::mfma_32x32x16_bf16(f.w[1][PW[p]], b[PX[p]], a1);
   }
 }
 
 __device__ __forceinline__ void em_zero(f32x16& a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+__device__ __forceinline__ void em_load_x(float (&xr)[8][8], const float* __restrict__ xp) {
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const float4 v = *reinterpret_cast<const float4*>(xp + 16 * ks);
+    const float4 w = *reinterpret_cast<const float4*>(xp + 16 * ks + 4);
+    xr[ks][0] = v.x; xr[ks][1] = v.y; xr[ks][2] = v.z; xr[ks][3] = v.w;
+    xr[ks][4] = w.x; xr[ks][5] = w.y; xr[ks][6] = w.z; xr[ks][7] = w.w;
+  }
 }
 
 template <bool BWD>
@@ -141,114 +156,165 @@ __global__ __launch_bounds__(256, 1) void edge_mlp_kernel(FdEdgeMlpDesc d) {
   const int nmine = (ntiles - first + G - 1) / G;
   const int total_stages = nmine * EM_NSTAGE;
 
-  // ---- weight stream: every wave copies a quarter (12 pieces) of each stage ----
+  // ---- weight stream: every wave copies a quarter (12 pieces) of each stage; stage s lives in buffer s & 1 ----
   const char* __restrict__ img_lane = static_cast<const char*>(d.img) + wave * (EM_STAGE / 4) + lane * 16;
   char* const lds_wave = lds + wave * (EM_STAGE / 4);
+  const char* const lds_lane = lds + lane * 16;
   int issued = 0;      // stages whose copy has been issued
-  int consumed = 0;    // stages whose multiplication has begun
   auto issue_stage = [&]() {
     const char* src = img_lane + (long)(issued % EM_NSTAGE) * EM_STAGE;
     char* dst = lds_wave + (issued & 1) * EM_STAGE;
 #pragma unroll
-    for (int p = 0; p < EM_STAGE / 4 / EM_PIECE; ++p) fd::glds16(src + p * EM_PIECE, dst + p * EM_PIECE);
+    for (int g4 = 0; g4 < 3; ++g4)   // four pieces per address setup (the immediate offset reaches 4095)
+      fd::glds16x4(src + g4 * 4096, dst + g4 * 4096);
     ++issued;
   };
-  // begin stage `consumed`: its copy (issued one stage ago) has landed and is visible to the block; every wave is done
-  // with the previous stage, so the other buffer takes the next copy.  Returns the stage's LDS address + 16 * lane.
-  auto stage_begin = [&]() -> const char* {
+  // Called when the LAST half-unit of a stage has its fragments in registers: the next stage's copy (issued one stage
+  // ago) has landed and is visible to the block, every wave has finished READING the stage that ends, so its buffer
+  // takes the copy of the stage after the next.
+  auto stage_advance = [&]() {
+    fd::wait_vmem();     // the LDS-DMA is issued from inline asm: the compiler does not wait for it
     __syncthreads();
     if (issued < total_stages) issue_stage();
-    const char* cur = lds + (consumed & 1) * EM_STAGE + lane * 16;
-    ++consumed;
-    return cur;
   };
-  issue_stage();
 
-  for (int ti = 0; ti < nmine; ++ti) {
-    const long row0 = ((long)first + (long)ti * G) * EM_ROWS + wave * 32;
-    const long row = row0 + l31;
-    const bool rok = row < rows;
-    const long rc = rok ? row : rows - 1;         // rows past the end are clamped on load, masked on store
-    const long qi = rc / d.nres;                  // (b, i)
-    const long qj = (qi / d.nres) * d.nres + (rc - qi * d.nres);   // (b, j)
+  EmHalf H[2];
+  uint4 bq[2][3];      // activation planes (B operand) of a k-step, ping-pong: every region has an even number of k-steps
+  float xr[8][8];      // x in B-operand layout: k = 16 ks + 8 h + e
+  float4 pre[4][4];    // forward: P1_i + Q1_j of the COMING chunk (loaded under layer 2); backward: this chunk's gate (h2)
 
-    // x in B-operand layout: k = 16 ks + 8 h + e
-    float xr[8][8];
-    {
-      const float* xp = d.x + rc * EM_C + 8 * h;
+  auto row_of = [&](int ti) -> long { return ((long)first + (long)ti * G) * EM_ROWS + wave * 32 + l31; };
+  // one n-block (16 values per lane) of the chunk's pair terms / gates.  Issued in four groups spread over the
+  // previous phase's stages: 8 loads in flight cost 32 registers, all 32 at once would cost 128.
+  auto load_pre = [&](long rcx, int c, int nb) {
+    const long qix = rcx / d.nres, qjx = (qix / d.nres) * d.nres + (rcx - qix * d.nres);
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const float4 v = *reinterpret_cast<const float4*>(xp + 16 * ks);
-        const float4 w = *reinterpret_cast<const float4*>(xp + 16 * ks + 4);
-        xr[ks][0] = v.x; xr[ks][1] = v.y; xr[ks][2] = v.z; xr[ks][3] = v.w;
-        xr[ks][4] = w.x; xr[ks][5] = w.y; xr[ks][6] = w.z; xr[ks][7] = w.w;
+    for (int q = 0; q < 4; ++q) {
+      const int col = 128 * c + 32 * nb + 8 * q + 4 * h;
+      if (!BWD) {
+        const float4 a = *reinterpret_cast<const float4*>(d.p1 + qix * EM_H + col);
+        const float4 bq_ = *reinterpret_cast<const float4*>(d.q1 + qjx * EM_H + col);
+        pre[nb][q] = make_float4(a.x + bq_.x, a.y + bq_.y, a.z + bq_.z, a.w + bq_.w);
+      } else {
+        pre[nb][q] = *reinterpret_cast<const float4*>(d.gate1 + rcx * EM_H + col);
       }
     }
+  };
+
+  // half-unit HJ of a region (static index; 16 half-units fill the two stage buffers)
+#define EM_HALF(HJ, A0, A1, BCUR)                                                          \
+  do {                                                                                     \
+    if ((((HJ) + 1) & 7) == 0) stage_advance();                                            \
+    em_read_half(H[((HJ) + 1) & 1], lds_lane + (((HJ) + 1) & 15) * (EM_UNIT / 2));         \
+    fd::sched_pin(); /* the prefetch stays ahead of this half-unit's MFMAs */               \
+    em_mma_half(A0, A1, H[(HJ) & 1], BCUR);                                                \
+  } while (0)
+
+  // ---- prologue ----
+  issue_stage();
+  {
+    const long r = row_of(0);
+    const long rc = r < rows ? r : rows - 1;
+    em_load_x(xr, d.x + rc * EM_C + 8 * h);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      load_pre(rc, 0, nb);
+      fd::sched_fence();
+    }
+  }
+  fd::wait_vmem();
+  __syncthreads();
+  issue_stage();
+  em_read_half(H[0], lds_lane);
+  em_split8(xr[0], bq[0][0], bq[0][1], bq[0][2]);
+
+  for (int ti = 0; ti < nmine; ++ti) {
+    const long row = row_of(ti);
+    const bool rok = row < rows;
+    const long rc = rok ? row : rows - 1;         // rows past the end are clamped on load, masked on store
+    const long rown = row_of(ti + 1);
+    const long rcn = rown < rows ? rown : rows - 1;   // the next tile's row (any valid row when there is none)
 
     f32x16 acc2[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) em_zero(acc2[i]);
+    for (int nb = 0; nb < 12; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // forward: the layer-2 bias is the accumulator's initial value
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!BWD) a = *reinterpret_cast<const float4*>(d.bias2 + 32 * nb + 8 * q + 4 * h);
+        acc2[nb][4 * q + 0] = a.x; acc2[nb][4 * q + 1] = a.y; acc2[nb][4 * q + 2] = a.z; acc2[nb][4 * q + 3] = a.w;
+      }
 
     for (int c = 0; c < 3; ++c) {
-      // ---- layer 1, chunk c: 128 hidden units x K = 128 ----
+      // ---- layer 1, chunk c: 128 hidden units x K = 128 (8 units) ----
       f32x16 acc1[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) em_zero(acc1[i]);
-#pragma unroll
-      for (int sg = 0; sg < 2; ++sg) {
-        const char* st = stage_begin();
-#pragma unroll
-        for (int uu = 0; uu < EM_UPS; ++uu) {
-          uint4 b[3];
-          em_split8(xr[4 * sg + uu], b[0], b[1], b[2]);
-          em_unit(acc1[0], acc1[1], acc1[2], acc1[3], b, st + uu * EM_UNIT);
-        }
-      }
-      // epilogue 1: forward  h1 = relu(acc + P1_i + Q1_j);  backward  d2 = acc gated by h2 > 0
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int col = 128 * c + 32 * nb + 8 * q + 4 * h;
+          // forward: the pair terms are the accumulator's initial value
+          acc1[nb][4 * q + 0] = BWD ? 0.f : pre[nb][q].x; acc1[nb][4 * q + 1] = BWD ? 0.f : pre[nb][q].y;
+          acc1[nb][4 * q + 2] = BWD ? 0.f : pre[nb][q].z; acc1[nb][4 * q + 3] = BWD ? 0.f : pre[nb][q].w;
+        }
+#pragma clang loop unroll(full)
+      for (int j = 0; j < 8; ++j) {
+        if (j + 1 < 8) em_split8(xr[j + 1], bq[(j + 1) & 1][0], bq[(j + 1) & 1][1], bq[(j + 1) & 1][2]);
+        if (BWD && (j & 1) == 0) load_pre(rc, c, j >> 1);   // this chunk's gates (h2), used by epilogue 1
+        EM_HALF(2 * j, acc1[0], acc1[1], bq[j & 1]);
+        EM_HALF(2 * j + 1, acc1[2], acc1[3], bq[j & 1]);
+      }
+      // epilogue 1: forward  h1 = relu(acc);  backward  d2 = acc gated by h2 > 0
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc1[nb][4 * q + e];
           if (!BWD) {
-            const float4 a = *reinterpret_cast<const float4*>(d.p1 + qi * EM_H + col);
-            const float4 bq = *reinterpret_cast<const float4*>(d.q1 + qj * EM_H + col);
-            v[0] += a.x + bq.x; v[1] += a.y + bq.y; v[2] += a.z + bq.z; v[3] += a.w + bq.w;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
           } else {
-            const float4 g = *reinterpret_cast<const float4*>(d.gate1 + rc * EM_H + col);
+            const float4 g = pre[nb][q];
             v[0] = g.x > 0.f ? v[0] : 0.f; v[1] = g.y > 0.f ? v[1] : 0.f;
             v[2] = g.z > 0.f ? v[2] : 0.f; v[3] = g.w > 0.f ? v[3] : 0.f;
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc1[nb][4 * q + e] = v[e];
           if (d.save1 != nullptr && rok)
-            *reinterpret_cast<float4*>(d.save1 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(d.save1 + row * EM_H + 128 * c + 32 * nb + 8 * q + 4 * h) =
+                make_float4(v[0], v[1], v[2], v[3]);
         }
-      // ---- layer 2, k in chunk c: 24 units (k-step ks, row group g) = 6 stages ----
+      {
+        float t[8];
 #pragma unroll
-      for (int sg = 0; sg < 6; ++sg) {
-        const char* st = stage_begin();
-        uint4 b[3];
+        for (int e = 0; e < 8; ++e) t[e] = acc1[0][e];
+        em_split8(t, bq[0][0], bq[0][1], bq[0][2]);
+      }
+      // ---- layer 2, k in chunk c: 24 units (k-step ks, row group g) ----
+#pragma clang loop unroll(full)
+      for (int u2 = 0; u2 < 24; ++u2) {
+        const int ks = u2 / 3, g = u2 % 3, j = 8 + u2;
+        if (g == 2 && ks + 1 < 8) {        // planes of the next k-step
+          float t[8];
 #pragma unroll
-        for (int uu = 0; uu < EM_UPS; ++uu) {
-          const int u2 = 4 * sg + uu, ks = u2 / 3, g = u2 % 3;
-          if (g == 0 || uu == 0) {
-            float t[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = acc1[ks >> 1][8 * (ks & 1) + e];
-            em_split8(t, b[0], b[1], b[2]);
-          }
-          em_unit(acc2[4 * g + 0], acc2[4 * g + 1], acc2[4 * g + 2], acc2[4 * g + 3], b, st + uu * EM_UNIT);
+          for (int e = 0; e < 8; ++e) t[e] = acc1[(ks + 1) >> 1][8 * ((ks + 1) & 1) + e];
+          em_split8(t, bq[(ks + 1) & 1][0], bq[(ks + 1) & 1][1], bq[(ks + 1) & 1][2]);
         }
+        if (u2 == 23) em_split8(xr[0], bq[0][0], bq[0][1], bq[0][2]);   // first k-step of what follows (layer 1 or layer 3)
+        if (!BWD && (u2 & 3) == 2 && u2 < 16) {   // pair terms of the next chunk (the next tile's first after c = 2),
+          if (c < 2) load_pre(rc, c + 1, u2 >> 2); else load_pre(rcn, 0, u2 >> 2);   // one n-block per stage
+        }
+        EM_HALF(2 * j, acc2[4 * g + 0], acc2[4 * g + 1], bq[ks & 1]);
+        EM_HALF(2 * j + 1, acc2[4 * g + 2], acc2[4 * g + 3], bq[ks & 1]);
       }
     }
 
-    // epilogue 2: forward  h2 = relu(acc2 + b2);  backward  d1 = acc2 gated by h1 > 0
+    f32x16 acc3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) em_zero(acc3[i]);
+    // epilogue 2: forward  h2 = relu(acc2);  backward  d1 = acc2 gated by h1 > 0
 #pragma unroll
     for (int nb = 0; nb < 12; ++nb)
 #pragma unroll
@@ -258,8 +324,6 @@ __global__ __launch_bounds__(256, 1) void edge_mlp_kernel(FdEdgeMlpDesc d) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc2[nb][4 * q + e];
         if (!BWD) {
-          const float4 a = *reinterpret_cast<const float4*>(d.bias2 + col);
-          v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
         } else {
@@ -274,50 +338,59 @@ __global__ __launch_bounds__(256, 1) void edge_mlp_kernel(FdEdgeMlpDesc d) {
       }
 
     // ---- layer 3: 128 outputs x (K = 128 of x, then K = 384 of the hidden layer) ----
-    f32x16 acc3[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) em_zero(acc3[i]);
-#pragma unroll
-    for (int sg = 0; sg < 2; ++sg) {
-      const char* st = stage_begin();
-#pragma unroll
-      for (int uu = 0; uu < EM_UPS; ++uu) {
-        uint4 b[3];
-        em_split8(xr[4 * sg + uu], b[0], b[1], b[2]);
-        em_unit(acc3[0], acc3[1], acc3[2], acc3[3], b, st + uu * EM_UNIT);
-      }
-    }
-#pragma unroll
-    for (int sg = 0; sg < 6; ++sg) {
-      const char* st = stage_begin();
-#pragma unroll
-      for (int uu = 0; uu < EM_UPS; ++uu) {
-        const int v = 4 * sg + uu, kb = v >> 1, t2 = v & 1;
+#pragma clang loop unroll(full)
+    for (int j = 0; j < 8; ++j) {
+      if (j + 1 < 8) {
+        em_split8(xr[j + 1], bq[(j + 1) & 1][0], bq[(j + 1) & 1][1], bq[(j + 1) & 1][2]);
+      } else {
         float t[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) t[e] = acc2[kb][8 * t2 + e];
-        uint4 b[3];
-        em_split8(t, b[0], b[1], b[2]);
-        em_unit(acc3[0], acc3[1], acc3[2], acc3[3], b, st + uu * EM_UNIT);
+        for (int e = 0; e < 8; ++e) t[e] = acc2[0][e];
+        em_split8(t, bq[0][0], bq[0][1], bq[0][2]);
       }
+      EM_HALF(2 * j, acc3[0], acc3[1], bq[j & 1]);
+      EM_HALF(2 * j + 1, acc3[2], acc3[3], bq[j & 1]);
+    }
+#pragma clang loop unroll(full)
+    for (int v = 0; v < 24; ++v) {
+      const int j = 8 + v;
+      if (v == 0) em_load_x(xr, d.x + rcn * EM_C + 8 * h);     // x of the next tile (this tile's is consumed)
+      if (v + 1 < 24) {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = acc2[(v + 1) >> 1][8 * ((v + 1) & 1) + e];
+        em_split8(t, bq[(v + 1) & 1][0], bq[(v + 1) & 1][1], bq[(v + 1) & 1][2]);
+      } else {
+        em_split8(xr[0], bq[0][0], bq[0][1], bq[0][2]);        // first k-step of the next tile
+      }
+      EM_HALF(2 * j, acc3[0], acc3[1], bq[v & 1]);
+      EM_HALF(2 * j + 1, acc3[2], acc3[3], bq[v & 1]);
     }
 
     // ---- final epilogue ----
     if (!BWD) {
-      // y = acc + Pf_i + Qf_j ; z' = rowscale * LayerNorm(y).  A row's 128 values sit in two lanes (l, l ^ 32).
+      // z' = rowscale * LayerNorm(y).  A row's 128 values sit in two lanes (l, l ^ 32).
       float s = 0.f;
+      const long qi = rc / d.nres, qj = (qi / d.nres) * d.nres + (rc - qi * d.nres);
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 32 * nb + 8 * q + 4 * h;
+          const float4 pa = *reinterpret_cast<const float4*>(d.pf + qi * EM_C + col);
+          const float4 qa = *reinterpret_cast<const float4*>(d.qf + qj * EM_C + col);
+          acc3[nb][4 * q + 0] += pa.x + qa.x; acc3[nb][4 * q + 1] += pa.y + qa.y;
+          acc3[nb][4 * q + 2] += pa.z + qa.z; acc3[nb][4 * q + 3] += pa.w + qa.w;
+        }
+        fd::sched_fence();
+      }
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int col = 32 * nb + 8 * q + 4 * h;
-          const float4 a = *reinterpret_cast<const float4*>(d.pf + qi * EM_C + col);
-          const float4 bq = *reinterpret_cast<const float4*>(d.qf + qj * EM_C + col);
-          acc3[nb][4 * q + 0] += a.x + bq.x; acc3[nb][4 * q + 1] += a.y + bq.y;
-          acc3[nb][4 * q + 2] += a.z + bq.z; acc3[nb][4 * q + 3] += a.w + bq.w;
           s += (acc3[nb][4 * q + 0] + acc3[nb][4 * q + 1]) + (acc3[nb][4 * q + 2] + acc3[nb][4 * q + 3]);
           if (d.y != nullptr && rok)
-            *reinterpret_cast<float4*>(d.y + row * EM_C + col) =
+            *reinterpret_cast<float4*>(d.y + row * EM_C + 32 * nb + 8 * q + 4 * h) =
                 make_float4(acc3[nb][4 * q + 0], acc3[nb][4 * q + 1], acc3[nb][4 * q + 2], acc3[nb][4 * q + 3]);
         }
       s += __shfl_xor(s, 32);
@@ -339,7 +412,8 @@ __global__ __launch_bounds__(256, 1) void edge_mlp_kernel(FdEdgeMlpDesc d) {
         if (d.rstd != nullptr) d.rstd[row] = rstd;
       }
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
+      for (int nb = 0; nb < 4; ++nb) {
+        fd::sched_fence();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int col = 32 * nb + 8 * q + 4 * h;
@@ -352,18 +426,19 @@ __global__ __launch_bounds__(256, 1) void edge_mlp_kernel(FdEdgeMlpDesc d) {
           o.w = (acc3[nb][4 * q + 3] * rstd * gm.w + bt.w) * rs;
           if (rok) *reinterpret_cast<float4*>(d.out + row * EM_C + col) = o;
         }
+      }
     } else {
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int col = 32 * nb + 8 * q + 4 * h;
           if (rok)
-            *reinterpret_cast<float4*>(d.out + row * EM_C + col) =
+            *reinterpret_cast<float4*>(d.out + row * EM_C + 32 * nb + 8 * q + 4 * h) =
                 make_float4(acc3[nb][4 * q + 0], acc3[nb][4 * q + 1], acc3[nb][4 * q + 2], acc3[nb][4 * q + 3]);
         }
     }
   }
+#undef EM_HALF
 }
 
 }  // namespace

@@ -40,9 +40,12 @@ __device__ __forceinline__ float bf16hi_f32(unsigned w) { return __builtin_bit_c
 // LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane straight from global memory into LDS, no VGPR round trip.
 // The LDS destination is WAVE-UNIFORM base + lane * 16 (not a per-lane scatter); the source address is per lane.
 // Completion is tracked by vmcnt like any load: __syncthreads() (vmcnt(0) + barrier) publishes it to the block.
+// OFF (0..4095) is the instruction's immediate offset, applied to BOTH addresses: pieces at src + OFF -> dst + OFF share
+// one M0 / address setup.
+template <int OFF = 0>
 __device__ __forceinline__ void glds16(const void* g_lane, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_lane,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, OFF, 0);
 }
 
 // s_setprio 3: this wave wins instruction arbitration on its SIMD
@@ -53,6 +56,35 @@ __device__ __forceinline__ void block_barrier_nofence() { __builtin_amdgcn_s_bar
 
 // compiler-only fence: memory operations are not moved across it (bounds register live ranges in unrolled epilogues)
 __device__ __forceinline__ void sched_fence() { asm volatile("" ::: "memory"); }
+
+// Four LDS-DMA pieces (src + k KB -> dst + k KB, k = 0..3) behind ONE M0 setup, as inline asm: the compiler does not
+// see these loads, so it neither drains them with a vmcnt(0) in front of the next ds_read (it cannot prove that an LDS
+// read does not alias a pending LDS-DMA write) nor waits for them at __syncthreads().  The caller owns the wait:
+// wait_vmem() before the barrier that publishes the copy.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void glds16x4(const void* g_lane, void* lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(lds_wave_base));
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g_lane), "s"(dst)
+      : "memory");
+}
+// s_waitcnt vmcnt(0): every vector-memory operation of this wave (loads, stores, LDS-DMA) has completed
+__device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// the instruction scheduler moves nothing across this point (pins a software-pipelined order)
+__device__ __forceinline__ void sched_pin() { __builtin_amdgcn_sched_barrier(0); }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }

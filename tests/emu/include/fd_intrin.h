@@ -98,15 +98,23 @@ static inline f32x16 mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) {
 }
 
 // LDS-DMA: lane l copies 16 bytes from its own global address to (wave-uniform base) + 16 l
+template <int OFF = 0>
 static inline void glds16(const void* g_lane, void* lds_wave_base) {
-  memcpy(static_cast<char*>(lds_wave_base) + 16 * hipemu::g_cur->lane, g_lane, 16);
+  memcpy(static_cast<char*>(lds_wave_base) + OFF + 16 * hipemu::g_cur->lane, static_cast<const char*>(g_lane) + OFF, 16);
 }
+
+static inline void glds16x4(const void* g_lane, void* lds_wave_base) {
+  for (int k = 0; k < 4; ++k)
+    memcpy(static_cast<char*>(lds_wave_base) + 1024 * k + 16 * hipemu::g_cur->lane, static_cast<const char*>(g_lane) + 1024 * k, 16);
+}
+static inline void wait_vmem() {}
 
 static inline void raise_wave_priority() {}
 
 static inline void block_barrier_nofence() { hipemu::barrier(); }
 
 static inline void sched_fence() {}
+static inline void sched_pin() {}
 
 
 static inline int lane_id() { return hipemu::g_cur->lane; }

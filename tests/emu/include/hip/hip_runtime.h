@@ -136,3 +136,5 @@ static inline double rsqrt(double x) { return 1.0 / sqrt(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline void sincosf_emu(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline unsigned __float_as_uint(float x) { unsigned u; memcpy(&u, &x, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float x; memcpy(&x, &u, 4); return x; }
