@@ -141,8 +141,6 @@ typedef struct FdEdgeMlpDesc {
   int backward;
   float eps;
   int blocks;            /* 0 = one persistent block per CU (256) */
-  int debug;             /* ablation switches for profiling (results are then WRONG): 1 = no weight copies after the
-                            first stage, 2 = no MFMAs / fragment reads */
 } FdEdgeMlpDesc;
 int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream);
 

@@ -26,6 +26,10 @@ typedef __bf16 fd_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x16 mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(fd_bf16x8, a), __builtin_bit_cast(fd_bf16x8, b), c, 0, 0, 0);
 }
+// v_mfma_f32_16x16x32_bf16: A[i=l&15][k=8*(l>>4)+e], B[k=8*(l>>4)+e][j=l&15]; D reg r -> row 4*(l>>4)+r, col l&15.
+__device__ __forceinline__ f32x4 mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(fd_bf16x8, a), __builtin_bit_cast(fd_bf16x8, b), c, 0, 0, 0);
+}
 // two f32 -> one dword of two bf16, round-to-nearest-even (v_cvt_pk_bf16_f32): lo in bits 0..15
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
   // (asm rather than two __bf16 casts: the compiler otherwise re-derives each half with its own conversion when
@@ -75,6 +79,20 @@ __device__ __forceinline__ void glds16x4(const void* g_lane, void* lds_wave_base
       "global_load_lds_dwordx4 %1, off offset:1024\n\t"
       "global_load_lds_dwordx4 %1, off offset:2048\n\t"
       "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g_lane), "s"(dst)
+      : "memory");
+}
+__device__ __forceinline__ void glds16x2(const void* g_lane, void* lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(lds_wave_base));
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(g_lane), "s"(dst)

@@ -148,13 +148,22 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
     de = empty((R, CE), dev)
     ops.linear_dx(mv(dPf), (Wf, CZ, EH), mv(de), R, CZ, CE)
     ops.linear_dx(mv(dQf), (Wf, CZ + CE, EH), mv(de), R, CZ, CE, beta=True)
-    ops.linear_dx(mv(dy), (Wf, 0, EH), mv(dz), Pn, CZ, CZ)                     # dz = dy Wf_z
-    dh2 = empty((Pn, EH), dev)
-    ops.linear_dx(mv(dy), mv(Wf), mv(dh2), Pn, CZ, EH, gate=mv(h2))
-    _lin_grads(G, f"{pre}.trunk.2.weight", f"{pre}.trunk.2.bias", mv(dh2), mv(h1), Pn, EH, EH)
-    dh1 = empty((Pn, EH), dev)
-    ops.linear_dx(mv(dh2), mv(W2), mv(dh1), Pn, EH, EH, gate=mv(h1))
-    del dh2
+    if FUSED_EDGE:
+        # the dX chain in one launch: d2 = [h2 > 0] dy Wf, d1 = [h1 > 0] d2 W2, dz = dy Wf_z + d1 W1_z (fd_edge_mlp with
+        # the transposed weight image); d2 / d1 are written once, for the weight-gradient GEMMs and the pair reductions
+        dh2 = empty((Pn, EH), dev); dh1 = empty((Pn, EH), dev)
+        ops.edge_mlp(dy, _edge_mlp_image(P, pre, None, backward=True), dz, Pn, N, gate1=h2, gate2=h1, save1=dh2,
+                     save2=dh1, backward=True)
+        _lin_grads(G, f"{pre}.trunk.2.weight", f"{pre}.trunk.2.bias", mv(dh2), mv(h1), Pn, EH, EH)
+        del dh2
+    else:
+        ops.linear_dx(mv(dy), (Wf, 0, EH), mv(dz), Pn, CZ, CZ)                     # dz = dy Wf_z
+        dh2 = empty((Pn, EH), dev)
+        ops.linear_dx(mv(dy), mv(Wf), mv(dh2), Pn, CZ, EH, gate=mv(h2))
+        _lin_grads(G, f"{pre}.trunk.2.weight", f"{pre}.trunk.2.bias", mv(dh2), mv(h1), Pn, EH, EH)
+        dh1 = empty((Pn, EH), dev)
+        ops.linear_dx(mv(dh2), mv(W2), mv(dh1), Pn, EH, EH, gate=mv(h1))
+        del dh2
     gW1 = G[f"{pre}.trunk.0.weight"]
     ops.side(lambda: ops.linear_dw(mv(dh1), mv(z), (gW1, 0, EH), Pn, EH, CZ), (dh1, z), Pn)
     dP1 = zeros((R, EH), dev); dQ1 = zeros((R, EH), dev)
@@ -166,7 +175,8 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
     ops.side(_grads_1, (dP1, dQ1, e), R)
     ops.linear_dx(mv(dP1), (W1, CZ, EH), mv(de), R, EH, CE, beta=True)
     ops.linear_dx(mv(dQ1), (W1, CZ + CE, EH), mv(de), R, EH, CE, beta=True)
-    ops.linear_dx(mv(dh1), (W1, 0, EH), mv(dz), Pn, EH, CZ, beta=True)          # dz += dh1 W1_z
+    if not FUSED_EDGE:
+        ops.linear_dx(mv(dh1), (W1, 0, EH), mv(dz), Pn, EH, CZ, beta=True)          # dz += dh1 W1_z
     _lin_grads(G, f"{pre}.initial_embed.weight", f"{pre}.initial_embed.bias", mv(de), mv(sv["n3"]), R, CE, CS)
     ops.linear_dx(mv(de), mv(P[f"{pre}.initial_embed.weight"]), mv(dn3), R, CE, CS, beta=True)
 

@@ -103,6 +103,34 @@ static inline void glds16(const void* g_lane, void* lds_wave_base) {
   memcpy(static_cast<char*>(lds_wave_base) + OFF + 16 * hipemu::g_cur->lane, static_cast<const char*>(g_lane) + OFF, 16);
 }
 
+// 16x16x32 bf16: A[i=l&15][k=8*(l>>4)+e], B[k=8*(l>>4)+e][j=l&15]; D reg r -> row 4*(l>>4)+r, col l&15
+static inline f32x4 mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) {
+  struct AB { unsigned a[4], b[4]; } ab{{a.x, a.y, a.z, a.w}, {b.x, b.y, b.z, b.w}};
+  auto tab = hipemu::wave_exchange(&ab, sizeof(ab));
+  int l = hipemu::g_cur->lane;
+  int col = l & 15, g = l >> 4;
+  f32x4 d;
+  for (int r = 0; r < 4; ++r) {
+    int row = 4 * g + r;
+    float acc = c[r];
+    for (int kg = 0; kg < 4; ++kg) {
+      AB x, y;
+      memcpy(&x, tab[row + 16 * kg], sizeof(AB));
+      memcpy(&y, tab[col + 16 * kg], sizeof(AB));
+      for (int e = 0; e < 4; ++e) {
+        acc = fmaf(bf16lo_f32(x.a[e]), bf16lo_f32(y.b[e]), acc);
+        acc = fmaf(bf16hi_f32(x.a[e]), bf16hi_f32(y.b[e]), acc);
+      }
+    }
+    d[r] = acc;
+  }
+  return d;
+}
+
+static inline void glds16x2(const void* g_lane, void* lds_wave_base) {
+  for (int k = 0; k < 2; ++k)
+    memcpy(static_cast<char*>(lds_wave_base) + 1024 * k + 16 * hipemu::g_cur->lane, static_cast<const char*>(g_lane) + 1024 * k, 16);
+}
 static inline void glds16x4(const void* g_lane, void* lds_wave_base) {
   for (int k = 0; k < 4; ++k)
     memcpy(static_cast<char*>(lds_wave_base) + 1024 * k + 16 * hipemu::g_cur->lane, static_cast<const char*>(g_lane) + 1024 * k, 16);

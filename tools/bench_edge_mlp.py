@@ -27,7 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="30x128,1x256,8x128,1x128,1x512")
     ap.add_argument("--blocks", type=int, default=0)
-    ap.add_argument("--ablate", action="store_true")
+    ap.add_argument("--fwd-only", action="store_true", help="only the no-save forward (PMC runs)")
     a = ap.parse_args()
     dev = "cuda"
     P = {k: v.to(dev) for k, v in fo.synth_params(seed=0, conf=dict(fo.CONF, num_blocks=2)).items()}
@@ -51,17 +51,14 @@ def main():
         b2, gm, bt = P[f"{pre}.trunk.2.bias"], P[f"{pre}.layer_norm.weight"], P[f"{pre}.layer_norm.bias"]
         kw = dict(p1=P1, q1=Q1, bias2=b2, pf=Pf, qf=Qf, gamma=gm, beta=bt, rowscale=emask, blocks=a.blocks)
         t_inf = timeit(lambda: ops.edge_mlp(z, img, out, Pn, N, **kw))
+        if a.fwd_only:
+            print(f"B={B} N={N}: fused fwd(no save) {t_inf:.3f} ms ({flops / t_inf / 1e9:.0f} TF)")
+            continue
         t_trn = timeit(lambda: ops.edge_mlp(z, img, out, Pn, N, save1=h1, save2=h2, y=y, mean=mean, rstd=rstd, **kw))
         dz, d2, d1 = e(Pn, 128), e(Pn, 384), e(Pn, 384)
         t_bwd = timeit(lambda: ops.edge_mlp(y, imgT, dz, Pn, N, gate1=h2, gate2=h1, save1=d2, save2=d1, backward=True,
                                             blocks=a.blocks))
         t_bwd_ns = timeit(lambda: ops.edge_mlp(y, imgT, dz, Pn, N, gate1=h2, gate2=h1, backward=True, blocks=a.blocks))
-        if False and a.ablate:
-            for dbg, what in ((1, "no weight copies"), (2, "no MFMAs"), (3, "neither"), (4, "no epilogue memory ops"),
-                              (8, "no split"), (12, "no epi mem, no split"), (15, "nothing but barriers + x load"),
-                              (13, "MFMA + frag reads only")):
-                t = timeit(lambda: ops.edge_mlp(z, img, out, Pn, N, debug=dbg, **kw))
-                print(f"   ablation {what}: {t:.3f} ms (full {t_inf:.3f})")
         tf = lambda ms: flops / ms / 1e9
         print(f"B={B} N={N} rows={Pn}: unfused fwd {t_unf:.3f} ms ({tf(t_unf):.0f} TF) | fused fwd(no save) {t_inf:.3f} ms "
               f"({tf(t_inf):.0f} TF) | fused fwd(+h1,h2,y) {t_trn:.3f} ms ({tf(t_trn):.0f} TF) | fused bwd chain(+d2,d1) "
