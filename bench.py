@@ -7,12 +7,18 @@ all-reduce + Adam.  value = residues/s over all ranks, inputs resident in HBM.
 
   python bench.py --gpus 1 --steps 10 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --mode sample --n-res 256 --batch 1 --steps 1 --warmup 1        # full 500-step sampling
+  python bench.py --mixed-n                                                         # BASELINE configs[3]
 
-One JSON line on stdout (rank 0).  `roofline` = the dominant kernel (the fd_gemm tile with the largest share of the
-step: the 256x128 split-bf16 MFMA kernel), timed with HIP events on its own stream in three steps right after the
-timed region (launches serialised; events inside the timed region would cost ~2.5 ms per step and overlap across the two
-streams); `cpu_baseline` = the oracle
-(CPU port of the reference, oracle/framediff_oracle.py) on a bounded sample of the same workload.
+One JSON line on stdout (rank 0):
+  * value / ms_per_step: the training step (the first half of BASELINE.json's metric);
+  * config.sampling: the second half -- backbones/s of 500-step reverse diffusion at N = 128 / 256 / 512, from bounded
+    device-resident runs (--sample-steps diffusion steps each, scaled to 501 network forwards; rank 0 at N = 1 GPU only);
+  * config.self_conditioning_50pct: the step with the reference's 50 % extra no-grad forward (train_se3_diffusion.py:535-537);
+  * roofline: the dominant kernel (largest share of the serialised step among fd_gemm's tiles and the fused
+    edge-transition kernel), timed with HIP events on its own stream in three steps right after the timed region;
+  * cpu_baseline: the unmodified reference when FD_REFERENCE_ROOT (default /root/reference) exists, else the oracle (CPU port),
+    on a bounded sample of the same workload, best of a thread sweep.
 """
 import argparse
 import json
@@ -24,6 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
+
+ARITH = ("fp32 storage and accumulation everywhere; pair-level GEMMs and the fused edge transition = 3-term bf16 split on the "
+         "bf16 MFMA (fp32-accurate; FD_GEMM_EXACT_F32=1 forces bitwise-fp32 MFMA chains), all other GEMMs fp32 MFMA, IGSO(3) fp64")
 
 
 def parse():
@@ -37,42 +46,96 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "forward", "sample"])
     ap.add_argument("--num-t", type=int, default=500, help="reverse-diffusion steps per backbone (sample mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sampling", action="store_true", help="skip the bounded sampling runs of the default line")
+    ap.add_argument("--sample-steps", type=int, default=50, help="diffusion steps of each bounded sampling run")
     ap.add_argument("--no-graph", action="store_true", help="sample mode: eager launches instead of one hipGraph per step")
-    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    ap.add_argument("--mixed-n", action="store_true",
+                    help="BASELINE configs[3]: every step all ranks draw the same N in [100, 512], B = min(32, 5e5 // N^2)")
     return ap.parse_args()
 
 
-def cpu_baseline(n_res, blocks, sample_b, steps=2):
-    """The oracle (CPU port) on a bounded sample: fwd + loss + bwd of `sample_b` backbones."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(n_res, blocks, sample_b, budget_s=40.0):
+    """fwd + DSM loss + bwd of `sample_b` backbones on the host: the unmodified reference if it is on this machine
+    (FD_REFERENCE_ROOT), else the oracle (CPU port); best of a thread sweep, bounded by `budget_s` seconds."""
     from oracle import framediff_oracle as fo
+    from oracle import ref_loader as rl
     from se3_diffusion_amd import train_step as ts
-    cores = max(1, (os.cpu_count() or 2) // 2)
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 2
     conf = dict(fo.CONF, num_blocks=blocks)
-    P = {k: v.requires_grad_(True) for k, v in fo.synth_params(seed=0, conf=conf).items()}
     batch = ts.synthetic_batch(sample_b, n_res, "cpu", seed=0)
     gt37, _ = fo.backbone_atoms(batch["rigids_0"][..., :4], batch["rigids_0"][..., 4:],
                                 batch["torsion_angles_sin_cos"][..., 2, :])
+    kind = "port"
+    step = None
+    if rl.available():
+        try:
+            rl.install()
+            from data import se3_diffuser as ref_se3      # the reference's own modules
+            from model import score_network as ref_sn
+            rconf = rl.base_conf(os.environ.get("FD_IGSO3_CACHE", "/tmp/fd_igso3_cache_bench"), num_blocks=blocks)
+            ref_model = ref_sn.ScoreNetwork(rconf.model, ref_se3.SE3Diffuser(rconf.diffuser))
+            ref_model.load_state_dict(fo.synth_params(seed=0, conf=conf), strict=True)
+            ref_model.train()
 
-    def step():
-        out = fo.score_network_forward(P, batch, conf)
-        loss = ts.dsm_loss(batch, out, gt37)
-        loss.backward()
-        for p in P.values():
-            p.grad = None
+            def step():
+                ref_model.zero_grad(set_to_none=True)
+                loss = ts.dsm_loss(batch, ref_model(batch), gt37)
+                loss.backward()
+            kind = "reference"
+        except Exception:  # noqa: BLE001 -- fall back to the port
+            step = None
+    if step is None:
+        P = {k: v.requires_grad_(True) for k, v in fo.synth_params(seed=0, conf=conf).items()}
 
-    step()
-    t0 = time.time()
-    for _ in range(steps):
+        def step():
+            out = fo.score_network_forward(P, batch, conf)
+            loss = ts.dsm_loss(batch, out, gt37)
+            loss.backward()
+            for p in P.values():
+                p.grad = None
+
+    sweep = [t for t in (32, 64, 16, 128) if t <= ncpu] or [ncpu]
+    t_start = time.time()
+    best, tried = None, []
+    for i, th in enumerate(sweep):
+        torch.set_num_threads(th)
+        if i == 0:
+            step()                               # warm-up (allocator, oneDNN primitives)
+        t0 = time.time()
         step()
-    dt = (time.time() - t0) / steps
-    return dict(value=round(sample_b * n_res / dt, 2), unit="residues/s", cores=cores, kind="port",
-                sample=f"{steps} steps of fwd+DSM loss+bwd, B={sample_b} x N={n_res}, {blocks} blocks, "
-                       f"torch-CPU fp32 oracle, {cores} threads, {dt:.2f} s/step")
+        dt = time.time() - t0
+        tried.append((th, round(dt, 2)))
+        if best is None or dt < best[1]:
+            best = (th, dt)
+        if time.time() - t_start + dt > budget_s:
+            break
+    th, dt = best
+    return dict(value=round(sample_b * n_res / dt, 2), unit="residues/s", cores=th, kind=kind,
+                sample=f"fwd + DSM loss + bwd, B={sample_b} x N={n_res}, {blocks} blocks, "
+                       f"{'unmodified reference' if kind == 'reference' else 'torch-CPU fp32 oracle (port)'}; best of threads "
+                       f"{tried} (threads, s/step) on {ncpu} logical CPUs ({_cpu_model()})")
 
 
-# fd_gemm tile code -> (kernel, dense MFMA peak in TFLOP/s of ALGORITHMIC fp32 flops).  The split kernel spends six
-# bf16 MFMAs (2.5 PFLOP/s dense, MI355X_MICROARCH.md) per fp32-accurate product, so its ceiling is 2500 / 6.
+# ---------------------------------------------------------------------------------------------------------------------
+# roofline bookkeeping
+# ---------------------------------------------------------------------------------------------------------------------
+# profile tile code -> (kernel, dense MFMA peak in TFLOP/s of ALGORITHMIC fp32 flops).  The split-bf16 kernels spend six
+# bf16 MFMAs (2.5 PFLOP/s dense, MI355X_MICROARCH.md) per fp32-accurate product, so their ceiling is 2500 / 6.
 _KERNELS = {
     1: ("gemm_kernel<128,128,2,2,*,*> (fp32 v_mfma_f32_32x32x2_f32)", 157.3),
     2: ("gemm_kernel<64,64,2,2,*,*> (fp32 v_mfma_f32_32x32x2_f32)", 157.3),
@@ -82,39 +145,81 @@ _KERNELS = {
     4: ("gemm_bx3p_kernel<*> / gemm_bx3_kernel<256,*,*,*> (256x128 tiles, fp32 operands as 3 bf16 terms, 6 x "
         "v_mfma_f32_32x32x16_bf16 per k-step; persistent blocks when a launch has >= 2 tiles per CU)",
         round(2500.0 / 6.0, 1)),
+    7: ("edge_mlp16_kernel<*> (fused edge transition 128->384->384->128 + LayerNorm per pair row, register-chained, "
+        "fp32 operands as 3 bf16 terms, 6 x v_mfma_f32_16x16x32_bf16 per k-step, weights streamed by LDS-DMA)",
+        round(2500.0 / 6.0, 1)),
 }
+# HBM bytes per launch of the dominant kernel from PMC (separate --pmc passes, FETCH_SIZE / WRITE_SIZE; profiles/
+# r02_pmc_edge_mlp.md), keyed by (tile, rows): forward without saves at B=30 x N=128
+_PMC_TRAFFIC = {(7, 491520): {"bytes_per_launch": 553e6, "algorithmic_bytes": 503e6,
+                              "source": "profiles/r02_pmc_edge_mlp.md (FETCH_SIZE 297 MB + WRITE_SIZE 256 MB, forward)"}}
 
 
-def dominant_gemm(prof):
-    """(tile, flops, seconds, launches) of the fd_gemm tile with the largest total time + totals over all tiles."""
+def dominant_kernel(prof):
+    """(tile, flops, seconds, launches) of the profiled kernel class with the largest total time + totals over all."""
     by = {}
     for rec in prof:
-        s = by.setdefault(rec[0], [0.0, 0.0, 0])
+        s = by.setdefault(rec[0], [0.0, 0.0, 0, rec[6]])
         s[0] += rec[3]
         s[1] += rec[4].elapsed_time(rec[5]) * 1e-3
         s[2] += 1
     tile = max(by, key=lambda k: by[k][1])
     tot_f = sum(v[0] for v in by.values())
     tot_t = sum(v[1] for v in by.values())
-    return tile, by[tile][0], by[tile][1], by[tile][2], tot_f, tot_t
+    return tile, by[tile][0], by[tile][1], by[tile][2], tot_f, tot_t, by[tile][3], {k: round(v[1] * 1e3, 3) for k, v in by.items()}
+
+
+def make_diffuser():
+    from types import SimpleNamespace as ns
+    from se3_diffusion_amd.data import se3_diffuser
+    dconf = ns(diffuse_trans=True, diffuse_rot=True, r3=ns(min_b=0.1, max_b=20.0, coordinate_scaling=0.1),
+               so3=ns(num_omega=1000, num_sigma=1000, min_sigma=0.1, max_sigma=1.5, schedule="logarithmic",
+                      cache_dir=os.environ.get("FD_IGSO3_CACHE", "/tmp/fd_igso3_cache_bench"), use_cached_score=False))
+    t0 = time.perf_counter()
+    diff = se3_diffuser.SE3Diffuser(dconf)
+    return diff, time.perf_counter() - t0
+
+
+def sampling_rates(dev, blocks, num_t_run, cases=((128, 1), (128, 8), (256, 1), (512, 1), (512, 8))):
+    """Bounded runs of the device-resident sampler: num_t_run diffusion steps (num_t_run + 1 network forwards) per case,
+    scaled to the 501 forwards of the reference's 500-step trajectory (config/inference.yaml:18-24)."""
+    from se3_diffusion_amd import sampler, train_step as ts
+    from se3_diffusion_amd.model.score_network import ScoreNetwork
+    diff, _ = make_diffuser()
+    torch.manual_seed(0)
+    model = ScoreNetwork(ts.base_model_conf(blocks), diff).to(dev)
+    ts.perturb_final_layers(model, seed=0)
+    model.eval()
+    gen = torch.Generator(device=dev).manual_seed(99)
+    out = {}
+    for N, B in cases:
+        def run(st=None):
+            feats = sampler.init_feats(diff, B, N, dev, generator=gen)
+            return sampler.sample(model, diff, feats, num_t=num_t_run, min_t=0.01, noise_scale=0.1, generator=gen, use_graph=True,
+                                  stats=st)
+        run()                                    # warm-up: allocator, tables
+        st = {}
+        r = run(st)
+        torch.cuda.synchronize()
+        assert torch.isfinite(r["rigids"]).all()
+        # loop_ms = the reverse loop (num_t_run steps = num_t_run network forwards incl. the last, frames-only one); the
+        # self-conditioning warm-up forward and the one-off graph capture of a trajectory are outside it -> scale to the
+        # 501 forwards of a 500-step trajectory
+        per_fwd = st["loop_ms"] * 1e-3 / num_t_run
+        out[f"N{N}_B{B}"] = {"backbones_per_s": round(B / (per_fwd * 501), 4), "ms_per_diffusion_step": round(per_fwd * 1e3, 3),
+                             "measured_steps": num_t_run}
+    return out
 
 
 def bench_sample(a, rank, world, dev, lib):
     """backbones/s of the full reverse diffusion (num_t steps = num_t + 1 network forwards + num_t - 1 reverse
     steps, config/inference.yaml:18-24): every rank samples its own batch of B backbones of length N; one bench
     'step' = one complete batch."""
-    from types import SimpleNamespace as ns
     from se3_diffusion_amd import sampler, train_step as ts
-    from se3_diffusion_amd.data import se3_diffuser
     from se3_diffusion_amd.model.score_network import ScoreNetwork
     N = a.n_res
     B = a.batch if a.batch > 0 else 1
-    dconf = ns(diffuse_trans=True, diffuse_rot=True, r3=ns(min_b=0.1, max_b=20.0, coordinate_scaling=0.1),
-               so3=ns(num_omega=1000, num_sigma=1000, min_sigma=0.1, max_sigma=1.5, schedule="logarithmic",
-                      cache_dir=os.environ.get("FD_IGSO3_CACHE", "/tmp/fd_igso3_cache_bench"), use_cached_score=False))
-    t_tab = time.perf_counter()
-    diff = se3_diffuser.SE3Diffuser(dconf)
-    t_tab = time.perf_counter() - t_tab
+    diff, t_tab = make_diffuser()
     torch.manual_seed(0)
     model = ScoreNetwork(ts.base_model_conf(a.blocks), diff).to(dev)
     ts.perturb_final_layers(model, seed=0)
@@ -135,7 +240,7 @@ def bench_sample(a, rank, world, dev, lib):
     for _ in range(a.warmup):
         step()
     barrier()
-    # per-kernel timing of the dominant kernel: HIP events around every fd_gemm launch of three network forwards
+    # per-kernel timing of the dominant kernel: HIP events around every profiled launch of three network forwards
     # on the stream they run on (the timed region below replays captured graphs, where events cannot be read back)
     pf = sampler.init_feats(diff, B, N, dev, generator=gen)
     lib.gemm_profile = []
@@ -156,7 +261,7 @@ def bench_sample(a, rank, world, dev, lib):
     dt = float(tmax.item())
     if rank != 0:
         return
-    tile, use_f, use_t, _n, tot_f, tot_t = dominant_gemm(prof)
+    tile, use_f, use_t, _n, tot_f, tot_t, _shape, _by = dominant_kernel(prof)
     kname, peak = _KERNELS[tile]
     achieved = use_f / max(use_t, 1e-9) / 1e12
     res = {
@@ -167,12 +272,10 @@ def bench_sample(a, rank, world, dev, lib):
         "config": {"workload": f"reverse diffusion, {a.num_t} steps (min_t 0.01, noise_scale 0.1, self-conditioning), per-GPU "
                                f"batch of {B} backbones x N={N}, config/base.yaml ScoreNetwork ({a.blocks} blocks), device-resident loop",
                    "parallelism": f"replicas x{world}", "ms_per_diffusion_step": round(dt / a.steps / a.num_t * 1e3, 3),
-                   "igso3_table_build_s": round(t_tab, 2),
-                   "arithmetic": "fp32 storage and accumulation everywhere; pair-level GEMMs = 3-term bf16 split on the bf16 MFMA (fp32-accurate, FD_GEMM_EXACT_F32=1 forces the fp32 MFMA), all other GEMMs fp32 MFMA, IGSO(3) fp64"},
+                   "igso3_table_build_s": round(t_tab, 2), "arithmetic": ARITH},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": None, "kernel": kname,
-                     "measured_on": "3 eager network forwards (HIP events per fd_gemm launch)",
-                     "gemm_time_frac_of_step": round(tot_t / 3 * (a.num_t + 1) * a.steps / dt, 4),
+                     "measured_on": "3 eager network forwards (HIP events per profiled launch)",
                      "step_model_tflops": round(tot_f / 3 * (a.num_t + 1) * a.steps / dt / 1e12, 2)},
     }
     print(json.dumps(res), flush=True)
@@ -198,25 +301,54 @@ def main():
     ts.perturb_final_layers(model, seed=0)
     fdist.broadcast_params(model)
     model.train()
-    batch = ts.synthetic_batch(B, N, dev, seed=100 + rank)
-    gt37, _ = ts.backbone_atoms(batch["rigids_0"], batch["torsion_angles_sin_cos"][..., 2, :])
     from se3_diffusion_amd.optim import FlatAdam
     # Adam (torch.optim.Adam's rule, lr 1e-4 as train_se3_diffusion.py:139) over flat parameter / gradient / moment
     # buffers: param.grad are views of ONE buffer (single RCCL all-reduce), the update is one launch
     opt = FlatAdam(model.parameters(), lr=1e-4)
     grads = opt
     model.accumulate_into_grad = True      # backward kernels accumulate straight into the flat all-reduce buffer
+    overlap = None
+    if world > 1 and os.environ.get("FD_DP_OVERLAP", "1") != "0":
+        # the all-reduce of a parameter group starts as soon as the backward pass has issued its last gradient launch
+        overlap = fdist.OverlapAllReduce(model, opt)
+        model._fd_grad_ready = overlap.ready
 
-    def step():
+    def make_batch(n, b, seed):
+        bt = ts.synthetic_batch(b, n, dev, seed=seed)
+        g37, _ = ts.backbone_atoms(bt["rigids_0"], bt["torsion_angles_sin_cos"][..., 2, :])
+        return bt, g37
+
+    if a.mixed_n:
+        # BASELINE configs[3]: the reference's DDP sampler hands every rank the same protein in a step
+        # (pdb_data_loader.py:467,483), i.e. all ranks share N; B = min(batch_size = 32, max_squared_res // N^2)
+        # (data/utils.py:395, base.yaml:83-84).  Lengths come from one seeded stream shared by all ranks; the batches are
+        # pre-generated so the timed region holds only the step.
+        import numpy as np
+        lens = np.random.RandomState(2024).randint(100, 513, size=a.warmup + a.steps)
+        sched = [(int(n), max(1, min(32, 500000 // (int(n) * int(n))))) for n in lens]
+        data = [make_batch(n, b, 1000 * i + rank) for i, (n, b) in enumerate(sched)]
+    else:
+        sched = [(N, B)] * (a.warmup + a.steps)
+        data = [make_batch(N, B, 100 + rank)] * (a.warmup + a.steps)
+
+    def step(i=0, self_cond=False):
+        batch, gt37 = data[i % len(data)]
         if a.mode == "forward":
             with torch.no_grad():
                 model(batch)
             return
+        if self_cond:                                # train_se3_diffusion.py:519-522,535-537
+            with torch.no_grad():
+                sc = model(batch)["rigids"][..., 4:]
+            batch = dict(batch, sc_ca_t=sc)
         grads.zero()
         out = model(batch)
         loss = floss.dsm_loss(batch, out, gt37)     # fused Experiment.loss_fn arithmetic (fd_dsm_loss)
         loss.backward()
-        grads.all_reduce_mean()
+        if overlap is not None:
+            overlap.finish()
+        else:
+            grads.all_reduce_mean()
         opt.step()
 
     def barrier():
@@ -225,23 +357,34 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    for i in range(a.warmup):
+        step(i)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    for i in range(a.steps):
+        step(a.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
-    # Per-launch HIP events are NOT recorded inside the timed region: 1200 event records per step cost ~2.5 ms of it
-    # (measured: 42.1 vs 39.3 ms in exact-fp32 mode), and with the weight-gradient GEMMs on a second stream a launch's
-    # start/stop events would span the kernels it shares the GPU with.  The roofline of the dominant kernel is taken
-    # from three more steps right after it, same shapes and data, with that side stream switched off (launches
-    # serialised) and events around every fd_gemm launch on the stream it runs on.
+    residues = sum(n * b for n, b in sched[a.warmup:])
+    # the reference's training step with its 50 % self-conditioning forward (every other step here), same shapes
+    sc_ms = None
+    if a.mode == "train" and not a.mixed_n:
+        k = max(2, a.steps - a.steps % 2)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(k):
+            step(i, self_cond=(i % 2 == 0))
+        barrier()
+        sc_ms = (time.perf_counter() - t0) / k * 1e3
+    # Per-launch HIP events are NOT recorded inside the timed region: 1200 event records per step cost ~2.5 ms of it,
+    # and with the weight-gradient GEMMs on a second stream a launch's start/stop events would span the kernels it shares
+    # the GPU with.  The roofline of the dominant kernel is taken from three more steps right after it, same shapes and
+    # data, with that side stream switched off (launches serialised) and events around every profiled launch on the
+    # stream it runs on.
     from se3_diffusion_amd import ops as fops
     side_was = fops.set_grad_stream(False)
     lib.gemm_profile = []
@@ -250,11 +393,11 @@ def main():
     torch.cuda.synchronize()
     prof, lib.gemm_profile = lib.gemm_profile, None
     fops.set_grad_stream(side_was)
-    # the same step with every GEMM on the exact fp32 MFMA (bitwise fmaf-chain products: FD_GEMM_EXACT_F32=1), so the
-    # line carries both arithmetic choices; not part of `value`
+    # the same step with every GEMM on the exact fp32 MFMA (bitwise fmaf-chain products: FD_GEMM_EXACT_F32=1; the fused
+    # edge-transition kernel off), so the line carries both arithmetic choices; not part of `value`
     exact_ms = None
-    if not os.environ.get("FD_BENCH_PROFILE"):     # (rocprofv3 runs: keep the kernel trace to the shipped arithmetic)
-        was_exact = lib.cdll.fd_gemm_set_exact_f32(1)
+    if not os.environ.get("FD_BENCH_PROFILE") and not a.mixed_n:   # (rocprofv3 runs: keep the trace to the shipped arithmetic)
+        was_exact = lib.set_exact_f32(True)
         step()
         barrier()
         t0 = time.perf_counter()
@@ -262,7 +405,7 @@ def main():
             step()
         barrier()
         exact_ms = (time.perf_counter() - t0) / 3 * 1e3
-        lib.cdll.fd_gemm_set_exact_f32(was_exact)
+        lib.set_exact_f32(was_exact)
 
     if rank != 0:
         return
@@ -275,36 +418,55 @@ def main():
         sys.stderr.write("tile akc bkc (M,N,K,batch,gate,beta,pair,ksplit)  calls/step  ms/step  TF/s\n")
         for k, v in rows[:40]:
             sys.stderr.write(f"{k}  {v[2] / 3:.1f}  {v[1] / 3 * 1e3:.3f}  {v[0] / v[1] / 1e12:.1f}\n")
-    tile, dflops, dtime, dn, all_flops, tot_t = dominant_gemm(prof)
+    tile, dflops, dtime, dn, all_flops, tot_t, dshape, by_tile = dominant_kernel(prof)
     kname, peak = _KERNELS[tile]
     achieved = dflops / dtime / 1e12
     nprof = 3
     ms = dt / a.steps * 1e3
+    traffic = _PMC_TRAFFIC.get((tile, dshape[0]))
+    workload = (f"config/base.yaml ScoreNetwork ({a.blocks} IPA blocks, 17.4M params), per-GPU batch "
+                + (f"B={B} x N={N} residues" if not a.mixed_n else
+                   "of same-length backbones, N ~ U{100..512} per step shared by all ranks, B = min(32, 5e5 // N^2) "
+                   "(BASELINE configs[3])")
+                + (", fwd + fused DSM loss + bwd + RCCL grad all-reduce + Adam" if a.mode == "train" else ", forward only"))
     res = {
         "metric": "residues/sec IPA fwd+bwd" if a.mode == "train" else "residues/sec IPA fwd",
-        "value": round(world * B * N * a.steps / dt, 1), "unit": "residues/s", "n_gpus": world,
+        "value": round(world * residues / dt, 1), "unit": "residues/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"config/base.yaml ScoreNetwork ({a.blocks} IPA blocks, 17.4M params), per-GPU batch "
-                               f"B={B} x N={N} residues, {'fwd + fused DSM loss + bwd + RCCL grad all-reduce + Adam' if a.mode == 'train' else 'forward only'}",
-                   "parallelism": f"dp{world}", "global_batch": world * B, "n_res": N,
+        "config": {"workload": workload, "parallelism": f"dp{world}", "global_batch": world * B, "n_res": N,
                    "ms_per_step_exact_f32_gemms": None if exact_ms is None else round(exact_ms, 3),
-                   "arithmetic": "fp32 storage and accumulation everywhere; pair-level GEMMs = 3-term bf16 split on the bf16 MFMA (fp32-accurate, FD_GEMM_EXACT_F32=1 forces the fp32 MFMA), all other GEMMs fp32 MFMA, IGSO(3) fp64"},
+                   "self_conditioning_50pct": None if sc_ms is None else {
+                       "ms_per_step": round(sc_ms, 3), "residues_per_s": round(world * B * N / sc_ms * 1e3, 1),
+                       "note": "every other step runs the reference's extra no-grad forward (train_se3_diffusion.py:535-537)"},
+                   "arithmetic": ARITH},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": None, "kernel": kname,
+                     "frac": round(achieved / peak, 4),
+                     "traffic": None if traffic is None else traffic["bytes_per_launch"], "kernel": kname,
                      "vs_fp32_mfma_peak": round(achieved / 157.3, 4),
-                     "traffic_note": "PMC (offline, profiles/r01_pmc_fd_gemm.md): 1.62 GB HBM per M=491520,N=K=384 launch "
-                                     "vs 1.51 GB algorithmic (FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                     "traffic_note": None if traffic is None else
+                     f"HBM bytes per forward launch from PMC, {traffic['source']}; algorithmic {traffic['algorithmic_bytes']:.3g} B",
                      "measured_on": "3 steps right after the timed region with the gradient side stream off "
-                                    "(HIP events per fd_gemm launch on its stream)",
+                                    "(HIP events per profiled launch on its stream)",
                      "launches_per_step": dn // nprof,
                      "avg_launch_us": round(dtime / max(1, dn) * 1e6, 2),
                      "algorithmic_flops_per_launch": round(dflops / max(1, dn), 1),
+                     "serialised_ms_per_step_by_kernel_class": {str(k): round(v / nprof, 3) for k, v in by_tile.items()},
                      "serialised_gemm_ms_per_step": round(tot_t / nprof * 1e3, 3),
                      "all_gemm_tflops": round(all_flops / max(tot_t, 1e-9) / 1e12, 2),
                      "step_model_tflops": round(all_flops / nprof / (dt / a.steps) / 1e12, 2)},
     }
-    if not a.no_cpu_baseline and world == 1:
+    if world == 1 and a.mode == "train" and not a.no_sampling and not a.mixed_n:
+        try:
+            data.clear()
+            torch.cuda.empty_cache()
+            res["config"]["sampling"] = dict(
+                sampling_rates(dev, a.blocks, a.sample_steps),
+                note=f"backbones/s of the 500-step reverse diffusion (501 network forwards), device-resident loop, one hipGraph per "
+                     f"step; bounded runs of {a.sample_steps} steps scaled to 501 forwards; full 500-step runs: profiles/")
+        except Exception as e:  # noqa: BLE001 -- must not lose the training measurement
+            res["config"]["sampling"] = {"error": repr(e)}
+    if not a.no_cpu_baseline and world == 1 and not a.mixed_n:
         try:
             res["cpu_baseline"] = cpu_baseline(N, a.blocks, a.cpu_sample_batch)
         except Exception as e:  # noqa: BLE001 -- the baseline must not lose the GPU measurement

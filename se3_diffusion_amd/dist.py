@@ -75,6 +75,73 @@ class FlatGrads:
             self.flat.div_(dist.get_world_size())
 
 
+class OverlapAllReduce:
+    """The gradient all-reduce in parameter groups, each started as soon as the backward pass has issued the group's last
+    gradient launch (trunk.backward's on_done): heads, trunk blocks nb-1 .. 0, embedder.  The groups are contiguous
+    ranges of the flat gradient buffer (named_parameters() order = embedding_layer, trunk block by block, torsion head),
+    so every call is one RCCL all-reduce on a slice -- issued from the gradient side stream, i.e. behind the weight-
+    gradient GEMMs that run there and, through the stream wait, behind the main stream's launches so far.
+
+        hook = OverlapAllReduce(model, opt)        # opt: optim.FlatAdam or dist.FlatGrads over model.parameters()
+        model._fd_grad_ready = hook.ready          # ScoreNetwork(accumulate_into_grad=True) forwards it to the backward
+        loss.backward(); hook.finish(); opt.step()
+    """
+
+    def __init__(self, model, flat):
+        self.flat = flat
+        self.buf = flat.flat_g if hasattr(flat, "flat_g") else flat.flat
+        offs = dict(zip((id(p) for p in flat.params), flat.offsets))
+        spans = {}
+        for name, p in model.named_parameters():
+            if id(p) not in offs:
+                continue
+            if name.startswith("embedding_layer."):
+                tag = "embed"
+            elif name.startswith("score_model.trunk."):
+                tag = int(name.split(".")[2].rsplit("_", 1)[1])      # ..._{b}
+            else:
+                tag = "heads"
+            lo, hi = offs[id(p)], offs[id(p)] + p.numel()
+            a, b = spans.get(tag, (lo, hi))
+            spans[tag] = (min(a, lo), max(b, hi))
+        # contiguity: the groups tile the buffer without interleaving
+        order = sorted(spans.items(), key=lambda kv: kv[1][0])
+        for (_, (_, hi)), (_, (lo, _)) in zip(order[:-1], order[1:]):
+            assert hi <= lo, "parameter groups interleave in the flat buffer"
+        self.spans = {k: (order[i][1][0], order[i + 1][1][0] if i + 1 < len(order) else self.buf.numel())
+                      for i, (k, _) in enumerate(order)}
+        self.handles, self.done = [], set()
+
+    def ready(self, tag):
+        if not (dist.is_initialized() and dist.get_world_size() > 1) or tag not in self.spans:
+            return
+        from . import ops
+        lo, hi = self.spans[tag]
+        chunk = self.buf[lo:hi]
+        st = ops.grad_stream(chunk.device) if chunk.is_cuda else None
+        if st is not None:
+            with torch.cuda.stream(st):
+                self.handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
+        self.done.add(tag)
+
+    def finish(self):
+        """After backward(): reduce whatever the hook was not called for, wait, average."""
+        if hasattr(self.flat, "rebind"):
+            self.flat.rebind()
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        for tag in self.spans:
+            if tag not in self.done:
+                lo, hi = self.spans[tag]
+                dist.all_reduce(self.buf[lo:hi], op=dist.ReduceOp.SUM)
+        for h in self.handles:
+            h.wait()
+        self.handles, self.done = [], set()
+        self.buf.div_(dist.get_world_size())
+
+
 def broadcast_params(module, src=0):
     """Replicate rank-`src` parameters and buffers (what DDP does at wrap time)."""
     if dist.is_initialized() and dist.get_world_size() > 1:

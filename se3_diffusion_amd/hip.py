@@ -162,6 +162,16 @@ class FdLib:
             fn.argtypes = [_CT[c] for c in sig]
         self.backend = self.cdll.fd_backend().decode()
         self.is_device = self.backend == "gfx950"
+        # mirror of the library's FD_GEMM_EXACT_F32 switch (the fused split-bf16 kernels consult it on the host side)
+        self.exact_f32 = os.environ.get("FD_GEMM_EXACT_F32", "0") not in ("", "0")
+
+    def set_exact_f32(self, exact: bool) -> bool:
+        """exact=True: every GEMM on the fp32-MFMA kernels (bitwise fmaf chains) and the fused split-bf16 kernels off
+        (fd_gemm_set_exact_f32).  Returns the previous setting."""
+        was = self.exact_f32
+        self.cdll.fd_gemm_set_exact_f32(1 if exact else 0)
+        self.exact_f32 = bool(exact)
+        return was
 
     # -- helpers ---------------------------------------------------------
     def _check(self, rc: int, what: str):

@@ -88,7 +88,7 @@ class _ScoreNetFn(torch.autograd.Function):
             # .grad (e.g. dist.FlatGrads: one flat buffer for the single RCCL all-reduce) the gradients are written
             # in place -- no 282 zero-fills + 282 autograd accumulation kernels per step
             G = {k: v.grad for k, v in P.items()}
-            trunk.backward(P, G, ctx.sv, d_out)
+            trunk.backward(P, G, ctx.sv, d_out, on_done=getattr(ctx.module, "_fd_grad_ready", None))
             ctx.sv = None
             return (None, None, None, None) + tuple(None for _ in names)
         G = {k: torch.zeros_like(v) for k, v in P.items()}

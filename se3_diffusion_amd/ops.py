@@ -93,6 +93,19 @@ def side(fn, tensors, rows):
     _SIDE["used"] = True
 
 
+def grad_stream(device):
+    """The gradient side stream of `device` (None when disabled or not a GPU): work queued on it after side_sync()
+    runs behind every gradient launch issued so far on either stream."""
+    if not (_SIDE["on"] and device.type == "cuda"):
+        return None
+    st = _SIDE["streams"].get(device.index)
+    if st is None:
+        st = _SIDE["streams"][device.index] = torch.cuda.Stream(device=device)
+    st.wait_stream(torch.cuda.current_stream())
+    _SIDE["used"] = True
+    return st
+
+
 def set_grad_stream(on):
     """Enable / disable the gradient side stream; returns the previous setting."""
     was = _SIDE["on"]
@@ -217,4 +230,16 @@ def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, 
             tens.append(t)
     d.rows, d.nres, d.backward, d.eps, d.blocks = int(rows), int(nres), int(bool(backward)), 1e-5, int(blocks)
     L = lib()
-    L._check(L.cdll.fd_edge_mlp(hip.ctypes.byref(d), L._stream(tens)), "fd_edge_mlp")
+    stream = L._stream(tens)
+    prof = L.gemm_profile
+    if prof is not None and L.is_device:
+        # same record layout as FdLib.gemm (tile code 7 = the fused edge-transition kernel); algorithmic flops of the
+        # chain: 2 * rows * (128*384 + 384*384 + 384*128 + 128*128)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L._check(L.cdll.fd_edge_mlp(hip.ctypes.byref(d), stream), "fd_edge_mlp")
+        e1.record()
+        prof.append((7, True, True, 2.0 * int(rows) * 262144, e0, e1, (int(rows), 128, 384, 1, int(bool(backward)), 0, 0, 1)))
+        return
+    L._check(L.cdll.fd_edge_mlp(hip.ctypes.byref(d), stream), "fd_edge_mlp")

@@ -35,10 +35,11 @@ def _f64(x, dev):
 
 @torch.no_grad()
 def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_condition=True, center=True,
-           generator=None, noise_fn=None, return_traj=False, use_graph=False):
+           generator=None, noise_fn=None, return_traj=False, use_graph=False, stats=None):
     """Run the reverse process on `feats` (from init_feats).  noise_fn(step, shape) -> (z_rot, z_trans) injects
     draws (e.g. the numpy stream, for trajectory parity); default draws on the device.
-    Returns dict(rigids [B,N,7], atom37 [B,N,37,3], psi, (rigid_traj list))."""
+    Returns dict(rigids [B,N,7], atom37 [B,N,37,3], psi, (rigid_traj list)).  `stats` (a dict) receives loop_ms = device
+    time of the reverse loop itself (HIP events; excludes the one-off warm-up + graph capture) and its step count."""
     dev = feats["rigids_t"].device
     B, N = feats["res_mask"].shape
     steps = np.linspace(min_t, 1.0, num_t)[::-1]
@@ -117,6 +118,9 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
             for k, v in saved.items():
                 st[k].copy_(v)
         out = None
+        if stats is not None and lib.is_device:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         for i, t in enumerate(steps):
             if t > min_t:
                 set_t(t)
@@ -132,6 +136,10 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
                 psi.copy_(out["psi"])
             if return_traj:
                 traj.append(st["rigids_t"].clone())
+        if stats is not None and lib.is_device:
+            ev1.record()
+            ev1.synchronize()
+            stats.update(loop_ms=ev0.elapsed_time(ev1), steps=len(steps), captured=graph is not None)
     finally:
         # an exception mid-trajectory must not leave the weight-derived cache, eval mode or the profiling switch behind
         model.__dict__.pop("_fd_static", None)

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from . import hip, ops
+from .trace import rng
 from . import network as nw
 from .network import CS, CZ, TD, H, _lin_grads
 from .ops import empty, zeros, mv, lib
@@ -58,13 +59,18 @@ def _edge_mlp_image(P, pre, cache, backward=False):
     return img
 
 
-FUSED_EDGE = os.environ.get("FD_EDGE_FUSED", "1") != "0"
+_FUSED_EDGE = os.environ.get("FD_EDGE_FUSED", "1") != "0"
+
+
+def fused_edge():
+    """The fused edge-transition kernel computes in split-bf16 (fp32-accurate): off in exact-fp32 mode."""
+    return _FUSED_EDGE and not lib().exact_f32
 
 
 def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None):
     """z' = emask * LN(W_f (relu(W_2 relu(W_1 x)) + x) + b_f), x = [z | e_i | e_j], e = W_init n3 -- the whole pair-level
     chain in ONE launch (fd_edge_mlp): h1 / h2 never reach HBM unless the backward needs them (save)."""
-    if not FUSED_EDGE:
+    if not fused_edge():
         return edge_transition_fwd_unfused(P, b, n3, z, emask, B, N)
     pre = f"score_model.trunk.edge_transition_{b}"
     dev = z
@@ -148,7 +154,8 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
     de = empty((R, CE), dev)
     ops.linear_dx(mv(dPf), (Wf, CZ, EH), mv(de), R, CZ, CE)
     ops.linear_dx(mv(dQf), (Wf, CZ + CE, EH), mv(de), R, CZ, CE, beta=True)
-    if FUSED_EDGE:
+    fused = fused_edge()
+    if fused:
         # the dX chain in one launch: d2 = [h2 > 0] dy Wf, d1 = [h1 > 0] d2 W2, dz = dy Wf_z + d1 W1_z (fd_edge_mlp with
         # the transposed weight image); d2 / d1 are written once, for the weight-gradient GEMMs and the pair reductions
         dh2 = empty((Pn, EH), dev); dh1 = empty((Pn, EH), dev)
@@ -175,7 +182,7 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
     ops.side(_grads_1, (dP1, dQ1, e), R)
     ops.linear_dx(mv(dP1), (W1, CZ, EH), mv(de), R, EH, CE, beta=True)
     ops.linear_dx(mv(dQ1), (W1, CZ + CE, EH), mv(de), R, EH, CE, beta=True)
-    if not FUSED_EDGE:
+    if not fused:
         ops.linear_dx(mv(dh1), (W1, 0, EH), mv(dz), Pn, EH, CZ, beta=True)          # dz += dh1 W1_z
     _lin_grads(G, f"{pre}.initial_embed.weight", f"{pre}.initial_embed.bias", mv(de), mv(sv["n3"]), R, CE, CS)
     ops.linear_dx(mv(de), mv(P[f"{pre}.initial_embed.weight"]), mv(dn3), R, CE, CS, beta=True)
@@ -335,7 +342,8 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
         if cache.get("_sig") != sig:
             cache.clear()
             cache["_sig"] = sig
-    node0, z, sv_embed = nw.embed_fwd(P, f, B, N, cache)
+    with rng("embed.fwd"):
+        node0, z, sv_embed = nw.embed_fwd(P, f, B, N, cache)
     emask = sv_embed["emask"]
 
     def _dmask():
@@ -356,35 +364,44 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
     stages = []
     for b in range(num_blocks):
         pre = f"score_model.trunk.ipa_{b}"
-        x1, sv_ipa = nw.ipa_fwd(P, pre, mv(node), z, quat, trans, mask.view(-1), B, N, cache)
-        u, sv_ln = nw.ln_skip_fwd(P, b, x1, init_node, R)
-        u0 = u
-        sv_t = []
-        for l in range(2):
-            u, s_ = nw.tfmr_layer_fwd(P, f"score_model.trunk.seq_tfmr_{b}.layers.{l}", u, key_add, B, N)
-            sv_t.append(s_)
-        if tfmr_bool_mask:
-            u2 = empty((R, TD), dev)
-            L.call("fd_rowscale", u, TD, mask.view(-1), u2, TD, R, TD)
-            u = u2
-        n3, sv_pn = nw.post_node_fwd(P, b, u, u0, mask.view(-1), R)
-        q2, t2, sv_bb = bb_update_fwd(P, b, n3, dmask.view(-1), quat, trans, R)
+        with rng(f"ipa_{b}.fwd"):
+            x1, sv_ipa = nw.ipa_fwd(P, pre, mv(node), z, quat, trans, mask.view(-1), B, N, cache)
+        with rng(f"seq_tfmr_{b}.fwd"):
+            u, sv_ln = nw.ln_skip_fwd(P, b, x1, init_node, R)
+            u0 = u
+            sv_t = []
+            for l in range(2):
+                u, s_ = nw.tfmr_layer_fwd(P, f"score_model.trunk.seq_tfmr_{b}.layers.{l}", u, key_add, B, N)
+                sv_t.append(s_)
+            if tfmr_bool_mask:
+                u2 = empty((R, TD), dev)
+                L.call("fd_rowscale", u, TD, mask.view(-1), u2, TD, R, TD)
+                u = u2
+        with rng(f"node_transition_{b}.fwd"):
+            n3, sv_pn = nw.post_node_fwd(P, b, u, u0, mask.view(-1), R)
+            q2, t2, sv_bb = bb_update_fwd(P, b, n3, dmask.view(-1), quat, trans, R)
         sv_et = None
         if b < num_blocks - 1:
-            z, sv_et = edge_transition_fwd(P, b, n3, z, emask, B, N, save=save, cache=cache)
+            with rng(f"edge_transition_{b}.fwd"):
+                z, sv_et = edge_transition_fwd(P, b, n3, z, emask, B, N, save=save, cache=cache)
         stages.append(dict(ipa=sv_ipa, ln=sv_ln, tfmr=sv_t, pn=sv_pn, bb=sv_bb, et=sv_et))
         node, quat, trans = n3, q2, t2
         if not save:
             stages[-1] = None
-    out, sv_h = heads_fwd(P, node, quat, trans, f, B, N, dconf)
+    with rng("heads.fwd"):
+        out, sv_h = heads_fwd(P, node, quat, trans, f, B, N, dconf)
     if not save:
         return out, None
     return out, dict(feats=f, embed=sv_embed, stages=stages, heads=sv_h, B=B, N=N, num_blocks=num_blocks,
                      bool_mask=tfmr_bool_mask, mask=mask, dmask=dmask)
 
 
-def backward(P, G, sv, d_out):
-    """Gradients of sum_k <d_out[k], out[k]> w.r.t. every parameter, accumulated into G."""
+def backward(P, G, sv, d_out, on_done=None):
+    """Gradients of sum_k <d_out[k], out[k]> w.r.t. every parameter, accumulated into G.
+    on_done(tag): called when every gradient launch of a parameter group has been ISSUED -- "heads", then block
+    nb-1 ... 0, then "embed" -- so a data-parallel caller can start that group's all-reduce under the rest of the
+    backward pass (dist.OverlapAllReduce)."""
+    notify = on_done if on_done is not None else (lambda tag: None)
     B, N, nb = sv["B"], sv["N"], sv["num_blocks"]
     R, Pn = B * N, B * N * N
     f = sv["feats"]
@@ -392,7 +409,9 @@ def backward(P, G, sv, d_out):
     if sv["bool_mask"]:
         raise NotImplementedError("backward is defined for the training-mode (additive) transformer mask")
     dnode = zeros((R, CS), dev)
-    dq, dt = heads_bwd(P, G, sv["heads"], f, d_out, dnode)
+    with rng("heads.bwd"):
+        dq, dt = heads_bwd(P, G, sv["heads"], f, d_out, dnode)
+    notify("heads")
     dinit = zeros((R, CS), dev)
     dz = None
     for b in reversed(range(nb)):
@@ -401,29 +420,36 @@ def backward(P, G, sv, d_out):
         dz_in = None
         if st["et"] is not None:
             dz_in = empty((Pn, CZ), dev)
-            edge_transition_bwd(P, G, b, st["et"], dz, dz_in, dn3)
+            with rng(f"edge_transition_{b}.bwd"):
+                edge_transition_bwd(P, G, b, st["et"], dz, dz_in, dn3)
         dframe = zeros((R, 12), dev)
         # IPA backward needs dx1, which needs dn3 complete (incl. bb_update's contribution), but bb_update's
         # input-frame gradient needs the IPA's dframe: split bb_update in two steps via a zero dframe first.
-        dq_in, dt_in = bb_update_bwd(P, G, b, st["bb"], dq, dt, None, dn3)
-        du0 = zeros((R, TD), dev)
-        du2 = nw.post_node_bwd(P, G, b, st["pn"], dn3, du0)
-        du = du2
-        for l in reversed(range(2)):
-            du = nw.tfmr_layer_bwd(P, G, f"score_model.trunk.seq_tfmr_{b}.layers.{l}", st["tfmr"][l], du)
-        ops.add_view(mv(du0), mv(du), R, TD)
-        dx1 = empty((R, CS), dev)
-        nw.ln_skip_bwd(P, G, b, st["ln"], du0, dx1, dinit)
+        with rng(f"node_transition_{b}.bwd"):
+            dq_in, dt_in = bb_update_bwd(P, G, b, st["bb"], dq, dt, None, dn3)
+            du0 = zeros((R, TD), dev)
+            du2 = nw.post_node_bwd(P, G, b, st["pn"], dn3, du0)
+        with rng(f"seq_tfmr_{b}.bwd"):
+            du = du2
+            for l in reversed(range(2)):
+                du = nw.tfmr_layer_bwd(P, G, f"score_model.trunk.seq_tfmr_{b}.layers.{l}", st["tfmr"][l], du)
+            ops.add_view(mv(du0), mv(du), R, TD)
+            dx1 = empty((R, CS), dev)
+            nw.ln_skip_bwd(P, G, b, st["ln"], du0, dx1, dinit)
         ds = zeros((R, CS), dev)
         if dz_in is None:
             dz_in = zeros((Pn, CZ), dev)
-        nw.ipa_bwd(P, G, f"score_model.trunk.ipa_{b}", st["ipa"], dx1, mv(ds), dz_in, dframe)
+        with rng(f"ipa_{b}.bwd"):
+            nw.ipa_bwd(P, G, f"score_model.trunk.ipa_{b}", st["ipa"], dx1, mv(ds), dz_in, dframe)
         # fold the IPA frame gradients (dL/dR, dL/dt of the block's input frame) into (dq, dt)
         _frame_grad_fold(st["bb"]["quat"], dframe, dq_in, dt_in, R)
         dq, dt, dnode, dz = dq_in, dt_in, ds, dz_in
+        notify(b)
     # node = init_node at block 0 input; both carry gradient into the node embedder
     ops.add_view(mv(dnode), mv(dinit), R, CS)
-    nw.embed_bwd(P, G, sv["embed"], dnode, dz)
+    with rng("embed.bwd"):
+        nw.embed_bwd(P, G, sv["embed"], dnode, dz)
+    notify("embed")
     ops.join_grad_stream()   # the node-level weight gradients ran beside the dX chain (ops.side)
 
 

@@ -102,3 +102,98 @@ def test_shard_indices():
     from se3_diffusion_amd import dist as fdist
     got = sorted(i for r in range(4) for i in fdist.shard_indices(10, r, 4))
     assert got == list(range(10))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the real ScoreNetwork (kernel sources under the host interpreter, 1 block, N = 8): 2 ranks x B = 1 == 1 rank x B = 2
+# ---------------------------------------------------------------------------------------------------------------------
+def _sn_setup(emu_path):
+    from oracle import framediff_oracle as fo
+    from se3_diffusion_amd import hip, train_step as ts
+    from se3_diffusion_amd.model.score_network import ScoreNetwork
+    hip._TEST_OVERRIDE = hip.FdLib(emu_path)
+    conf = dict(fo.CONF, num_blocks=1)
+    model = ScoreNetwork(ts.base_model_conf(1), diffuser=None)
+    model.load_state_dict(fo.synth_params(seed=3, conf=conf), strict=True)
+    model.train()
+    batch = ts.synthetic_batch(2, 8, "cpu", seed=9)
+    gt37, _ = fo.backbone_atoms(batch["rigids_0"][..., :4], batch["rigids_0"][..., 4:], batch["torsion_angles_sin_cos"][..., 2, :])
+    return model, batch, gt37, ts
+
+
+def _sn_loss(ts, model, batch, gt37, sl):
+    b = {k: v[sl] for k, v in batch.items()}
+    return ts.dsm_loss(b, model(b), gt37[sl])
+
+
+def _sn_worker(rank, world, port, q, emu_path, mode):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from se3_diffusion_amd import dist as fdist
+    fdist.init_from_env(backend="gloo")
+    model, batch, gt37, ts = _sn_setup(emu_path)
+    sl = slice(rank, rank + 1)                                  # backbone i -> rank i (shard_indices(2, rank, 2))
+    assert fdist.shard_indices(2, rank, world) == [rank]
+    names = [n for n, _ in model.named_parameters()]
+    if mode == "flat":
+        from se3_diffusion_amd.optim import FlatAdam
+        opt = FlatAdam(model.parameters(), lr=1e-3)
+        model.accumulate_into_grad = True                       # gradients are written straight into the all-reduce buffer
+        hook = fdist.OverlapAllReduce(model, opt)               # per-group all-reduce from inside the backward (bench.py, N > 1)
+        model._fd_grad_ready = hook.ready
+        assert set(hook.spans) == {"embed", 0, "heads"} and sum(b - a for a, b in hook.spans.values()) == opt.numel
+        opt.zero_grad()
+        _sn_loss(ts, model, batch, gt37, sl).backward()
+        assert hook.done == {"embed", 0, "heads"}
+        hook.finish()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        opt.step()
+    else:
+        # the reference's own wrapping (train_se3_diffusion.py:273-277): DistributedDataParallel with
+        # find_unused_parameters=True (linear_rbf / torsion_pred.linear_3 never receive gradient)
+        ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        opt.zero_grad()
+        _sn_loss(ts, ddp, batch, gt37, sl).backward()
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()}
+        opt.step()
+    q.put((rank, {n: g.double().numpy() for n, g in grads.items()},
+           torch.cat([p.detach().reshape(-1) for p in model.parameters()]).double().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _sn_single(emu_path):
+    from se3_diffusion_amd import hip
+    model, batch, gt37, ts = _sn_setup(emu_path)
+    # DP averages the per-rank losses (each normalised by its own example count: B = 1 per rank)
+    loss = 0.5 * (_sn_loss(ts, model, batch, gt37, slice(0, 1)) + _sn_loss(ts, model, batch, gt37, slice(1, 2)))
+    loss.backward()
+    hip._TEST_OVERRIDE = None
+    return {n: (p.grad.double() if p.grad is not None else torch.zeros_like(p).double()) for n, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("mode", ["flat", "ddp"])
+def test_score_network_data_parallel_matches_single_process(emu_lib, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sn_worker, args=(r, 2, port, q, emu_lib.path, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (g, torch.tensor(w)) for r, g, w in (q.get(timeout=600) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert torch.equal(res[0][1], res[1][1])                    # replicas stay bit-identical after the optimiser step
+    ref = _sn_single(emu_lib.path)
+    # the all-reduced gradient == the gradient of the single-process two-backbone loss, to fp32 round-off (compared
+    # before Adam: its normalised update turns the round-off of analytically-zero gradients into +-lr steps)
+    bad = []
+    for n, g in ref.items():
+        got = torch.tensor(res[0][0][n])
+        err = float((got - g).abs().max())
+        if err > 2e-5 * float(g.abs().max()) + 1e-7:
+            bad.append((n, err, float(g.abs().max())))
+    assert not bad, bad[:8]

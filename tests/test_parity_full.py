@@ -10,7 +10,7 @@ Two checkers, both at FULL depth (4 blocks):
 Every case runs three times: with the shipped GEMM selection, with the persistent split-bf16 kernel forced on
 (fd_gemm_set_persistent_blocks(8): the B=30 configuration's kernel at a size the oracle can check; at N=256 the
 M >= 65536 weight-gradient tiles 4/6 engage by themselves) and with FD_GEMM_EXACT_F32 (every GEMM a bitwise fp32
-fmaf chain).
+fmaf chain; the fused split-bf16 edge-transition kernel is then replaced by the unfused fp32 launch sequence).
 
 Tolerances (fp32, the table in DESIGN.md "Numerics"): outputs 2e-4 of the tensor's max magnitude (rot_score 1e-3),
 parameter gradients 2e-3 of the tensor's max magnitude + 2e-5 absolute (analytically-zero gradients).
@@ -44,11 +44,11 @@ class gemm_mode:
     def __enter__(self):
         c = self.lib.cdll
         self.was_p = c.fd_gemm_set_persistent_blocks(8 if self.mode == "persistent" else 256)
-        self.was_e = c.fd_gemm_set_exact_f32(1 if self.mode == "exact_f32" else 0)
+        self.was_e = self.lib.set_exact_f32(self.mode == "exact_f32")
 
     def __exit__(self, *a):
         self.lib.cdll.fd_gemm_set_persistent_blocks(self.was_p)     # the setters return the previous value
-        self.lib.cdll.fd_gemm_set_exact_f32(self.was_e)
+        self.lib.set_exact_f32(self.was_e)
 
 
 def _check_outputs(out, ref):
