@@ -144,6 +144,41 @@ typedef struct FdEdgeMlpDesc {
 } FdEdgeMlpDesc;
 int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream);
 
+/* ---- edge embedder, fused (model/score_network.py:97-101,129-153 Embedder edge path, data/utils.py:570-580) ----
+ * One kernel builds the 120-d pair feature on the fly and runs the MLP 120 -> 128 -> 128 -> 128 + LayerNorm + pair mask
+ * in the registers of the wave that owns the pair row (se3_diffusion_amd/csrc/fd_edge_embed.hip).  The part of the first
+ * layer that depends on one residue only arrives as p[b,i] = W0[:, 0:33] pt_i + b0 and q[b,j] = W0[:, 33:66] pt_j
+ * (pt = [t-emb(32) | fixed]); the kernel adds W0[:, 66:120] [relpos sincos(32) | distogram(22)].  The image packs
+ * W0[:, 66:120], W2, W4 ([128,120], [128,128], [128,128] row-major) as bf16 planes (FD_EDGE_EMBED_IMAGE_BYTES). */
+#define FD_EDGE_EMBED_IMAGE_BYTES (20 * 12288)
+int fd_edge_embed_pack(const float* W0, const float* W2, const float* W4, void* image, void* stream);
+typedef struct FdEdgeEmbedDesc {
+  const long* seq_idx;    /* [B*nres] */
+  const float* sc_ca;     /* [B*nres,3] self-conditioning CA positions (A) */
+  const float* idenom;    /* [16] index-embedding denominators (host table, score_network.py:26-29) */
+  const float* dg_lower;  /* [22] distogram bin edges (data/utils.py:573-578) */
+  const float* dg_upper;  /* [22] */
+  const void* img;
+  const float* p;         /* [B*nres,128] */
+  const float* q;         /* [B*nres,128] */
+  const float* bias2;     /* [128] */
+  const float* bias3;     /* [128] */
+  const float* gamma;     /* LayerNorm weight [128] */
+  const float* beta;      /* LayerNorm bias [128] */
+  const float* rowscale;  /* optional [rows] pair mask */
+  float* h1;              /* optional saves for the backward: [rows,128] post-ReLU layer 1 */
+  float* h2;              /* ... layer 2 */
+  float* h3;              /* ... layer 3 (pre-LayerNorm) */
+  float* mean;            /* optional [rows] */
+  float* rstd;            /* optional [rows] */
+  float* out;             /* [rows,128] */
+  long rows;              /* B * nres * nres */
+  int nres;
+  float eps;
+  int blocks;             /* 0 = one persistent block per CU (256) */
+} FdEdgeEmbedDesc;
+int fd_edge_embed(const FdEdgeEmbedDesc* desc, void* stream);
+
 /* ---- embedder features: score_network.py:14-47,97-148; data/utils.py:570-580 ----
  * tscaled = (t*1e4) as fp32 [B]; tfreq[16], idenom[16], dg_lower[22], dg_upper[22] are the
  * host-computed tables of the reference's own op sequence. */

@@ -88,6 +88,19 @@ class FdEdgeMlpDesc(Structure):
 EDGE_MLP_IMAGE_BYTES = 128 * 12288
 
 
+class FdEdgeEmbedDesc(Structure):
+    _fields_ = [
+        ("seq_idx", c_void_p), ("sc_ca", c_void_p), ("idenom", c_void_p), ("dg_lower", c_void_p), ("dg_upper", c_void_p),
+        ("img", c_void_p), ("p", c_void_p), ("q", c_void_p), ("bias2", c_void_p), ("bias3", c_void_p),
+        ("gamma", c_void_p), ("beta", c_void_p), ("rowscale", c_void_p),
+        ("h1", c_void_p), ("h2", c_void_p), ("h3", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("out", c_void_p),
+        ("rows", c_long), ("nres", c_int), ("eps", c_float), ("blocks", c_int),
+    ]
+
+
+EDGE_EMBED_IMAGE_BYTES = 20 * 12288
+
+
 def _ptr(t, off=0):
     """Raw address of a tensor (plus an element offset)."""
     if t is None:
@@ -106,6 +119,8 @@ _SIGS = {
     "fd_gemm_set_persistent_blocks": "i",
     "fd_edge_mlp_pack": "pllpllpllpllps",
     "fd_edge_mlp": "Ss",
+    "fd_edge_embed_pack": "pppps",
+    "fd_edge_embed": "Ss",
     "fd_layernorm_fwd": "plpppplpplifs",
     "fd_layernorm_bwd": "plplpppppl" + "ipplis",
     "fd_colsum_acc": "pllips",

@@ -18,6 +18,7 @@ Stage list per trunk block b (A3 of SURVEY.md):
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -89,7 +90,15 @@ def mlp3_ln_bwd(P, G, pre, sv, dy):
     _lin_grads(G, f"{pre}.0.weight", f"{pre}.0.bias", mv(dh1), sv["x"], M, Cc, K0)
 
 
-def embed_fwd(P, feats, B, N, cache=None):
+_FUSED_EMBED = os.environ.get("FD_EMBED_FUSED", "1") != "0"
+
+
+def fused_embed():
+    """The fused edge-embedder kernel computes in split-bf16 (fp32-accurate): off in exact-fp32 mode."""
+    return _FUSED_EMBED and not lib().exact_f32
+
+
+def embed_fwd(P, feats, B, N, cache=None, save=True):
     dev = feats["res_mask"]
     mask = feats["res_mask"]
     tfreq, idenom, lower, upper = ops.feature_tables(dev.device)
@@ -100,18 +109,56 @@ def embed_fwd(P, feats, B, N, cache=None):
     nf = empty((R, 65), dev)
     lib().call("fd_node_feats", seq, tscaled, fixed, tfreq, idenom, nf, B, N)
     node, sv_n = mlp3_ln_fwd(P, "embedding_layer.node_embedder", mv(nf), R, 65, CS, mask)
-    ef = empty((Pn, 120), dev)
-    lib().call("fd_edge_feats", seq, tscaled, fixed, feats["sc_ca_t"], tfreq, idenom, lower, upper, ef, B, N)
     emask = pair_mask(mask, B, N) if cache is None else cache.setdefault("emask", None)
     if emask is None:
         emask = cache["emask"] = pair_mask(mask, B, N)
-    edge, sv_e = mlp3_ln_fwd(P, "embedding_layer.edge_embedder", mv(ef), Pn, 120, CZ, emask)
+    pre = "embedding_layer.edge_embedder"
+    if not fused_embed():
+        ef = empty((Pn, 120), dev)
+        lib().call("fd_edge_feats", seq, tscaled, fixed, feats["sc_ca_t"], tfreq, idenom, lower, upper, ef, B, N)
+        edge, sv_e = mlp3_ln_fwd(P, pre, mv(ef), Pn, 120, CZ, emask)
+        return node, edge, dict(node=sv_n, edge=sv_e, emask=emask)
+    # fused: no [P,120] feature tensor, no hidden activations in HBM.  The residue-only part of the first layer
+    # (t-embedding + fixed flag of i and of j = the first 33 columns of the node feature) is node-level:
+    # p = W0[:, 0:33] pt + b0, q = W0[:, 33:66] pt
+    W0 = P[f"{pre}.0.weight"]
+    p_ = empty((R, CZ), dev); q_ = empty((R, CZ), dev)
+    ops.linear((nf, 0, 65), (W0, 0, 120), P[f"{pre}.0.bias"], mv(p_), R, CZ, 33)
+    ops.linear((nf, 0, 65), (W0, 33, 120), None, mv(q_), R, CZ, 33)
+    key = ("ee_img", pre)
+    if cache is not None and key in cache:
+        img = cache[key]
+    else:
+        img = ops.edge_embed_pack(W0, P[f"{pre}.2.weight"], P[f"{pre}.4.weight"])
+        if cache is not None:
+            cache[key] = img
+    edge = empty((Pn, CZ), dev)
+    kw = {}
+    if save:
+        h1 = empty((Pn, CZ), dev); h2 = empty((Pn, CZ), dev); h3 = empty((Pn, CZ), dev)
+        mean = empty((Pn,), dev); rstd = empty((Pn,), dev)
+        kw = dict(h1=h1, h2=h2, h3=h3, mean=mean, rstd=rstd)
+    ops.edge_embed(seq, feats["sc_ca_t"], idenom, lower, upper, img, p_, q_, P[f"{pre}.2.bias"], P[f"{pre}.4.bias"],
+                   P[f"{pre}.5.weight"], P[f"{pre}.5.bias"], edge, Pn, N, rowscale=emask, **kw)
+    sv_e = None
+    if save:
+        # the backward is the unfused MLP backward; its first-layer weight gradient needs the [P,120] feature tensor,
+        # which is regenerated there (embed_bwd) instead of being kept alive through the whole step
+        sv_e = dict(x=None, h1=h1, h2=h2, h3=h3, mean=mean, rstd=rstd, rowscale=emask, M=Pn, K0=120, C=CZ,
+                    regen=(seq, tscaled, fixed, feats["sc_ca_t"], B, N))
     return node, edge, dict(node=sv_n, edge=sv_e, emask=emask)
 
 
 def embed_bwd(P, G, sv, dnode, dedge):
     mlp3_ln_bwd(P, G, "embedding_layer.node_embedder", sv["node"], dnode)
-    mlp3_ln_bwd(P, G, "embedding_layer.edge_embedder", sv["edge"], dedge)
+    se = sv["edge"]
+    if se.get("x") is None:
+        seq, tscaled, fixed, sc, B, N = se["regen"]
+        tfreq, idenom, lower, upper = ops.feature_tables(dedge.device)
+        ef = empty((B * N * N, 120), dedge)
+        lib().call("fd_edge_feats", seq, tscaled, fixed, sc, tfreq, idenom, lower, upper, ef, B, N)
+        se = dict(se, x=mv(ef))
+    mlp3_ln_bwd(P, G, "embedding_layer.edge_embedder", se, dedge)
 
 
 def pair_mask(mask, B, N):

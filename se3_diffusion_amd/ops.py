@@ -243,3 +243,38 @@ def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, 
         prof.append((7, True, True, 2.0 * int(rows) * 262144, e0, e1, (int(rows), 128, 384, 1, int(bool(backward)), 0, 0, 1)))
         return
     L._check(L.cdll.fd_edge_mlp(hip.ctypes.byref(d), stream), "fd_edge_mlp")
+
+
+# ---------------------------------------------------------------------------
+# fused edge embedder (csrc/fd_edge_embed.hip)
+# ---------------------------------------------------------------------------
+def edge_embed_pack(W0, W2, W4, out=None):
+    img = out if out is not None else torch.empty(hip.EDGE_EMBED_IMAGE_BYTES, dtype=torch.uint8, device=W0.device)
+    lib().call("fd_edge_embed_pack", W0, W2, W4, img)
+    return img
+
+
+def edge_embed(seq_idx, sc_ca, idenom, dg_lower, dg_upper, img, p, q, bias2, bias3, gamma, beta, out, rows, nres, *,
+               rowscale=None, h1=None, h2=None, h3=None, mean=None, rstd=None, blocks=0):
+    d = hip.FdEdgeEmbedDesc()
+    tens = []
+    for name, t in (("seq_idx", seq_idx), ("sc_ca", sc_ca), ("idenom", idenom), ("dg_lower", dg_lower), ("dg_upper", dg_upper),
+                    ("img", img), ("p", p), ("q", q), ("bias2", bias2), ("bias3", bias3), ("gamma", gamma), ("beta", beta),
+                    ("rowscale", rowscale), ("h1", h1), ("h2", h2), ("h3", h3), ("mean", mean), ("rstd", rstd), ("out", out)):
+        setattr(d, name, None if t is None else t.data_ptr())
+        if t is not None:
+            tens.append(t)
+    d.rows, d.nres, d.eps, d.blocks = int(rows), int(nres), 1e-5, int(blocks)
+    L = lib()
+    stream = L._stream(tens)
+    prof = L.gemm_profile
+    if prof is not None and L.is_device:
+        # profile record (tile code 8): algorithmic flops of the per-pair part: 2 * rows * (54 + 128 + 128) * 128
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L._check(L.cdll.fd_edge_embed(hip.ctypes.byref(d), stream), "fd_edge_embed")
+        e1.record()
+        prof.append((8, True, True, 2.0 * int(rows) * 310 * 128, e0, e1, (int(rows), 128, 128, 1, 0, 0, 0, 1)))
+        return
+    L._check(L.cdll.fd_edge_embed(hip.ctypes.byref(d), stream), "fd_edge_embed")

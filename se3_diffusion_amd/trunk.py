@@ -343,7 +343,7 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
             cache.clear()
             cache["_sig"] = sig
     with rng("embed.fwd"):
-        node0, z, sv_embed = nw.embed_fwd(P, f, B, N, cache)
+        node0, z, sv_embed = nw.embed_fwd(P, f, B, N, cache, save=save)
     emask = sv_embed["emask"]
 
     def _dmask():
