@@ -10,11 +10,15 @@
 // stream through a two-stage LDS ring by LDS-DMA.
 #pragma once
 
-constexpr int EM_ROWS = 128;               // rows per block tile (8 waves x 16)
+#ifndef EM_WAVES
+#define EM_WAVES 4                         // waves per block (8 or 4); a stage holds EM_WAVES / 2 units so that every wave
+#endif                                     // copies 6 KB (six 1 KB LDS-DMA pieces) of it
+constexpr int EM_ROWS = 16 * EM_WAVES;     // rows per block tile
 constexpr int EM_PIECE = 1024;             // one fragment: 64 lanes x 16 B
 constexpr int EM_UNIT = 12 * EM_PIECE;     // 4 n-blocks x 3 planes
-constexpr int EM_UPS = 4;                  // units per stage
-constexpr int EM_STAGE = EM_UPS * EM_UNIT; // 48 KB
+constexpr int EM_UPS = EM_WAVES / 2;       // units per stage
+constexpr int EM_STAGE = EM_UPS * EM_UNIT; // 48 KB (8 waves) / 24 KB (4 waves)
+constexpr int EM_BLOCKS_PER_CU = 8 / EM_WAVES;
 
 __device__ __forceinline__ void em_split8(const float (&x)[8], uint4& s0, uint4& s1, uint4& s2) {
   unsigned t0[4], t1[4], t2[4];

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void edge_embed_pack_kernel(const float* __res
   *reinterpret_cast<uint4*>(dst + 2 * EM_PIECE) = s2;
 }
 
-__global__ __launch_bounds__(512, 2) void edge_embed_kernel(FdEdgeEmbedDesc d) {
+__global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_kernel(FdEdgeEmbedDesc d) {
   __shared__ __attribute__((aligned(16))) char lds[2 * EM_STAGE];
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -64,8 +64,8 @@ __global__ __launch_bounds__(512, 2) void edge_embed_kernel(FdEdgeEmbedDesc d) {
   const int total_stages = nmine * EE_NSTAGE;
 
   // ---- weight stream (as fd_edge_mlp.hip): every wave copies an eighth of each stage; stage s lives in buffer s & 1 ----
-  const char* __restrict__ img_lane = static_cast<const char*>(d.img) + wave * (EM_STAGE / 8) + lane * 16;
-  char* const lds_wave = lds + wave * (EM_STAGE / 8);
+  const char* __restrict__ img_lane = static_cast<const char*>(d.img) + wave * (EM_STAGE / EM_WAVES) + lane * 16;
+  char* const lds_wave = lds + wave * (EM_STAGE / EM_WAVES);
   int issued = 0, consumed = 0;
   auto issue_stage = [&]() {
     const char* src = img_lane + (long)(issued % EE_NSTAGE) * EM_STAGE;
@@ -131,12 +131,13 @@ __global__ __launch_bounds__(512, 2) void edge_embed_kernel(FdEdgeEmbedDesc d) {
       const float4 qa = *reinterpret_cast<const float4*>(d.q + qj * EE_C + 16 * nb + 4 * g);
       acc1[nb][0] = pa.x + qa.x; acc1[nb][1] = pa.y + qa.y; acc1[nb][2] = pa.z + qa.z; acc1[nb][3] = pa.w + qa.w;
     }
-    {
+#pragma clang loop unroll(full)
+    for (int sg = 0; sg < 4 / EM_UPS; ++sg) {
       const char* st = stage_begin();
       em16_read_half(H[0], st);
 #pragma clang loop unroll(full)
       for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
-        const int r = hh >> 1, g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
+        const int r = EM_UPS * sg + (hh >> 1), g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
         if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
         fd::sched_pin();
         if (g2 == 0 && (hh & 1) == 0) {
@@ -165,12 +166,12 @@ __global__ __launch_bounds__(512, 2) void edge_embed_kernel(FdEdgeEmbedDesc d) {
       acc3[nb][0] = b3.x; acc3[nb][1] = b3.y; acc3[nb][2] = b3.z; acc3[nb][3] = b3.w;
     }
 #pragma clang loop unroll(full)
-    for (int sg = 0; sg < 2; ++sg) {
+    for (int sg = 0; sg < 8 / EM_UPS; ++sg) {
       const char* st = stage_begin();
       em16_read_half(H[0], st);
 #pragma clang loop unroll(full)
       for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
-        const int r = 4 * sg + (hh >> 1), ks = r >> 1, g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
+        const int r = EM_UPS * sg + (hh >> 1), ks = r >> 1, g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
         if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
         fd::sched_pin();
         if (g2 == 0 && (hh & 1) == 0) em16_split2(acc1[2 * ks], acc1[2 * ks + 1], b[0], b[1], b[2]);
@@ -187,12 +188,12 @@ __global__ __launch_bounds__(512, 2) void edge_embed_kernel(FdEdgeEmbedDesc d) {
             make_float4(acc2[nb][0], acc2[nb][1], acc2[nb][2], acc2[nb][3]);
     }
 #pragma clang loop unroll(full)
-    for (int sg = 0; sg < 2; ++sg) {
+    for (int sg = 0; sg < 8 / EM_UPS; ++sg) {
       const char* st = stage_begin();
       em16_read_half(H[0], st);
 #pragma clang loop unroll(full)
       for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
-        const int r = 4 * sg + (hh >> 1), ks = r >> 1, g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
+        const int r = EM_UPS * sg + (hh >> 1), ks = r >> 1, g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
         if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
         fd::sched_pin();
         if (g2 == 0 && (hh & 1) == 0) em16_split2(acc2[2 * ks], acc2[2 * ks + 1], b[0], b[1], b[2]);
@@ -267,8 +268,8 @@ extern "C" int fd_edge_embed(const FdEdgeEmbedDesc* desc, void* stream) {
   for (const void* p : ptrs) FD_CHECK_ARG(fd_aligned16(p), "fd_edge_embed: operands must be 16-byte aligned");
   if (d.rows == 0) return FD_OK;
   const long ntiles = (d.rows + EM_ROWS - 1) / EM_ROWS;
-  const int blocks = d.blocks > 0 ? d.blocks : 256;   // MI355X: one persistent block per CU
-  hipLaunchKernelGGL(edge_embed_kernel, dim3((unsigned)(ntiles < blocks ? ntiles : blocks)), dim3(512), 0,
+  const int blocks = d.blocks > 0 ? d.blocks : 256 * EM_BLOCKS_PER_CU;   // MI355X: persistent blocks fill the 256 CUs
+  hipLaunchKernelGGL(edge_embed_kernel, dim3((unsigned)(ntiles < blocks ? ntiles : blocks)), dim3(64 * EM_WAVES), 0,
                      (hipStream_t)stream, d);
   FD_CHECK_LAUNCH("fd_edge_embed");
   return FD_OK;

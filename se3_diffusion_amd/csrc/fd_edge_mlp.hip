@@ -19,13 +19,15 @@
 // the kernel consumes them: staging is a straight LDS-DMA copy (global_load_lds_dwordx4, no VGPRs, no VALU) and every
 // fragment read a conflict-free ds_read_b128 of a lane-linear 1 KB piece (PMC: SQ_LDS_BANK_CONFLICT = 0).
 //
-// Block = 8 waves x 16 rows = 128-row tiles, persistent (one block per CU walks the tiles), <= 256 registers per wave
-// so that TWO waves share a SIMD: while one waits (LDS fragment, pair-term load, barrier) the other feeds the matrix
-// pipe.  (Measured against the first version -- 4 waves x 32 rows, v_mfma_f32_32x32x16_bf16, one 512-register wave
-// per SIMD, every wait of the in-order stream = MFMA idle time: pipe busy 40 % -> 50 %, 1.47 -> 1.27 ms at
-// B=30 x N=128; unfused launch sequence 2.11 ms.)  Per tile the weight stream is 128 units of 12 KB (4 n-blocks of 16 x
-// one 32-k step x 3 planes), grouped in 32 stages of 48 KB through a two-stage LDS ring; stage s+1 is in flight
-// while stage s is multiplied:
+// Block = 4 waves x 16 rows = 64-row tiles, persistent, TWO blocks per CU (<= 256 registers per wave, 48 KB of LDS per
+// block): two waves share a SIMD, so while one waits (LDS fragment, pair-term load, barrier) the other feeds the matrix
+// pipe, and the two blocks of a CU drift apart, so one block's barrier / epilogue runs under the other's MFMAs.
+// Measured at B=30 x N=128 (491,520 rows): first version -- 4 waves x 32 rows, v_mfma_f32_32x32x16_bf16, one
+// 512-register wave per SIMD, every wait of the in-order stream = MFMA idle time -- 1.47 ms, PMC pipe busy 40 %;
+// 8 waves x 16 rows, one block per CU: 1.27 ms, 50 %; this shape: 1.28 ms there and 0.059 vs 0.077 ms on the 16,384 rows
+// of a single N = 128 backbone (256 tiles instead of 128); the unfused launch sequence takes 2.11 / 0.125 ms.
+// Per tile the weight stream is 128 units of 12 KB (4 n-blocks of 16 x one 32-k step x 3 planes) in stages of two
+// units through a two-stage LDS ring; stage s+1 is in flight while stage s is multiplied:
 //     for c in 0..2:   8 units  W1z[n in chunk c]        (layer 1, K = 128)      -> h1 chunk c (32 registers)
 //                     24 units  W2[all n][k in chunk c]  (layer 2, partial K)    -> acc2 (96 registers) += ...
 //     8 units Wfz, 24 units Wf                           (layer 3, K = 128 + 384)
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void edge_mlp_pack16_kernel(EmMat A1, EmMat A2
 }
 
 template <bool BWD>
-__global__ __launch_bounds__(512, 2) void edge_mlp16_kernel(FdEdgeMlpDesc d) {
+__global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpDesc d) {
   __shared__ __attribute__((aligned(16))) char lds[2 * EM_STAGE];
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -103,8 +105,8 @@ __global__ __launch_bounds__(512, 2) void edge_mlp16_kernel(FdEdgeMlpDesc d) {
   const int total_stages = nmine * EM_NSTAGE;
 
   // ---- weight stream: every wave copies an eighth (6 pieces) of each stage; stage s lives in buffer s & 1 ----
-  const char* __restrict__ img_lane = static_cast<const char*>(d.img) + wave * (EM_STAGE / 8) + lane * 16;
-  char* const lds_wave = lds + wave * (EM_STAGE / 8);
+  const char* __restrict__ img_lane = static_cast<const char*>(d.img) + wave * (EM_STAGE / EM_WAVES) + lane * 16;
+  char* const lds_wave = lds + wave * (EM_STAGE / EM_WAVES);
   int issued = 0, consumed = 0;
   auto issue_stage = [&]() {
     const char* src = img_lane + (long)(issued % EM_NSTAGE) * EM_STAGE;
@@ -168,12 +170,12 @@ __global__ __launch_bounds__(512, 2) void edge_mlp16_kernel(FdEdgeMlpDesc d) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc1[nb][r] = 0.f;
 #pragma clang loop unroll(full)
-      for (int sg = 0; sg < 2; ++sg) {
+      for (int sg = 0; sg < 8 / EM_UPS; ++sg) {
         const char* st = stage_begin();
         em16_read_half(H[0], st);
 #pragma clang loop unroll(full)
         for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
-          const int r = 4 * sg + (hh >> 1), g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
+          const int r = EM_UPS * sg + (hh >> 1), g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
           if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
           fd::sched_pin();
           if (g2 == 0 && (hh & 1) == 0) em_split8(xr[r >> 1], b[0], b[1], b[2]);
@@ -206,12 +208,12 @@ __global__ __launch_bounds__(512, 2) void edge_mlp16_kernel(FdEdgeMlpDesc d) {
       }
       // ---- layer 2, k in chunk c: units (k-step u2 / 6, n-group u2 % 6) ----
 #pragma clang loop unroll(full)
-      for (int sg = 0; sg < 6; ++sg) {
+      for (int sg = 0; sg < 24 / EM_UPS; ++sg) {
         const char* st = stage_begin();
         em16_read_half(H[0], st);
 #pragma clang loop unroll(full)
         for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
-          const int u2 = 4 * sg + (hh >> 1), ks = u2 / 6, g6 = u2 % 6, a = 4 * g6 + 2 * (hh & 1);
+          const int u2 = EM_UPS * sg + (hh >> 1), ks = u2 / 6, g6 = u2 % 6, a = 4 * g6 + 2 * (hh & 1);
           if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
           fd::sched_pin();
           if (g6 == 0 && (hh & 1) == 0) em16_split2(acc1[2 * ks], acc1[2 * ks + 1], b[0], b[1], b[2]);
@@ -249,12 +251,12 @@ __global__ __launch_bounds__(512, 2) void edge_mlp16_kernel(FdEdgeMlpDesc d) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc3[nb][r] = 0.f;
 #pragma clang loop unroll(full)
-    for (int sg = 0; sg < 2; ++sg) {
+    for (int sg = 0; sg < 8 / EM_UPS; ++sg) {
       const char* st = stage_begin();
       em16_read_half(H[0], st);
 #pragma clang loop unroll(full)
       for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
-        const int r = 4 * sg + (hh >> 1), g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
+        const int r = EM_UPS * sg + (hh >> 1), g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
         if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
         fd::sched_pin();
         if (g2 == 0 && (hh & 1) == 0) em_split8(xr[r >> 1], b[0], b[1], b[2]);
@@ -263,12 +265,12 @@ __global__ __launch_bounds__(512, 2) void edge_mlp16_kernel(FdEdgeMlpDesc d) {
       }
     }
 #pragma clang loop unroll(full)
-    for (int sg = 0; sg < 6; ++sg) {
+    for (int sg = 0; sg < 24 / EM_UPS; ++sg) {
       const char* st = stage_begin();
       em16_read_half(H[0], st);
 #pragma clang loop unroll(full)
       for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
-        const int v = 4 * sg + (hh >> 1), ks = v >> 1, g2 = v & 1, a = 4 * g2 + 2 * (hh & 1);
+        const int v = EM_UPS * sg + (hh >> 1), ks = v >> 1, g2 = v & 1, a = 4 * g2 + 2 * (hh & 1);
         if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
         fd::sched_pin();
         if (g2 == 0 && (hh & 1) == 0) em16_split2(acc2[2 * ks], acc2[2 * ks + 1], b[0], b[1], b[2]);
@@ -363,12 +365,12 @@ extern "C" int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream) {
   for (const void* p : ptrs) FD_CHECK_ARG(fd_aligned16(p), "fd_edge_mlp: operands must be 16-byte aligned");
   if (d.rows == 0) return FD_OK;
   const long ntiles = (d.rows + EM_ROWS - 1) / EM_ROWS;
-  const int blocks = d.blocks > 0 ? d.blocks : 256;   // MI355X: one persistent block per CU
+  const int blocks = d.blocks > 0 ? d.blocks : 256 * EM_BLOCKS_PER_CU;   // MI355X: persistent blocks fill the 256 CUs
   const int grid = (int)(ntiles < blocks ? ntiles : blocks);
   if (d.backward)
-    hipLaunchKernelGGL(edge_mlp16_kernel<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(edge_mlp16_kernel<true>, dim3(grid), dim3(64 * EM_WAVES), 0, (hipStream_t)stream, d);
   else
-    hipLaunchKernelGGL(edge_mlp16_kernel<false>, dim3(grid), dim3(512), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(edge_mlp16_kernel<false>, dim3(grid), dim3(64 * EM_WAVES), 0, (hipStream_t)stream, d);
   FD_CHECK_LAUNCH("fd_edge_mlp");
   return FD_OK;
 }
