@@ -323,9 +323,7 @@ def main():
         # (pdb_data_loader.py:467,483), i.e. all ranks share N; B = min(batch_size = 32, max_squared_res // N^2)
         # (data/utils.py:395, base.yaml:83-84).  Lengths come from one seeded stream shared by all ranks; the batches are
         # pre-generated so the timed region holds only the step.
-        import numpy as np
-        lens = np.random.RandomState(2024).randint(100, 513, size=a.warmup + a.steps)
-        sched = [(int(n), max(1, min(32, 500000 // (int(n) * int(n))))) for n in lens]
+        sched = fdist.mixed_length_schedule(a.warmup + a.steps)
         data = [make_batch(n, b, 1000 * i + rank) for i, (n, b) in enumerate(sched)]
     else:
         sched = [(N, B)] * (a.warmup + a.steps)

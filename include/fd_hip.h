@@ -209,6 +209,21 @@ int fd_ipa_opair_fwd(const float* A, const float* zb, float* feats, int B, int N
 int fd_ipa_opair_bwd(const float* A, const float* zb, const float* dfeats, float* dA, float* dzb, int B, int N,
                      void* stream);
 
+/* dkp[b,j,h,:] = gamma_h sum_i dLogits[b,h,i,j] (qp[b,i,h,:] - kp[b,j,h,:]) (the key-side point gradient) */
+int fd_ipa_kpts_bwd(const float* dL, const float* qp, const float* kp, const float* head_w, float* dkp, int B, int N,
+                    void* stream);
+/* The pair pass of IPA in one kernel per direction (se3_diffusion_amd/csrc/fd_ipa_pair.hip): z is read once for both
+ * linear_b and down_z; the [P,40] projections zb / dzb stay in LDS.  W40 = [linear_b.weight ; down_z.weight] [40,128],
+ * b40 likewise.  N <= 512.
+ *   fwd: S [B,8,N,N] holds sqrt(1/(3C)) q k^T on entry and the attention probabilities on return; feats[:, o_pair] written.
+ *   bwd: dA holds dO V^T + d(o_pt) v_pts^T on entry and dLogits on return; dz (+)= dzb W40 (dz_accumulate 0: assign);
+ *        dW40 [40,128] and db40 [40] accumulated atomically; dqp / dkp / dhead_w as fd_ipa_softmax_bwd. */
+int fd_ipa_pair_fwd(float* S, const float* z, const float* W40, const float* b40, const float* qp, const float* kp,
+                    const float* head_w, const float* mask, float* feats, int B, int N, void* stream);
+int fd_ipa_pair_bwd(const float* A, float* dA, const float* z, const float* W40, const float* b40, const float* dfeats,
+                    const float* qp, const float* kp, const float* head_w, float* dz, int dz_accumulate, float* dqp,
+                    float* dkp, float* dhead_w, float* hw_part, float* dW40, float* db40, int B, int N, void* stream);
+
 /* ---- sequence-transformer softmax (nn.MultiheadAttention, ipa_pytorch.py:584-593) ---- */
 int fd_row_softmax_fwd(float* S, const float* key_add, long rows, int N, int rows_per_batch, void* stream);
 int fd_row_softmax_bwd(const float* A, float* dA, long rows, int N, void* stream);

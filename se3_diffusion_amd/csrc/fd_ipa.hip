@@ -438,6 +438,9 @@ extern "C" int fd_ipa_softmax_fwd(float* S, const float* zb, const float* qp, co
   return FD_OK;
 }
 
+extern "C" int fd_ipa_kpts_bwd(const float* dL, const float* qp, const float* kp, const float* head_w, float* dkp, int B,
+                               int N, void* stream);
+
 extern "C" int fd_ipa_softmax_bwd(const float* A, float* dA, const float* qp, const float* kp, const float* head_w,
                                   float* dzb, float* dqp, float* dkp, float* dhead_w, float* hw_part, int B, int N,
                                   void* stream) {
@@ -450,9 +453,15 @@ extern "C" int fd_ipa_softmax_bwd(const float* A, float* dA, const float* qp, co
     int rc = fd_colsum_acc(hw_part, H, (long)B * N, H, dhead_w, stream);
     if (rc != FD_OK) return rc;
   }
+  return fd_ipa_kpts_bwd(dA, qp, kp, head_w, dkp, B, N, stream);
+}
+
+extern "C" int fd_ipa_kpts_bwd(const float* dL, const float* qp, const float* kp, const float* head_w, float* dkp, int B,
+                               int N, void* stream) {
+  if (B == 0 || N == 0) return FD_OK;
   hipLaunchKernelGGL(ipa_kpts_bwd_kernel, dim3((unsigned)((N + 63) / 64), H, (unsigned)B), dim3(256), 0,
-                     (hipStream_t)stream, dA, qp, kp, head_w, dkp, N);
-  FD_CHECK_LAUNCH("fd_ipa_softmax_bwd(kpts)");
+                     (hipStream_t)stream, dL, qp, kp, head_w, dkp, N);
+  FD_CHECK_LAUNCH("fd_ipa_kpts_bwd");
   return FD_OK;
 }
 

@@ -149,6 +149,16 @@ def broadcast_params(module, src=0):
             dist.broadcast(t.data, src=src)
 
 
+def mixed_length_schedule(steps, seed=2024, min_len=100, max_len=512, batch_size=32, max_squared_res=500000):
+    """BASELINE configs[3] (cluster_time_batch on mixed lengths under DDP): the reference's DistributedTrainSampler hands
+    every rank the SAME protein in a step (pdb_data_loader.py:467,483), so all ranks share N and nobody waits for a
+    straggler; B = min(batch_size, max_squared_res // N^2) (data/utils.py:395, config/base.yaml:83-84).  The lengths come
+    from one seeded stream that every rank reproduces: [(N, B)] * steps."""
+    import numpy as np
+    lens = np.random.RandomState(seed).randint(min_len, max_len + 1, size=steps)
+    return [(int(n), max(1, min(batch_size, max_squared_res // (int(n) * int(n))))) for n in lens]
+
+
 def shard_indices(n_items, rank, world):
     """Backbone i goes to rank i % world (reference DistributedTrainSampler: indices[rank::world])."""
     return list(range(rank, n_items, world))

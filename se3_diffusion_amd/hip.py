@@ -134,6 +134,9 @@ _SIGS = {
     "fd_ipa_points_bwd": "pppppppliiiis",
     "fd_ipa_softmax_fwd": "ppppppiis",
     "fd_ipa_softmax_bwd": "ppppppppppiis",
+    "fd_ipa_kpts_bwd": "pppppiis",
+    "fd_ipa_pair_fwd": "pppppppppiis",
+    "fd_ipa_pair_bwd": "pppppppppp" + "i" + "pppppp" + "iis",
     "fd_ipa_opt_fwd": "ppppls",
     "fd_ipa_opt_bwd": "pppppls",
     "fd_ipa_opair_fwd": "pppiis",

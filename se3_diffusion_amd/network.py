@@ -43,6 +43,8 @@ def check_conf(conf):
                 f"the gfx950 kernels are built for config/base.yaml dimensions; model.ipa.{k}={getattr(ipa, k)} != {v}")
     if conf.node_embed_size != 256 or conf.edge_embed_size != 128:
         raise NotImplementedError("node_embed_size/edge_embed_size must be 256/128")
+    if getattr(ipa, "seq_tfmr_num_layers", 2) != 2:
+        raise NotImplementedError(f"the trunk runs 2 transformer layers per block; model.ipa.seq_tfmr_num_layers={ipa.seq_tfmr_num_layers}")
     e = conf.embed
     if e.index_embed_size != 32 or e.num_bins != 22 or not e.embed_self_conditioning:
         raise NotImplementedError("embed config must match config/base.yaml (index 32, 22 bins, self-conditioning)")
@@ -91,6 +93,10 @@ def mlp3_ln_bwd(P, G, pre, sv, dy):
 
 
 _FUSED_EMBED = os.environ.get("FD_EMBED_FUSED", "1") != "0"
+# the fused IPA pair pass (fd_ipa_pair.hip: z read once, zb / dzb only in LDS) is correct and tested but measured SLOWER
+# than the launch sequence it replaces at the training size (B=30 x N=128: forward 325 vs 260 us, backward 758 vs 450 us
+# per block -- one (b, i) row per block serialises its phases at 2 blocks per CU), so it is opt-in
+FUSED_IPA_PAIR = os.environ.get("FD_IPA_PAIR_FUSED", "0") != "0"
 
 
 def fused_embed():
@@ -198,31 +204,39 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
         b40 = torch.cat([P[f"{pre}.linear_b.bias"], P[f"{pre}.down_z.bias"]], 0).contiguous()
         if cache is not None:
             cache[("W40", pre)] = (W40, b40)
-    zb = empty((Pn, ZB), dev)
-    ops.linear(mv(z), mv(W40), b40, mv(zb), Pn, ZB, CZ)
+    fused = FUSED_IPA_PAIR and N <= 512
     A = empty((B, H, N, N), dev)
     L = lib()
     L.gemm(proj, proj, A, N, N, C, (LDP, 1), (1, LDP), N, b_off=2048, batch=B * H, bdiv=H,
            a_bs=(N * LDP, C), b_bs=(N * LDP, 2 * C), c_bs=(H * N * N, N * N), alpha=math.sqrt(1.0 / (3 * C)))
-    L.call("fd_ipa_softmax_fwd", A, zb, qp, kp, P[f"{pre}.head_weights"], mask, B, N)
     feats = empty((R, LDF), dev)
+    zb = None
+    if fused:
+        # the pair pass in one launch: zb = W40 z + b40 stays in LDS; logits + softmax (A in place) + o_pair
+        L.call("fd_ipa_pair_fwd", A, z, W40, b40, qp, kp, P[f"{pre}.head_weights"], mask, feats, B, N)
+    else:
+        zb = empty((Pn, ZB), dev)
+        ops.linear(mv(z), mv(W40), b40, mv(zb), Pn, ZB, CZ)
+        L.call("fd_ipa_softmax_fwd", A, zb, qp, kp, P[f"{pre}.head_weights"], mask, B, N)
     L.gemm(A, proj, feats, N, C, N, (N, 1), (LDP, 1), LDF, b_off=2048 + C, batch=B * H, bdiv=H,
            a_bs=(H * N * N, N * N), b_bs=(N * LDP, 2 * C), c_bs=(N * LDF, C))
     optg = empty((R, H, PV * 3), dev)
     L.gemm(A, vp, optg, N, PV * 3, N, (N, 1), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
            a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
     L.call("fd_ipa_opt_fwd", optg, quat, trans, feats, R)
-    L.call("fd_ipa_opair_fwd", A, zb, feats, B, N)
+    if not fused:
+        L.call("fd_ipa_opair_fwd", A, zb, feats, B, N)
     x1 = empty((R, CS), dev)
     ops.linear(mv(feats), mv(P[f"{pre}.linear_out.weight"]), P[f"{pre}.linear_out.bias"], mv(x1), R, CS, LDF,
                rowscale=mask, resid=s)
-    sv = dict(s=s, z=z, quat=quat, trans=trans, mask=mask, proj=proj, qp=qp, kp=kp, vp=vp, W40=W40, zb=zb, A=A,
+    sv = dict(s=s, z=z, quat=quat, trans=trans, mask=mask, proj=proj, qp=qp, kp=kp, vp=vp, W40=W40, b40=b40, zb=zb, A=A,
               feats=feats, B=B, N=N)
     return x1, sv
 
 
-def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe):
-    """dx1 [R,256] -> accumulates ds (view, +=), dz [P,128] (+=), dframe [R,12] (+=); param grads into G."""
+def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True):
+    """dx1 [R,256] -> accumulates ds (view, +=), dz [P,128] (+= ; = when dz_accumulate is False and the fused pair pass
+    runs), dframe [R,12] (+=); param grads into G."""
     B, N = sv["B"], sv["N"]
     R, Pn = B * N, B * N * N
     dev = dx1
@@ -252,14 +266,21 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe):
     dvp = empty((R, H, PV * 3), dev)
     L.gemm(A, doptg, dvp, N, PV * 3, N, (1, N), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
            a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
-    # o_pair
-    dzb = empty((Pn, ZB), dev)
-    L.call("fd_ipa_opair_bwd", A, zb, dfeats, dA, dzb, B, N)
-    # softmax (dA becomes dLogits) + point/bias/head-weight grads
     dqp = empty((R, H, PQ * 3), dev); dkp = empty((R, H, PQ * 3), dev)
     dhw = G[f"{pre}.head_weights"] if G is not None else zeros((H,), dev)
     hw_part = empty((R, H), dev)
-    L.call("fd_ipa_softmax_bwd", A, dA, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, hw_part, B, N)
+    fused = zb is None
+    if fused:
+        # o_pair backward, softmax backward, dz (+)= dzb W40, dW40 / db40: one launch, dzb only in LDS
+        dW40 = zeros((ZB, CZ), dev); db40 = zeros((ZB,), dev)
+        L.call("fd_ipa_pair_bwd", A, dA, z, sv["W40"], sv["b40"], dfeats, qp, kp, P[f"{pre}.head_weights"], dz,
+               int(bool(dz_accumulate)), dqp, dkp, dhw, hw_part, dW40, db40, B, N)
+    else:
+        # o_pair
+        dzb = empty((Pn, ZB), dev)
+        L.call("fd_ipa_opair_bwd", A, zb, dfeats, dA, dzb, B, N)
+        # softmax (dA becomes dLogits) + point/bias/head-weight grads
+        L.call("fd_ipa_softmax_bwd", A, dA, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, hw_part, B, N)
     sc = math.sqrt(1.0 / (3 * C))
     # dQ = sc * dL K ; dK = sc * dL^T Q
     L.gemm(dA, proj, dproj, N, C, N, (N, 1), (LDP, 1), LDP, b_off=2048, batch=B * H, bdiv=H,
@@ -268,11 +289,13 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe):
            a_bs=(H * N * N, N * N), b_bs=(N * LDP, C), c_bs=(N * LDP, 2 * C), alpha=sc)
     L.call("fd_ipa_points_bwd", proj, quat, dqp, dkp, dvp, dproj, dframe, R, H, C, PQ, PV)
     # z path: dz += dzb W40 ; dW40 += dzb^T z
-    ops.linear_dx(mv(dzb), mv(sv["W40"]), mv(dz), Pn, ZB, CZ, beta=True)
+    if not fused:
+        ops.linear_dx(mv(dzb), mv(sv["W40"]), mv(dz), Pn, ZB, CZ, beta=True)
     if G is not None:
-        dW40 = zeros((ZB, CZ), dev); db40 = zeros((ZB,), dev)
-        ops.linear_dw(mv(dzb), mv(z), mv(dW40), Pn, ZB, CZ)
-        ops.bias_grad(mv(dzb), db40, Pn, ZB)
+        if not fused:
+            dW40 = zeros((ZB, CZ), dev); db40 = zeros((ZB,), dev)
+            ops.linear_dw(mv(dzb), mv(z), mv(dW40), Pn, ZB, CZ)
+            ops.bias_grad(mv(dzb), db40, Pn, ZB)
         G[f"{pre}.linear_b.weight"] += dW40[:H]; G[f"{pre}.down_z.weight"] += dW40[H:]
         G[f"{pre}.linear_b.bias"] += db40[:H]; G[f"{pre}.down_z.bias"] += db40[H:]
     # projections: ds += dproj_slice W ; dW += dproj_slice^T s

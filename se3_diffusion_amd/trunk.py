@@ -437,10 +437,12 @@ def backward(P, G, sv, d_out, on_done=None):
             dx1 = empty((R, CS), dev)
             nw.ln_skip_bwd(P, G, b, st["ln"], du0, dx1, dinit)
         ds = zeros((R, CS), dev)
+        dz_acc = dz_in is not None
         if dz_in is None:
-            dz_in = zeros((Pn, CZ), dev)
+            # last block: no edge transition behind this IPA, its z gradient IS dz (the fused pair pass assigns)
+            dz_in = empty((Pn, CZ), dev) if (st["ipa"]["zb"] is None) else zeros((Pn, CZ), dev)
         with rng(f"ipa_{b}.bwd"):
-            nw.ipa_bwd(P, G, f"score_model.trunk.ipa_{b}", st["ipa"], dx1, mv(ds), dz_in, dframe)
+            nw.ipa_bwd(P, G, f"score_model.trunk.ipa_{b}", st["ipa"], dx1, mv(ds), dz_in, dframe, dz_accumulate=dz_acc)
         # fold the IPA frame gradients (dL/dR, dL/dt of the block's input frame) into (dq, dt)
         _frame_grad_fold(st["bb"]["quat"], dframe, dq_in, dt_in, R)
         dq, dt, dnode, dz = dq_in, dt_in, ds, dz_in
