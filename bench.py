@@ -148,11 +148,13 @@ _KERNELS = {
     7: ("edge_mlp16_kernel<*> (fused edge transition 128->384->384->128 + LayerNorm per pair row, register-chained, "
         "fp32 operands as 3 bf16 terms, 6 x v_mfma_f32_16x16x32_bf16 per k-step, weights streamed by LDS-DMA)",
         round(2500.0 / 6.0, 1)),
+    8: ("edge_embed_kernel (fused edge embedder: relpos + distogram features generated in registers, 3 register-chained "
+        "layers + LayerNorm, split-bf16 v_mfma_f32_16x16x32_bf16)", round(2500.0 / 6.0, 1)),
 }
 # HBM bytes per launch of the dominant kernel from PMC (separate --pmc passes, FETCH_SIZE / WRITE_SIZE; profiles/
-# r02_pmc_edge_mlp.md), keyed by (tile, rows): forward without saves at B=30 x N=128
-_PMC_TRAFFIC = {(7, 491520): {"bytes_per_launch": 553e6, "algorithmic_bytes": 503e6,
-                              "source": "profiles/r02_pmc_edge_mlp.md (FETCH_SIZE 297 MB + WRITE_SIZE 256 MB, forward)"}}
+# r02_pmc_edge_mlp.txt), keyed by (tile, rows): forward without saves at B=30 x N=128
+_PMC_TRAFFIC = {(7, 491520): {"bytes_per_launch": 550e6, "algorithmic_bytes": 503e6,
+                              "source": "profiles/r02_pmc_edge_mlp.txt (FETCH_SIZE 294 MB + WRITE_SIZE 256 MB, forward)"}}
 
 
 def dominant_kernel(prof):
