@@ -150,6 +150,8 @@ _KERNELS = {
         round(2500.0 / 6.0, 1)),
     8: ("edge_embed_kernel (fused edge embedder: relpos + distogram features generated in registers, 3 register-chained "
         "layers + LayerNorm, split-bf16 v_mfma_f32_16x16x32_bf16)", round(2500.0 / 6.0, 1)),
+    9: ("pair_dw_kernel (grouped pair-row weight gradients: 384x128 tiles, float4 staging + ds_read_b64_tr_b16 operands, "
+        "split-bf16 v_mfma_f32_32x32x16_bf16)", round(2500.0 / 6.0, 1)),
 }
 # HBM bytes per launch of the dominant kernel from PMC (separate --pmc passes, FETCH_SIZE / WRITE_SIZE; profiles/
 # r02_pmc_edge_mlp.txt), keyed by (tile, rows): forward without saves at B=30 x N=128
@@ -416,7 +418,7 @@ def main():
             s[0] += p[3]; s[1] += p[4].elapsed_time(p[5]) * 1e-3; s[2] += 1
         rows = sorted(shapes.items(), key=lambda kv: -kv[1][1])
         sys.stderr.write("tile akc bkc (M,N,K,batch,gate,beta,pair,ksplit)  calls/step  ms/step  TF/s\n")
-        for k, v in rows[:40]:
+        for k, v in rows[:80]:
             sys.stderr.write(f"{k}  {v[2] / 3:.1f}  {v[1] / 3 * 1e3:.3f}  {v[0] / v[1] / 1e12:.1f}\n")
     tile, dflops, dtime, dn, all_flops, tot_t, dshape, by_tile = dominant_kernel(prof)
     kname, peak = _KERNELS[tile]

@@ -179,6 +179,32 @@ typedef struct FdEdgeEmbedDesc {
 } FdEdgeEmbedDesc;
 int fd_edge_embed(const FdEdgeEmbedDesc* desc, void* stream);
 
+/* ---- weight gradients of the pair-row MLPs, grouped (autograd of the Linear layers of EdgeTransition,
+ * model/ipa_pytorch.py:194-233: dW = dY^T X with the B*N*N pair rows as the reduction index) ----
+ * One launch for up to FD_PAIR_DW_MAX_ITEMS output tiles of 384 x 128 that share the row count
+ * (se3_diffusion_amd/csrc/fd_pair_dw.hip):  C[m, n] += sum_p (A[p, m] + [m < 128] A_add[p, m]) * B[p, n].
+ * Split-bf16 arithmetic (fp32-accurate, as fd_gemm tile 4); C accumulates atomically. */
+#define FD_PAIR_DW_MAX_ITEMS 8
+typedef struct FdPairDwItem {
+  const float* A;       /* [rows, 384], row stride lda: its columns index m */
+  long lda;
+  const float* A_add;   /* optional [rows, 128], row stride ld_add: added to columns 0..127 of A */
+  long ld_add;
+  const float* B;       /* [rows, 128], row stride ldb: its columns index n */
+  long ldb;
+  float* C;             /* trans == 0: C[m * ldc + n] += ...; trans != 0: C[n * ldc + m] += ... */
+  long ldc;
+  float* a_colsum;      /* optional [384]: += sum_p A[p, :] (+ A_add) -- the bias gradient when A is dY */
+  int trans;
+} FdPairDwItem;
+typedef struct FdPairDwDesc {
+  FdPairDwItem item[FD_PAIR_DW_MAX_ITEMS];
+  int nitems;
+  long rows;            /* B * nres * nres */
+  int blocks;           /* 0 = one persistent block per CU (256) */
+} FdPairDwDesc;
+int fd_pair_dw(const FdPairDwDesc* desc, void* stream);
+
 /* ---- embedder features: score_network.py:14-47,97-148; data/utils.py:570-580 ----
  * tscaled = (t*1e4) as fp32 [B]; tfreq[16], idenom[16], dg_lower[22], dg_upper[22] are the
  * host-computed tables of the reference's own op sequence. */

@@ -1,0 +1,276 @@
+// fd_pair_dw: the weight gradients of the pair-row MLPs (EdgeTransition, model/ipa_pytorch.py:194-233, autograd of its
+// three Linear layers) as ONE grouped launch on MI355X (gfx950).
+//
+//   C_t[m, n] += sum_p A_t[p, m] * B_t[p, n]        t = 0 .. nitems-1,  p over the B*N*N pair rows
+//
+// Every item is a 384 x 128 output tile (m over the 384 columns of A_t, n over 128 columns of B_t); the 384 x 384
+// gradient of the middle layer is three items that share A.  Both operands are row-major [rows, features] fp32
+// tensors as the fused forward / backward kernels left them, so the reduction index p is the STRIDED one of both --
+// the shape fd_gemm's split kernel stages with 8 dword loads per 8-k slot.  Here:
+//   * a thread loads float4s along the feature axis (whole 128-byte lines per 8 lanes), splits them into the three
+//     bf16 planes (fp32-accurate split-bf16 arithmetic, as fd_gemm tile 4) and writes each plane as ds_write_b64
+//     into a [panel of 32 columns][k][32] image;
+//   * the MFMA operands are read back with ds_read_b64_tr_b16 (the LDS transpose read of gfx950): two reads give a
+//     lane its column's 8 consecutive k of a v_mfma_f32_32x32x16_bf16 operand -- no transposition in registers;
+//   * all 8 waves of the block stage AND multiply (wave tile 96 x 64, 36 MFMAs per 16-k stage and wave), two-stage
+//     LDS ring, one barrier per stage, global loads two stages ahead in registers;
+//   * a block owns ONE item and one contiguous range of pair rows for its whole life: one prologue, one flush of the
+//     384 x 128 accumulator tile with atomics (C accumulates; the caller's gradient buffer).  The blocks of a group
+//     (the items of one row range) are placed on one XCD and walk the same rows in lockstep, so an operand shared by
+//     several items (the three tiles of the middle layer) is fetched from HBM once and served by that XCD's L2.
+// Options per item: A_add [rows,128] is added to columns 0..127 of A while staging (final_layer: its input is
+// h2 + [z | e_i | e_j], so dWf[:, 0:128] = dy^T (h2[:, 0:128] + z) in the same pass); a_colsum accumulates the column
+// sums of A (the bias gradient); trans stores C[n, m].
+#include "fd_common.h"
+#include "../../include/fd_hip.h"
+
+namespace {
+
+constexpr int DW_THREADS = 512;
+constexpr int DW_KS = 16;                          // pair rows per stage = one MFMA k-step
+constexpr int DW_PSTRIDE = DW_KS * 64 + 64;        // bytes of a 32-column panel of one plane (+64: the two 8-lane halves
+                                                   // of a ds_write_b64 group land on different bank halves)
+constexpr int DW_PANELS = 16;                      // 12 of A (384 columns) + 4 of B (128 columns)
+constexpr int DW_PLANE = DW_PANELS * DW_PSTRIDE;
+constexpr int DW_STAGE = 3 * DW_PLANE;             // 52,224 B
+constexpr int DW_RING = 2;
+static_assert(DW_RING * DW_STAGE <= 160 * 1024, "LDS");
+
+// four consecutive fp32 of one row -> three bf16 planes (x = p0 + p1 + p2 exactly, round-to-nearest at every stage)
+__device__ __forceinline__ void dw_split4(const float4 v, uint2& s0, uint2& s1, uint2& s2) {
+  const unsigned h0 = fd::pack_bf16(v.x, v.y), h1 = fd::pack_bf16(v.z, v.w);
+  const float r0 = v.x - fd::bf16lo_f32(h0), r1 = v.y - fd::bf16hi_f32(h0);
+  const float r2 = v.z - fd::bf16lo_f32(h1), r3 = v.w - fd::bf16hi_f32(h1);
+  const unsigned m0 = fd::pack_bf16(r0, r1), m1 = fd::pack_bf16(r2, r3);
+  const float q0 = r0 - fd::bf16lo_f32(m0), q1 = r1 - fd::bf16hi_f32(m0);
+  const float q2 = r2 - fd::bf16lo_f32(m1), q3 = r3 - fd::bf16hi_f32(m1);
+  s0 = make_uint2(h0, h1);
+  s1 = make_uint2(m0, m1);
+  s2 = make_uint2(fd::pack_bf16(q0, q1), fd::pack_bf16(q2, q3));
+}
+
+// the 8 consecutive k of one column: k 8kg..8kg+3 and 8kg+4..8kg+7 (four 64-byte rows further)
+__device__ __forceinline__ uint4 dw_read8(const char* p) {
+  const uint2 lo = fd::lds_read_tr16(p), hi = fd::lds_read_tr16(p + 256);
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+// the item's pointers come out of a dynamically indexed kernel-argument array: tell the compiler they are global
+// (global_load / global_atomic instead of flat_*)
+template <typename T>
+__device__ __forceinline__ T* dw_global(T* p) {
+  return (T*)(__attribute__((address_space(1))) T*)p;
+}
+
+template <bool TRANS, bool HAS_ADD, bool HAS_CS>
+__device__ __forceinline__ void dw_block(const FdPairDwItem& it, long row0, long row1, char* lds) {
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- staging slots: thread -> row k = tid / 32 of the 16-row stage, float4 column c = tid % 32 of the three
+  // 128-column bands of A (slots 0..2) and of B (slot 3): 32 lanes cover 512 contiguous bytes of a row ----
+  const int kk = tid >> 5, c4 = tid & 31;
+  int wofs[4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) wofs[i] = (4 * i + (c4 >> 3)) * DW_PSTRIDE + kk * 64 + (c4 & 7) * 8;
+  wofs[3] = (12 + (c4 >> 3)) * DW_PSTRIDE + kk * 64 + (c4 & 7) * 8;
+  constexpr bool has_add = HAS_ADD, has_cs = HAS_CS;
+
+  const float* __restrict__ A = dw_global(it.A) + row0 * it.lda;
+  const float* __restrict__ B = dw_global(it.B) + row0 * it.ldb;
+  const float* __restrict__ Ad = has_add ? dw_global(it.A_add) + row0 * it.ld_add : A;
+  float* __restrict__ C = dw_global(it.C);
+  float* __restrict__ colsum = dw_global(it.a_colsum);
+  const long nrows = row1 - row0;
+  const int nst = (int)((nrows + DW_KS - 1) / DW_KS);
+
+  float4 rg[2][4], radd[2];
+  float csum[3][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) csum[i][e] = 0.f;
+
+  // Branch-free: rows past the end of the range are read from its last row (a valid address) and replaced by zeros, so
+  // the stage loop below is one basic block whatever the stage -- the scheduler interleaves the split / LDS writes of
+  // stage s + 1 and the loads of stage s + 3 with the MFMAs of stage s.
+  const long last = nrows - 1;
+  auto load = [&](float4 (&r)[4], float4& ra, int st) __attribute__((always_inline)) {
+    const long k = (long)st * DW_KS + kk;
+    const bool ok = k <= last;
+    const long kc = ok ? k : last;
+    const float* a = A + kc * it.lda + 4 * c4;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(a + 128 * i);
+      r[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+    {
+      const float4 v = *reinterpret_cast<const float4*>(B + kc * it.ldb + 4 * c4);
+      r[3] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+    if (has_add) {
+      const float4 v = *reinterpret_cast<const float4*>(Ad + kc * it.ld_add + 4 * c4);
+      ra = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+  };
+  auto put = [&](float4 (&r)[4], const float4& ra, char* dst) __attribute__((always_inline)) {
+    if (has_add) { r[0].x += ra.x; r[0].y += ra.y; r[0].z += ra.z; r[0].w += ra.w; }
+    if (has_cs) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { csum[i][0] += r[i].x; csum[i][1] += r[i].y; csum[i][2] += r[i].z; csum[i][3] += r[i].w; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint2 s0, s1, s2;
+      dw_split4(r[i], s0, s1, s2);
+      *reinterpret_cast<uint2*>(dst + wofs[i]) = s0;
+      *reinterpret_cast<uint2*>(dst + DW_PLANE + wofs[i]) = s1;
+      *reinterpret_cast<uint2*>(dst + 2 * DW_PLANE + wofs[i]) = s2;
+    }
+  };
+
+  // ---- MFMA side: wave (wm, wn) owns A panels 3wm..3wm+2 and B panels 2wn, 2wn+1 ----
+  const int i16 = lane & 15, half = (lane >> 4) & 1, kg = lane >> 5;
+  const int lofs = (8 * kg + (i16 >> 2)) * 64 + half * 32 + (i16 & 3) * 8;
+  const int a_rd = (3 * wm) * DW_PSTRIDE + lofs, b_rd = (12 + 2 * wn) * DW_PSTRIDE + lofs;
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto mma = [&](const char* st) __attribute__((always_inline)) {
+    uint4 fb[2][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j][s] = dw_read8(st + b_rd + j * DW_PSTRIDE + s * DW_PLANE);
+#pragma unroll
+    for (int sa = 2; sa >= 0; --sa) {   // the small terms first
+      uint4 fa[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) fa[i] = dw_read8(st + a_rd + i * DW_PSTRIDE + sa * DW_PLANE);
+#pragma unroll
+      for (int sb = 2 - sa; sb >= 0; --sb)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = TRANS ? fd::mfma_32x32x16_bf16(fb[j][sb], fa[i], acc[i][j])
+                              : fd::mfma_32x32x16_bf16(fa[i], fb[j][sb], acc[i][j]);
+    }
+  };
+
+  // ---- pipeline: stage s lives in register set s & 1 (loaded two stages ahead) and ring slot s & 1 ----
+  load(rg[0], radd[0], 0);
+  load(rg[1], radd[1], 1);
+  put(rg[0], radd[0], lds);
+  load(rg[0], radd[0], 2);
+  __syncthreads();
+  const bool mma_first = true;
+  auto step = [&](int s, float4 (&r)[4], float4& ra) __attribute__((always_inline)) {
+    // r / ra: the register set of stage s + 1 (stages past the end are zeros: see load)
+    // Waves w and w + 4 share a SIMD: one multiplies first and stages second, the other the opposite, so that the split
+    // VALU work of one runs under the MFMAs of the other instead of both queueing for the same pipe in the same phase.
+    if (mma_first) {
+      mma(lds + (s & 1) * DW_STAGE);
+      put(r, ra, lds + ((s + 1) & 1) * DW_STAGE);
+      load(r, ra, s + 3);
+    } else {
+      put(r, ra, lds + ((s + 1) & 1) * DW_STAGE);
+      load(r, ra, s + 3);
+      mma(lds + (s & 1) * DW_STAGE);
+    }
+    __syncthreads();
+  };
+  for (int s = 0; s < nst; s += 2) {
+    step(s, rg[1], radd[1]);
+    step(s + 1, rg[0], radd[0]);   // nst odd: one stage of zeros
+  }
+
+  // ---- flush: C (+)= acc, atomically (every row range adds its part) ----
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        // !TRANS: D[row = m][col = n]; TRANS: D[row = n][col = m]
+        const int m = (3 * wm + i) * 32 + (TRANS ? l31 : rr);
+        const int n = (2 * wn + j) * 32 + (TRANS ? rr : l31);
+        float* c = TRANS ? C + (long)n * it.ldc + m : C + (long)m * it.ldc + n;
+        atomicAdd(c, acc[i][j][r]);
+      }
+  if (has_cs) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(colsum + 4 * (c4 + 32 * i) + e, csum[i][e]);
+  }
+}
+
+__global__ __launch_bounds__(DW_THREADS, 1) void pair_dw_kernel(FdPairDwDesc d) {
+  __shared__ __attribute__((aligned(16))) char lds[DW_RING * DW_STAGE];
+  // logical block order: XCD-major (block b runs on XCD b % 8), so the items of a row range sit on one XCD
+  const int G = (int)gridDim.x, per = G >> 3;
+  const int L = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  const int ngroups = G / d.nitems;
+  const int group = L / d.nitems, item = L - group * d.nitems;
+  if (group >= ngroups) return;
+  // row ranges in whole stages
+  const long nst = (d.rows + DW_KS - 1) / DW_KS;
+  const long s0 = nst * group / ngroups, s1 = nst * (group + 1) / ngroups;
+  const long row0 = s0 * DW_KS, row1 = (s1 * DW_KS < d.rows) ? s1 * DW_KS : d.rows;
+  if (row0 >= row1) return;
+  // (a select chain, not d.item[item]: a dynamic index would spill the argument array to scratch)
+  FdPairDwItem it = d.item[0];
+#pragma unroll
+  for (int t = 1; t < FD_PAIR_DW_MAX_ITEMS; ++t)
+    if (item == t) it = d.item[t];
+  const int mode = (it.trans ? 4 : 0) | (it.A_add ? 2 : 0) | (it.a_colsum ? 1 : 0);
+  switch (mode) {
+    case 0: dw_block<false, false, false>(it, row0, row1, lds); break;
+    case 1: dw_block<false, false, true>(it, row0, row1, lds); break;
+    case 2: dw_block<false, true, false>(it, row0, row1, lds); break;
+    case 3: dw_block<false, true, true>(it, row0, row1, lds); break;
+    case 4: dw_block<true, false, false>(it, row0, row1, lds); break;
+    case 5: dw_block<true, false, true>(it, row0, row1, lds); break;
+    case 6: dw_block<true, true, false>(it, row0, row1, lds); break;
+    default: dw_block<true, true, true>(it, row0, row1, lds); break;
+  }
+}
+
+}  // namespace
+
+extern "C" int fd_pair_dw(const FdPairDwDesc* desc, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  FD_CHECK_ARG(desc != nullptr, "fd_pair_dw: null descriptor");
+  const FdPairDwDesc& d = *desc;
+  FD_CHECK_ARG(d.nitems >= 1 && d.nitems <= FD_PAIR_DW_MAX_ITEMS, "fd_pair_dw: 1..%d items", FD_PAIR_DW_MAX_ITEMS);
+  FD_CHECK_ARG(d.rows >= 0, "fd_pair_dw: negative row count");
+  if (d.rows == 0) return FD_OK;
+  for (int t = 0; t < d.nitems; ++t) {
+    const FdPairDwItem& it = d.item[t];
+    FD_CHECK_ARG(it.A && it.B && it.C, "fd_pair_dw: item %d: null operand", t);
+    FD_CHECK_ARG(fd_aligned16(it.A) && fd_aligned16(it.B) && (it.lda & 3) == 0 && (it.ldb & 3) == 0 && it.lda >= 384 &&
+                     it.ldb >= 128,
+                 "fd_pair_dw: item %d: A [rows,384] / B [rows,128] must be 16-byte aligned with row strides %% 4 == 0", t);
+    FD_CHECK_ARG(!it.A_add || (fd_aligned16(it.A_add) && (it.ld_add & 3) == 0 && it.ld_add >= 128),
+                 "fd_pair_dw: item %d: A_add [rows,128] must be 16-byte aligned with a row stride %% 4 == 0", t);
+    FD_CHECK_ARG(it.ldc >= (it.trans ? 384 : 128), "fd_pair_dw: item %d: ldc too small", t);
+  }
+  int blocks = d.blocks > 0 ? d.blocks : 256;   // MI355X: one persistent block per CU
+  blocks &= ~7;
+  if (blocks < 8 * ((d.nitems + 7) / 8)) blocks = 8 * ((d.nitems + 7) / 8);
+  // no more groups than 16-row stages
+  const long nst = (d.rows + DW_KS - 1) / DW_KS;
+  while (blocks > 8 && (long)(blocks / d.nitems) > nst) blocks -= 8;
+  hipLaunchKernelGGL(pair_dw_kernel, dim3(blocks), dim3(DW_THREADS), 0, stream, d);
+  FD_CHECK_LAUNCH("fd_pair_dw");
+  return FD_OK;
+}

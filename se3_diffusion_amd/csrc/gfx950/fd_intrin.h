@@ -98,6 +98,17 @@ __device__ __forceinline__ void glds16x2(const void* g_lane, void* lds_wave_base
       : "v"(g_lane), "s"(dst)
       : "memory");
 }
+// ds_read_b64_tr_b16: LDS transpose read.  Every lane passes the address of 4 consecutive 16-bit elements (8-byte
+// aligned); inside each group of 16 lanes the 16 x 4 elements are transposed: lane i receives element (i & 3) of lanes
+// 4j + (i >> 2), j = 0..3.  With a [k][16 columns] image whose row k is covered by lanes 4k..4k+3 of the group, lane i
+// gets column i for k = 0..3 -- the k-contiguous MFMA operand of a row-major (k-strided) tile.
+typedef short fd_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_read_tr16(const void* p) {
+  const fd_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (fd_s16x4 __attribute__((address_space(3)))*)(const __attribute__((address_space(3))) char*)p);
+  return __builtin_bit_cast(uint2, v);
+}
+
 // s_waitcnt vmcnt(0): every vector-memory operation of this wave (loads, stores, LDS-DMA) has completed
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

@@ -100,6 +100,19 @@ class FdEdgeEmbedDesc(Structure):
 
 EDGE_EMBED_IMAGE_BYTES = 20 * 12288
 
+PAIR_DW_MAX_ITEMS = 8
+
+
+class FdPairDwItem(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_long), ("A_add", c_void_p), ("ld_add", c_long), ("B", c_void_p), ("ldb", c_long),
+        ("C", c_void_p), ("ldc", c_long), ("a_colsum", c_void_p), ("trans", c_int),
+    ]
+
+
+class FdPairDwDesc(Structure):
+    _fields_ = [("item", FdPairDwItem * PAIR_DW_MAX_ITEMS), ("nitems", c_int), ("rows", c_long), ("blocks", c_int)]
+
 
 def _ptr(t, off=0):
     """Raw address of a tensor (plus an element offset)."""
@@ -121,6 +134,7 @@ _SIGS = {
     "fd_edge_mlp": "Ss",
     "fd_edge_embed_pack": "pppps",
     "fd_edge_embed": "Ss",
+    "fd_pair_dw": "Ss",
     "fd_layernorm_fwd": "plpppplpplifs",
     "fd_layernorm_bwd": "plplpppppl" + "ipplis",
     "fd_colsum_acc": "pllips",

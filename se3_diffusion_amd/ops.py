@@ -278,3 +278,45 @@ def edge_embed(seq_idx, sc_ca, idenom, dg_lower, dg_upper, img, p, q, bias2, bia
         prof.append((8, True, True, 2.0 * int(rows) * 310 * 128, e0, e1, (int(rows), 128, 128, 1, 0, 0, 0, 1)))
         return
     L._check(L.cdll.fd_edge_embed(hip.ctypes.byref(d), stream), "fd_edge_embed")
+
+
+# ---------------------------------------------------------------------------
+# grouped pair-row weight gradients (csrc/fd_pair_dw.hip)
+# ---------------------------------------------------------------------------
+def pair_dw(items, rows, blocks=0):
+    """One launch for up to 8 tiles  C[m, n] += sum_p (A[p, m] + [m < 128] A_add[p, m]) B[p, n]  (m < 384, n < 128).
+
+    items: dicts with A=(tensor, offset, ld) [rows,384], B=(tensor, offset, ld) [rows,128], C=(tensor, offset, ld) and
+    optionally A_add=(tensor, offset, ld) [rows,128], colsum=tensor [384], trans=bool (C[n, m])."""
+    d = hip.FdPairDwDesc()
+    tens = []
+    assert 1 <= len(items) <= hip.PAIR_DW_MAX_ITEMS
+    for t, it in enumerate(items):
+        e = d.item[t]
+        for name, ld in (("A", "lda"), ("B", "ldb"), ("C", "ldc"), ("A_add", "ld_add")):
+            v = it.get(name)
+            if v is None:
+                setattr(e, name, None)
+                setattr(e, ld, 0)
+                continue
+            ten, off, stride = v
+            setattr(e, name, hip._ptr(ten, off))
+            setattr(e, ld, int(stride))
+            tens.append(ten)
+        cs = it.get("colsum")
+        e.a_colsum = None if cs is None else hip._ptr(cs)
+        e.trans = int(bool(it.get("trans", False)))
+    d.nitems, d.rows, d.blocks = len(items), int(rows), int(blocks)
+    L = lib()
+    stream = L._stream(tens)
+    prof = L.gemm_profile
+    if prof is not None and L.is_device:
+        # profile record (tile code 9): 2 * rows * 384 * 128 flops per item
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream())
+        L._check(L.cdll.fd_pair_dw(hip.ctypes.byref(d), stream), "fd_pair_dw")
+        e1.record(torch.cuda.current_stream())
+        prof.append((9, False, False, 2.0 * int(rows) * 384 * 128 * len(items), e0, e1, (384, 128 * len(items), int(rows), 1, 0, 0, 0, 1)))
+        return
+    L._check(L.cdll.fd_pair_dw(hip.ctypes.byref(d), stream), "fd_pair_dw")

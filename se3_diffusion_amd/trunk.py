@@ -62,6 +62,9 @@ def _edge_mlp_image(P, pre, cache, backward=False):
 _FUSED_EDGE = os.environ.get("FD_EDGE_FUSED", "1") != "0"
 
 
+_GROUPED_DW = os.environ.get("FD_PAIR_DW", "1") != "0"   # grouped weight-gradient kernel (fd_pair_dw) behind the fused chain
+
+
 def fused_edge():
     """The fused edge-transition kernel computes in split-bf16 (fp32-accurate): off in exact-fp32 mode."""
     return _FUSED_EDGE and not lib().exact_f32
@@ -140,10 +143,13 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
                       rowscale=sv["emask"], dgamma=G[f"{pre}.layer_norm.weight"], dbeta=G[f"{pre}.layer_norm.bias"])
     # y = Wf h2 + Wf[:, :128] z + Pf_i + Qf_j (+bf inside Qf)
     gWf = G[f"{pre}.final_layer.weight"]
-    def _grads_y():
-        ops.linear_dw(mv(dy), mv(h2), mv(gWf), Pn, CZ, EH)
-        ops.linear_dw(mv(dy), mv(z), (gWf, 0, EH), Pn, CZ, CZ)
-    ops.side(_grads_y, (dy, h2, z), Pn)
+    fused = fused_edge()
+    grouped_dw = fused and _GROUPED_DW
+    if not grouped_dw:
+        def _grads_y():
+            ops.linear_dw(mv(dy), mv(h2), mv(gWf), Pn, CZ, EH)
+            ops.linear_dw(mv(dy), mv(z), (gWf, 0, EH), Pn, CZ, CZ)
+        ops.side(_grads_y, (dy, h2, z), Pn)
     dPf = zeros((R, CZ), dev); dQf = zeros((R, CZ), dev)
     L.call("fd_pair_reduce_acc", dy, B, N, CZ, dPf, dQf, CZ)
     def _grads_f():
@@ -154,14 +160,24 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
     de = empty((R, CE), dev)
     ops.linear_dx(mv(dPf), (Wf, CZ, EH), mv(de), R, CZ, CE)
     ops.linear_dx(mv(dQf), (Wf, CZ + CE, EH), mv(de), R, CZ, CE, beta=True)
-    fused = fused_edge()
+    gW1 = G[f"{pre}.trunk.0.weight"]
     if fused:
         # the dX chain in one launch: d2 = [h2 > 0] dy Wf, d1 = [h1 > 0] d2 W2, dz = dy Wf_z + d1 W1_z (fd_edge_mlp with
         # the transposed weight image); d2 / d1 are written once, for the weight-gradient GEMMs and the pair reductions
         dh2 = empty((Pn, EH), dev); dh1 = empty((Pn, EH), dev)
         ops.edge_mlp(dy, _edge_mlp_image(P, pre, None, backward=True), dz, Pn, N, gate1=h2, gate2=h1, save1=dh2,
                      save2=dh1, backward=True)
-        _lin_grads(G, f"{pre}.trunk.2.weight", f"{pre}.trunk.2.bias", mv(dh2), mv(h1), Pn, EH, EH)
+        if grouped_dw:
+            # every pair-row weight gradient of the transition in ONE grouped launch (fd_pair_dw): dW2 = d2^T h1 as three
+            # 384 x 128 tiles (+ its bias gradient), dW1[:, z part] = d1^T z, dWf = dy^T (h2 + [z | 0]) stored transposed
+            gW2, gb2 = G[f"{pre}.trunk.2.weight"], G[f"{pre}.trunk.2.bias"]
+            items = [dict(A=(dh2, 0, EH), B=(h1, CZ * j, EH), C=(gW2, CZ * j, EH), colsum=gb2 if j == 0 else None)
+                     for j in range(3)]
+            items.append(dict(A=(dh1, 0, EH), B=(z, 0, CZ), C=(gW1, 0, EH)))
+            items.append(dict(A=(h2, 0, EH), A_add=(z, 0, CZ), B=(dy, 0, CZ), C=(gWf, 0, EH), trans=True))
+            ops.side(lambda: ops.pair_dw(items, Pn), (dh2, dh1, h1, h2, z, dy), Pn)
+        else:
+            _lin_grads(G, f"{pre}.trunk.2.weight", f"{pre}.trunk.2.bias", mv(dh2), mv(h1), Pn, EH, EH)
         del dh2
     else:
         ops.linear_dx(mv(dy), (Wf, 0, EH), mv(dz), Pn, CZ, CZ)                     # dz = dy Wf_z
@@ -171,8 +187,8 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
         dh1 = empty((Pn, EH), dev)
         ops.linear_dx(mv(dh2), mv(W2), mv(dh1), Pn, EH, EH, gate=mv(h1))
         del dh2
-    gW1 = G[f"{pre}.trunk.0.weight"]
-    ops.side(lambda: ops.linear_dw(mv(dh1), mv(z), (gW1, 0, EH), Pn, EH, CZ), (dh1, z), Pn)
+    if not grouped_dw:
+        ops.side(lambda: ops.linear_dw(mv(dh1), mv(z), (gW1, 0, EH), Pn, EH, CZ), (dh1, z), Pn)
     dP1 = zeros((R, EH), dev); dQ1 = zeros((R, EH), dev)
     L.call("fd_pair_reduce_acc", dh1, B, N, EH, dP1, dQ1, EH)
     def _grads_1():

@@ -127,6 +127,20 @@ static inline f32x4 mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) {
   return d;
 }
 
+// ds_read_b64_tr_b16: within each group of 16 lanes, lane i receives element (i & 3) of lanes 4j + (i >> 2), j = 0..3
+static inline uint2 lds_read_tr16(const void* p) {
+  unsigned short own[4];
+  memcpy(own, p, 8);
+  auto tab = hipemu::wave_exchange(own, 8);
+  const int lane = hipemu::g_cur->lane, base = lane & ~15, i = lane & 15;
+  unsigned short r[4];
+  for (int j = 0; j < 4; ++j) memcpy(&r[j], tab[base + 4 * j + (i >> 2)] + 2 * (i & 3), 2);
+  uint2 out;
+  out.x = (unsigned)r[0] | ((unsigned)r[1] << 16);
+  out.y = (unsigned)r[2] | ((unsigned)r[3] << 16);
+  return out;
+}
+
 static inline void glds16x2(const void* g_lane, void* lds_wave_base) {
   for (int k = 0; k < 2; ++k)
     memcpy(static_cast<char*>(lds_wave_base) + 1024 * k + 16 * hipemu::g_cur->lane, static_cast<const char*>(g_lane) + 1024 * k, 16);
