@@ -150,6 +150,8 @@ _KERNELS = {
         round(2500.0 / 6.0, 1)),
     8: ("edge_embed_kernel (fused edge embedder: relpos + distogram features generated in registers, 3 register-chained "
         "layers + LayerNorm, split-bf16 v_mfma_f32_16x16x32_bf16)", round(2500.0 / 6.0, 1)),
+    10: ("gemm_s64_kernel<*,*> (64x64 split-bf16 tile, node-level / attention GEMMs, 6 x v_mfma_f32_32x32x16_bf16 per "
+         "k-step)", round(2500.0 / 6.0, 1)),
     9: ("pair_dw_kernel (grouped pair-row weight gradients: 384x128 tiles, float4 staging + ds_read_b64_tr_b16 operands, "
         "split-bf16 v_mfma_f32_32x32x16_bf16)", round(2500.0 / 6.0, 1)),
 }

@@ -502,6 +502,8 @@ bool epilogue_vectorisable(const FdGemmDesc& d, int ksplit) {
   return ok;
 }
 
+#include "fd_gemm_s64.h"     // gemm_s64_kernel: tile code 10
+
 // split-bf16 kernel: instantiated for A k-contiguous (activations [rows, features]) with either B layout
 // (y = x W^T and dx = dy W) and for both operands row-contiguous (dW = dY^T X)
 bool bx3_layout_ok(const FdGemmDesc& d) {
@@ -575,7 +577,13 @@ bool split_enabled() {
   return g_split_mode != 0;
 }
 
-// tile selection: 1 = 128x128, 2 = 64x64, 3 = 128x32 (fp32 MFMA); 4 = 256x128 split-bf16.
+// FD_GEMM_NO_S64=1: the automatic choice keeps the 64x64 fp32 tile (A/B measurements)
+bool s64_enabled() {
+  static const bool on = getenv("FD_GEMM_NO_S64") == nullptr;
+  return on;
+}
+
+// tile selection: 1 = 128x128, 2 = 64x64, 3 = 128x32 (fp32 MFMA); 4 = 256x128 split-bf16; 10 = 64x64 split-bf16.
 // Wide tiles when the problem fills the chip, narrow otherwise.
 int plan_tile(const FdGemmDesc& d, bool fast) {
   int cfg = d.tile;
@@ -596,7 +604,12 @@ int plan_tile(const FdGemmDesc& d, bool fast) {
     // (measured: 128x320x320 8 vs 11 us, 128x256x2688 25 vs 68 us, 1024x320x320 9 vs 12 us; with >= ~200 tiles of
     // 64x64 the wider tile's operand reuse wins again)
     if (cfg != 4 && blocks64 <= 128 && d.M <= 1024 && direct_ok(d)) cfg = 5;
+    // un-batched activations x weights with K >= 256 that would take the 64x64 fp32 tile: the 64x64 split-bf16 kernel
+    // (a third of its MFMA cycles; measured 15.0 vs 18.3 us at 3840 x 320 x 320, 41 vs 56 us at K = 1280; the weight
+    // gradients (both operands row-contiguous, split-K) and the batched attention products are not faster on it)
+    if (cfg == 2 && fast && d.a_cs == 1 && d.batch <= 1 && d.K >= 256 && split_enabled() && s64_enabled()) cfg = 10;
   }
+  if (cfg == 10 && !(fast && split_enabled())) cfg = 2;   // (explicit requests: exact-fp32 mode, unaligned operands)
   if ((cfg == 4 || cfg == 6) && !split_enabled()) {
     // FD_GEMM_EXACT_F32=1 also overrides explicit requests for the split-bf16 kernel (the host asks for it on the
     // weight gradients)
@@ -691,7 +704,7 @@ extern "C" int fd_gemm(const FdGemmDesc* desc, void* stream_) {
   if (cfg == 4 || cfg == 6)
     FD_CHECK_ARG(fast && bx3_layout_ok(d), "fd_gemm: tiles 4/6 (split-bf16) need 16-byte aligned operands and a k-contiguous A "
                                            "or both operands row-contiguous");
-  if (d.a_rowsum && !((cfg == 2 || cfg == 4 || cfg == 6) && fast && d.a_cs != 1 && d.b_rs != 1 && d.batch <= 1)) {
+  if (d.a_rowsum && !((cfg == 2 || cfg == 4 || cfg == 6 || cfg == 10) && fast && d.a_cs != 1 && d.b_rs != 1 && d.batch <= 1)) {
     // the fused row-sum lives in the instantiations with both operands row-contiguous (the dW = dY^T X case) of
     // the 64x64 fp32 kernel and the split-bf16 kernel; anything else takes the stand-alone column-sum kernel
     FD_CHECK_ARG(d.a_rs == 1 && d.alpha == 1.0f && (d.batch <= 1), "fd_gemm: a_rowsum needs a row-contiguous A, alpha 1, no batch");
@@ -705,6 +718,7 @@ extern "C" int fd_gemm(const FdGemmDesc* desc, void* stream_) {
     case 3: return fast ? launch_cfg<128, 32, 4, 1, true>(d, stream) : launch_cfg<128, 32, 4, 1, false>(d, stream);
     case 4: return launch_bx3<256>(d, stream);
     case 6: return launch_bx3<128>(d, stream);
+    case 10: return launch_s64(d, stream);
     case 5:
       FD_CHECK_ARG(direct_ok(d), "fd_gemm: tile 5 (latency kernel) needs K %% 8 == 0, unit-stride 16-byte aligned operands, "
                                  "no pair epilogue / split-K / row sum");

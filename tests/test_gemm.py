@@ -309,3 +309,54 @@ def test_gemm_split128_gpu(hip_lib):
     _splitk4(hip_lib, "cuda", M=128, N=384, K=40000, ks=64, tile=6)
     _splitk4_rowsum(hip_lib, "cuda", tile=6)
     _splitk4_rowsum(hip_lib, "cuda", M=128, N=128, K=65536, ks=64, tile=6)
+
+
+# ---- tile 10: 64 x 64 split-bf16 kernel (node-level / attention GEMMs): every layout through the same loader, the
+# row-contiguous operands through the LDS transpose read ----
+S64_CASES = [(64, 64, 32), (128, 128, 64), (100, 72, 40), (260, 136, 100), (132, 64, 36), (256, 384, 96)]
+
+
+@pytest.mark.parametrize("a_kc", [True, False])
+@pytest.mark.parametrize("b_kc", [True, False])
+def test_gemm_s64_layouts_emu(emu_lib, a_kc, b_kc):
+    for (M, N, K) in S64_CASES[:5]:
+        assert _run(emu_lib, "cpu", M, N, K, a_kc, b_kc, 10) < 2e-6, (M, N, K)
+    assert _run(emu_lib, "cpu", 100, 72, 40, a_kc, b_kc, 10, epi=True) < 2e-6
+
+
+def _s64_plan(lib, dev):
+    """the automatic plan sends aligned mid-size GEMMs to tile 10 and keeps unaligned ones on the fp32 tile"""
+    from se3_diffusion_amd import hip
+    import ctypes
+    d = hip.FdGemmDesc()
+    A = torch.zeros(3840 * 320, device=dev)
+    d.A, d.B, d.C = A.data_ptr(), A.data_ptr(), A.data_ptr()
+    d.M, d.N, d.K = 3840, 320, 320
+    d.a_rs, d.a_cs, d.b_rs, d.b_cs, d.ldc = 320, 1, 1, 320, 320
+    d.alpha = 1.0
+    assert lib.cdll.fd_gemm_plan(ctypes.byref(d)) == 10
+    d.K = 322                                   # K % 4 != 0: element-wise staging only exists on the fp32 tiles
+    d.a_rs = 322
+    assert lib.cdll.fd_gemm_plan(ctypes.byref(d)) == 2
+
+
+def test_gemm_s64_plan_splitk_rowsum_emu(emu_lib):
+    _s64_plan(emu_lib, "cpu")
+    _splitk4(emu_lib, "cpu", tile=10)
+    _splitk4_rowsum(emu_lib, "cpu", M=200, N=72, K=200, ks=3, tile=10)
+
+
+@pytest.mark.gpu
+def test_gemm_s64_gpu(hip_lib):
+    for a_kc in (True, False):
+        for b_kc in (True, False):
+            for (M, N, K) in S64_CASES:
+                assert _run(hip_lib, "cuda", M, N, K, a_kc, b_kc, 10) < 2e-6, (a_kc, b_kc, M, N, K)
+            assert _run(hip_lib, "cuda", 300, 132, 72, a_kc, b_kc, 10, epi=True) < 2e-6
+    _s64_plan(hip_lib, "cuda")
+    _splitk4(hip_lib, "cuda", tile=10)
+    _splitk4(hip_lib, "cuda", M=320, N=320, K=3840, ks=15, tile=10)
+    _splitk4_rowsum(hip_lib, "cuda", tile=10)
+    _splitk4_rowsum(hip_lib, "cuda", M=256, N=2688, K=3840, ks=13, tile=10)
+    assert _run(hip_lib, "cuda", 3840, 320, 320, True, True, 0) < 2e-6
+    assert _run(hip_lib, "cuda", 3840, 320, 960, True, False, 0) < 2e-6

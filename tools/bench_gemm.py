@@ -93,6 +93,16 @@ SHAPES = [
     ("kk K=320", 3840, 320, 320, True, True, 2, 1),
     ("kk K=640", 3840, 320, 640, True, True, 2, 1),
     ("kk K=1280", 3840, 320, 1280, True, True, 2, 1),
+    ("kk s64 K=32", 3840, 320, 32, True, True, 10, 1),
+    ("kk s64 K=64", 3840, 320, 64, True, True, 10, 1),
+    ("kk s64 K=160", 3840, 320, 160, True, True, 10, 1),
+    ("kk s64 K=320", 3840, 320, 320, True, True, 10, 1),
+    ("kk s64 K=640", 3840, 320, 640, True, True, 10, 1),
+    ("kk s64 K=1280", 3840, 320, 1280, True, True, 10, 1),
+    ("kk s64 NN K=320", 3840, 320, 320, True, False, 10, 1),
+    ("kk s64 TN ks15", 320, 320, 3840, False, False, 10, 15),
+    ("kk t2 TN ks15", 320, 320, 3840, False, False, 2, 15),
+    ("kk s64 TN ks30", 320, 320, 3840, False, False, 10, 30),
     ("n5 NT 3840x320x320 t5", 3840, 320, 320, True, True, 5, 1),
     ("n5 NT 3840x320x320 t2", 3840, 320, 320, True, True, 2, 1),
     ("n5 NN 3840x320x320 t5", 3840, 320, 320, True, False, 5, 1),
