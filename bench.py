@@ -369,6 +369,16 @@ def main():
         step(a.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("FD_BENCH_ENQUEUE"):
+        # host-side cost of a step: time inside step() with the GPU running asynchronously behind it.  If it is close to
+        # ms_per_step the launch stream, not the GPU, bounds the step.
+        cpu = []
+        for i in range(5):
+            t1 = time.perf_counter()
+            step(a.warmup + i)
+            cpu.append((time.perf_counter() - t1) * 1e3)
+        barrier()
+        sys.stderr.write(f"host enqueue time per step (ms): {[round(c, 2) for c in cpu]}; timed {dt / a.steps * 1e3:.2f}\n")
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)

@@ -12,6 +12,8 @@ python bench.py --mode sample --n-res 256 --batch 1 --steps 1 --warmup 1 > $O/be
 python bench.py --mode sample --n-res 512 --batch 8 --steps 1 --warmup 0 > $O/bench_sample_n512_b8.json 2>/dev/null
 python bench.py --mode sample --n-res 128 --batch 32 --steps 1 --warmup 0 > $O/bench_sample_n128_b32.json 2>/dev/null
 python tools/bench_edge_mlp.py --shapes 30x128,8x128,1x128,1x256,1x512 > $O/edge_mlp_microbench.log 2>&1
+python tools/bench_pair_dw.py > $O/pair_dw_microbench.log 2>&1
+python tools/bench_gemm.py --only kk --iters 50 > $O/gemm_s64_microbench.log 2>&1
 # per-kernel time of the training step, launches serialised
 FD_BENCH_PROFILE=1 FD_GRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python bench.py --steps 5 --warmup 2 --no-sampling --no-cpu-baseline > $O/kt.log 2>&1
 python tools/kernel_stats_md.py $O/kt/p_kernel_stats.csv "training step B=30 x N=128, 7 steps, FD_GRAD_STREAM=0 (serialised)" > $O/train_kernel_stats.md
@@ -20,5 +22,7 @@ rocprofv3 --kernel-trace --stats -d $O/ks -o p --output-format csv -- python ben
 python tools/kernel_stats_md.py $O/ks/p_kernel_stats.csv "sampling N=128 B=1, 100 steps, eager launches" > $O/sample_n128_b1_kernel_stats.md
 bash tools/pmc_edge_mlp.sh > $O/pmc_edge_mlp.txt 2>&1
 bash tools/pmc_step.sh > $O/pmc_step.txt 2>&1
+bash tools/pmc_pair_dw.sh > $O/pmc_pair_dw.txt 2>&1
+bash tools/prof_gap.sh > $O/step_gap.txt 2>&1
 find $O -name "*.csv" -size +512k -delete
 ls -la $O
