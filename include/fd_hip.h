@@ -235,6 +235,14 @@ int fd_ipa_opair_fwd(const float* A, const float* zb, float* feats, int B, int N
 int fd_ipa_opair_bwd(const float* A, const float* zb, const float* dfeats, float* dA, float* dzb, int B, int N,
                      void* stream);
 
+/* softmax + o_pair of a query row in one launch (fd_ipa_softmax_fwd followed by fd_ipa_opair_fwd, bit-identical), and
+ * their backward (fd_ipa_opair_bwd followed by fd_ipa_softmax_bwd): the probabilities / the updated dA stay in LDS */
+int fd_ipa_attn_fwd(float* S, const float* zb, const float* qp, const float* kp, const float* head_w,
+                    const float* mask, float* feats, int B, int N, void* stream);
+int fd_ipa_attn_bwd(const float* A, float* dA, const float* zb, const float* dfeats, const float* qp, const float* kp,
+                    const float* head_w, float* dzb, float* dqp, float* dkp, float* dhead_w, float* hw_part, int B,
+                    int N, void* stream);
+
 /* dkp[b,j,h,:] = gamma_h sum_i dLogits[b,h,i,j] (qp[b,i,h,:] - kp[b,j,h,:]) (the key-side point gradient) */
 int fd_ipa_kpts_bwd(const float* dL, const float* qp, const float* kp, const float* head_w, float* dkp, int B, int N,
                     void* stream);

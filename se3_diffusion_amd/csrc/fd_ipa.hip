@@ -133,7 +133,10 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict_
                                                               const float* __restrict__ qp,
                                                               const float* __restrict__ kp,
                                                               const float* __restrict__ head_w,
-                                                              const float* __restrict__ mask, int N) {
+                                                              const float* __restrict__ mask, float* __restrict__ feats,
+                                                              int N) {
+  // feats != nullptr: o_pair of the same (b, i) row is taken from the probabilities while they are in LDS
+  // (fd_ipa_attn_fwd: one launch and one pass over A less than softmax + opair)
   __shared__ float lg[H][MAXN];
   const long bi = blockIdx.x;
   const int b = (int)(bi / N), i = (int)(bi % N);
@@ -173,32 +176,77 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict_
       sum += e;
     }
     sum = fd::wave_sum(sum);
-    for (int j = lane; j < N; j += 64) Srow[j] = lg[h][j] / sum;
+    for (int j = lane; j < N; j += 64) {
+      const float a = lg[h][j] / sum;
+      Srow[j] = a;
+      lg[h][j] = a;
+    }
+  }
+  if (feats != nullptr) {
+    __syncthreads();
+    const int h = (int)threadIdx.x / CZ4, c = (int)threadIdx.x % CZ4;
+    const float* z = zb + bi * N * ZB + H + c;
+    float acc = 0.f;
+    for (int j = 0; j < N; ++j) acc += lg[h][j] * z[(long)j * ZB];
+    feats[bi * LDF + F_PAIR + h * CZ4 + c] = acc;
   }
 }
 
 // dL = A * (dA - sum_j A dA) written over dA; d(zb bias) = sqrt(1/3) dL; dqp_i; d head_w
+// FUSED (fd_ipa_attn_bwd): the o_pair backward of the same (b, i) row first -- dzb[:, 8:40] = sum_h A dout and
+// dA += dout . pair_z -- with A and the updated dA held in LDS (one launch, one pass over A and one over dA less).
+template <bool FUSED>
 __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __restrict__ A, float* __restrict__ dA,
                                                               const float* __restrict__ qp,
                                                               const float* __restrict__ kp,
                                                               const float* __restrict__ head_w,
                                                               float* __restrict__ dzb, float* __restrict__ dqp,
-                                                              float* __restrict__ hw_part, int N) {
+                                                              float* __restrict__ hw_part, const float* __restrict__ zb,
+                                                              const float* __restrict__ dfeats, int N) {
   __shared__ float dl_s[H][MAXN];
+  __shared__ float Ai[FUSED ? H : 1][FUSED ? MAXN : 1];
+  __shared__ float dout[H][CZ4];
   const long bi = blockIdx.x;
   const int b = (int)(bi / N), i = (int)(bi % N);
   const int lane = fd::lane_id(), wave = fd::wave_id();
   const float sq13 = sqrtf(1.0f / 3.0f);
   const float gscale = sqrtf(1.0f / (3.0f * ((float)PQ * 9.0f / 2.0f)));
+  if (FUSED) {
+    for (int e = (int)threadIdx.x; e < H * N; e += 256) {
+      const int h = e / N, j = e % N;
+      Ai[h][j] = A[(((long)b * H + h) * N + i) * N + j];
+    }
+    dout[threadIdx.x / CZ4][threadIdx.x % CZ4] = dfeats[bi * LDF + F_PAIR + threadIdx.x];
+    __syncthreads();
+    // d pair_z[b,i,j,c] = sum_h A[h][j] * dout[h][c]
+    for (int e = (int)threadIdx.x; e < N * CZ4; e += 256) {
+      const int j = e / CZ4, c = e % CZ4;
+      float acc = 0.f;
+#pragma unroll
+      for (int h = 0; h < H; ++h) acc += Ai[h][j] * dout[h][c];
+      dzb[(bi * N + j) * ZB + H + c] = acc;
+    }
+    // dA[b,h,i,j] + sum_c dout[h][c] * pair_z[b,i,j,c]
+    for (int e = (int)threadIdx.x; e < H * N; e += 256) {
+      const int h = e / N, j = e % N;
+      const float* z = zb + (bi * N + j) * ZB + H;
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < CZ4; ++c) acc += dout[h][c] * z[c];
+      dl_s[h][j] = dA[(((long)b * H + h) * N + i) * N + j] + acc;
+    }
+    __syncthreads();
+  }
   for (int hh = 0; hh < 2; ++hh) {
     const int h = wave * 2 + hh;
     const float w = head_w[h];
     const float gamma = softplus_f(w) * gscale;
     const long rowoff = (((long)b * H + h) * N + i) * N;
-    const float* Arow = A + rowoff;
+    const float* Arow = FUSED ? &Ai[h][0] : A + rowoff;
     float* dArow = dA + rowoff;
+    const float* dAin = FUSED ? &dl_s[h][0] : dArow;
     float dot = 0.f;
-    for (int j = lane; j < N; j += 64) dot += Arow[j] * dArow[j];
+    for (int j = lane; j < N; j += 64) dot += Arow[j] * dAin[j];
     dot = fd::wave_sum(dot);
     float q[PQ * 3], dq[PQ * 3];
     const float* qsrc = qp + (bi * H + h) * (PQ * 3);
@@ -206,7 +254,7 @@ __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __res
     for (int k = 0; k < PQ * 3; ++k) { q[k] = qsrc[k]; dq[k] = 0.f; }
     float dgam = 0.f;
     for (int j = lane; j < N; j += 64) {
-      const float dl = Arow[j] * (dArow[j] - dot);
+      const float dl = Arow[j] * (dAin[j] - dot);
       dArow[j] = dl;
       dl_s[h][j] = dl;
       const float* ksrc = kp + (((long)b * N + j) * H + h) * (PQ * 3);
@@ -433,8 +481,19 @@ extern "C" int fd_ipa_softmax_fwd(float* S, const float* zb, const float* qp, co
   FD_CHECK_ARG(N <= MAXN, "fd_ipa_softmax_fwd: N=%d exceeds %d", N, MAXN);
   if (B == 0 || N == 0) return FD_OK;
   hipLaunchKernelGGL(ipa_softmax_fwd_kernel, dim3((unsigned)((long)B * N)), dim3(256), 0, (hipStream_t)stream, S, zb,
-                     qp, kp, head_w, mask, N);
+                     qp, kp, head_w, mask, (float*)nullptr, N);
   FD_CHECK_LAUNCH("fd_ipa_softmax_fwd");
+  return FD_OK;
+}
+
+extern "C" int fd_ipa_attn_fwd(float* S, const float* zb, const float* qp, const float* kp, const float* head_w,
+                               const float* mask, float* feats, int B, int N, void* stream) {
+  FD_CHECK_ARG(N <= MAXN, "fd_ipa_attn_fwd: N=%d exceeds %d", N, MAXN);
+  FD_CHECK_ARG(feats != nullptr, "fd_ipa_attn_fwd: feats is required");
+  if (B == 0 || N == 0) return FD_OK;
+  hipLaunchKernelGGL(ipa_softmax_fwd_kernel, dim3((unsigned)((long)B * N)), dim3(256), 0, (hipStream_t)stream, S, zb,
+                     qp, kp, head_w, mask, feats, N);
+  FD_CHECK_LAUNCH("fd_ipa_attn_fwd");
   return FD_OK;
 }
 
@@ -446,9 +505,25 @@ extern "C" int fd_ipa_softmax_bwd(const float* A, float* dA, const float* qp, co
                                   void* stream) {
   FD_CHECK_ARG(N <= MAXN, "fd_ipa_softmax_bwd: N=%d exceeds %d", N, MAXN);
   if (B == 0 || N == 0) return FD_OK;
-  hipLaunchKernelGGL(ipa_softmax_bwd_kernel, dim3((unsigned)((long)B * N)), dim3(256), 0, (hipStream_t)stream, A, dA,
-                     qp, kp, head_w, dzb, dqp, hw_part, N);
+  hipLaunchKernelGGL(ipa_softmax_bwd_kernel<false>, dim3((unsigned)((long)B * N)), dim3(256), 0, (hipStream_t)stream, A,
+                     dA, qp, kp, head_w, dzb, dqp, hw_part, (const float*)nullptr, (const float*)nullptr, N);
   FD_CHECK_LAUNCH("fd_ipa_softmax_bwd");
+  {
+    int rc = fd_colsum_acc(hw_part, H, (long)B * N, H, dhead_w, stream);
+    if (rc != FD_OK) return rc;
+  }
+  return fd_ipa_kpts_bwd(dA, qp, kp, head_w, dkp, B, N, stream);
+}
+
+extern "C" int fd_ipa_attn_bwd(const float* A, float* dA, const float* zb, const float* dfeats, const float* qp,
+                               const float* kp, const float* head_w, float* dzb, float* dqp, float* dkp,
+                               float* dhead_w, float* hw_part, int B, int N, void* stream) {
+  FD_CHECK_ARG(N <= MAXN, "fd_ipa_attn_bwd: N=%d exceeds %d", N, MAXN);
+  FD_CHECK_ARG(zb && dfeats, "fd_ipa_attn_bwd: zb / dfeats are required");
+  if (B == 0 || N == 0) return FD_OK;
+  hipLaunchKernelGGL(ipa_softmax_bwd_kernel<true>, dim3((unsigned)((long)B * N)), dim3(256), 0, (hipStream_t)stream, A,
+                     dA, qp, kp, head_w, dzb, dqp, hw_part, zb, dfeats, N);
+  FD_CHECK_LAUNCH("fd_ipa_attn_bwd");
   {
     int rc = fd_colsum_acc(hw_part, H, (long)B * N, H, dhead_w, stream);
     if (rc != FD_OK) return rc;

@@ -97,6 +97,7 @@ _FUSED_EMBED = os.environ.get("FD_EMBED_FUSED", "1") != "0"
 # than the launch sequence it replaces at the training size (B=30 x N=128: forward 325 vs 260 us, backward 758 vs 450 us
 # per block -- one (b, i) row per block serialises its phases at 2 blocks per CU), so it is opt-in
 FUSED_IPA_PAIR = os.environ.get("FD_IPA_PAIR_FUSED", "0") != "0"
+FUSED_IPA_ATTN = os.environ.get("FD_IPA_ATTN_FUSED", "1") != "0"   # softmax + o_pair per query row in one launch
 
 
 def fused_embed():
@@ -217,14 +218,18 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
     else:
         zb = empty((Pn, ZB), dev)
         ops.linear(mv(z), mv(W40), b40, mv(zb), Pn, ZB, CZ)
-        L.call("fd_ipa_softmax_fwd", A, zb, qp, kp, P[f"{pre}.head_weights"], mask, B, N)
+        if FUSED_IPA_ATTN:
+            # logits + softmax (A in place) + o_pair (the pair part of feats) of every query row in one launch
+            L.call("fd_ipa_attn_fwd", A, zb, qp, kp, P[f"{pre}.head_weights"], mask, feats, B, N)
+        else:
+            L.call("fd_ipa_softmax_fwd", A, zb, qp, kp, P[f"{pre}.head_weights"], mask, B, N)
     L.gemm(A, proj, feats, N, C, N, (N, 1), (LDP, 1), LDF, b_off=2048 + C, batch=B * H, bdiv=H,
            a_bs=(H * N * N, N * N), b_bs=(N * LDP, 2 * C), c_bs=(N * LDF, C))
     optg = empty((R, H, PV * 3), dev)
     L.gemm(A, vp, optg, N, PV * 3, N, (N, 1), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
            a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
     L.call("fd_ipa_opt_fwd", optg, quat, trans, feats, R)
-    if not fused:
+    if not fused and not FUSED_IPA_ATTN:
         L.call("fd_ipa_opair_fwd", A, zb, feats, B, N)
     x1 = empty((R, CS), dev)
     ops.linear(mv(feats), mv(P[f"{pre}.linear_out.weight"]), P[f"{pre}.linear_out.bias"], mv(x1), R, CS, LDF,
@@ -276,11 +281,13 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True):
         L.call("fd_ipa_pair_bwd", A, dA, z, sv["W40"], sv["b40"], dfeats, qp, kp, P[f"{pre}.head_weights"], dz,
                int(bool(dz_accumulate)), dqp, dkp, dhw, hw_part, dW40, db40, B, N)
     else:
-        # o_pair
+        # o_pair backward + softmax backward (dA becomes dLogits) + point / bias / head-weight grads
         dzb = empty((Pn, ZB), dev)
-        L.call("fd_ipa_opair_bwd", A, zb, dfeats, dA, dzb, B, N)
-        # softmax (dA becomes dLogits) + point/bias/head-weight grads
-        L.call("fd_ipa_softmax_bwd", A, dA, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, hw_part, B, N)
+        if FUSED_IPA_ATTN:
+            L.call("fd_ipa_attn_bwd", A, dA, zb, dfeats, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, hw_part, B, N)
+        else:
+            L.call("fd_ipa_opair_bwd", A, zb, dfeats, dA, dzb, B, N)
+            L.call("fd_ipa_softmax_bwd", A, dA, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, hw_part, B, N)
     sc = math.sqrt(1.0 / (3 * C))
     # dQ = sc * dL K ; dK = sc * dL^T Q
     L.gemm(dA, proj, dproj, N, C, N, (N, 1), (LDP, 1), LDP, b_off=2048, batch=B * H, bdiv=H,

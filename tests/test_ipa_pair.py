@@ -41,6 +41,11 @@ def _run(dev, B, N, seed=0):
     L.call("fd_ipa_softmax_fwd", S_u, zb, t["qp"], t["kp"], t["hw"], t["mask"], B, N)
     f_u = zer(R, LDF)
     L.call("fd_ipa_opair_fwd", S_u, zb, f_u, B, N)
+    # softmax + o_pair in one launch (fd_ipa_attn_fwd, the shipped path): the same arithmetic, bit for bit
+    S_a = t["S0"].clone()
+    f_a = zer(R, LDF)
+    L.call("fd_ipa_attn_fwd", S_a, zb, t["qp"], t["kp"], t["hw"], t["mask"], f_a, B, N)
+    assert torch.equal(S_a, S_u) and torch.equal(f_a, f_u)
     S_f = t["S0"].clone()
     f_f = zer(R, LDF)
     L.call("fd_ipa_pair_fwd", S_f, t["z"], t["W40"], t["b40"], t["qp"], t["kp"], t["hw"], t["mask"], f_f, B, N)
@@ -53,6 +58,13 @@ def _run(dev, B, N, seed=0):
     L.call("fd_ipa_opair_bwd", S_u, zb, t["dfeats"], dA_u, dzb, B, N)
     dqp_u, dkp_u, dhw_u, part = e(R, H, PQ * 3), e(R, H, PQ * 3), zer(H), e(R, H)
     L.call("fd_ipa_softmax_bwd", S_u, dA_u, t["qp"], t["kp"], t["hw"], dzb, dqp_u, dkp_u, dhw_u, part, B, N)
+    # o_pair backward + softmax backward in one launch (fd_ipa_attn_bwd): bit-identical to the pair of launches
+    dA_a, dzb_a = t["dA0"].clone(), e(P, ZB)
+    dqp_a, dkp_a, dhw_a, part_a = e(R, H, PQ * 3), e(R, H, PQ * 3), zer(H), e(R, H)
+    L.call("fd_ipa_attn_bwd", S_u, dA_a, zb, t["dfeats"], t["qp"], t["kp"], t["hw"], dzb_a, dqp_a, dkp_a, dhw_a, part_a, B, N)
+    for name, got, want in (("dA", dA_a, dA_u), ("dzb", dzb_a, dzb), ("dqp", dqp_a, dqp_u), ("dkp", dkp_a, dkp_u)):
+        assert torch.equal(got, want), name
+    assert rel(dhw_a, dhw_u) < 1e-5          # (column sums of per-row partials: atomics, order not fixed)
     dz_u = t["dz0"].clone()
     ops.linear_dx(mv(dzb), mv(t["W40"]), mv(dz_u), P, ZB, CZ, beta=True)
     dW_u, db_u = zer(ZB, CZ), zer(ZB)
