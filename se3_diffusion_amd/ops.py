@@ -24,7 +24,38 @@ def empty(shape, like, dtype=F32):
 
 
 def zeros(shape, like, dtype=F32):
+    a = _ARENA["buf"]
+    if a is not None and dtype == F32 and a.device == like.device:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        lo = _ARENA["used"]
+        hi = lo + (n + 63) // 64 * 64                 # 256-byte aligned slices (16-byte operand paths of the kernels)
+        if hi <= a.numel():
+            _ARENA["used"] = hi
+            return a[lo:lo + n].view(shape)
     return torch.zeros(shape, device=like.device, dtype=dtype)
+
+
+# Zero arena: the backward pass needs ~15 zero-initialised accumulators per block (gradient sums that several launches add
+# into).  One memset over one buffer replaces the ~60 fill launches of a step (7.5 us each); zeros() carves from it
+# while it is open and falls back to torch.zeros when it is exhausted or closed.
+_ARENA = {"buf": None, "used": 0}
+
+
+class zero_arena:
+    def __init__(self, numel, like):
+        self.numel, self.like = int(numel), like
+
+    def __enter__(self):
+        self.prev = dict(_ARENA)
+        _ARENA["buf"] = torch.zeros(self.numel, device=self.like.device, dtype=F32) if self.numel > 0 else None
+        _ARENA["used"] = 0
+        return self
+
+    def __exit__(self, *exc):
+        _ARENA.update(self.prev)
+        return False
 
 
 # ---------------------------------------------------------------------------

@@ -62,6 +62,7 @@ def _edge_mlp_image(P, pre, cache, backward=False):
 _FUSED_EDGE = os.environ.get("FD_EDGE_FUSED", "1") != "0"
 
 
+_ZERO_ARENA = os.environ.get("FD_ZERO_ARENA", "1") != "0"   # one memset for the backward pass's zero-initialised sums
 _GROUPED_DW = os.environ.get("FD_PAIR_DW", "1") != "0"   # grouped weight-gradient kernel (fd_pair_dw) behind the fused chain
 
 
@@ -424,6 +425,17 @@ def backward(P, G, sv, d_out, on_done=None):
     dev = sv["mask"]
     if sv["bool_mask"]:
         raise NotImplementedError("backward is defined for the training-mode (additive) transformer mask")
+    # every zero-initialised accumulator of the pass from one memset (per block: dproj [R,6816], the node-term sums of the
+    # edge transition [R,2*(128+384)], du0, ds, dframe, ...: ~R * 8,700 floats)
+    with ops.zero_arena(R * (nb * 8800 + 1024) + 65536 if _ZERO_ARENA else 0, dev):
+        _backward(P, G, sv, d_out, notify)
+
+
+def _backward(P, G, sv, d_out, notify):
+    B, N, nb = sv["B"], sv["N"], sv["num_blocks"]
+    R, Pn = B * N, B * N * N
+    f = sv["feats"]
+    dev = sv["mask"]
     dnode = zeros((R, CS), dev)
     with rng("heads.bwd"):
         dq, dt = heads_bwd(P, G, sv["heads"], f, d_out, dnode)
