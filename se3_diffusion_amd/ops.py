@@ -80,6 +80,9 @@ def linear(x, W, b, out, M, N, K, *, relu=False, resid=None, rowscale=None, pair
                relu=relu, rowscale=rowscale, pair=pair, beta=beta, alpha=alpha, tile=tile, **kw)
 
 
+_DX_SPLITK = os.environ.get("FD_DX_SPLITK", "1") != "0"
+
+
 def linear_dx(dy, W, dx, M, N, K, *, beta=False, gate=None, rowscale=None, alpha=1.0, resid=None):
     """dx[M,K] (+)= dy[M,N] @ W[N,K]; optional relu gate (zero where gate<=0) on the result; resid adds a
     second matrix view (dx = resid + dy W: a residual branch without accumulating in place)."""
@@ -91,6 +94,13 @@ def linear_dx(dy, W, dx, M, N, K, *, beta=False, gate=None, rowscale=None, alpha
         kw.update(gate=(gate[0], gate[1]), ld_gate=gate[2])
     if resid is not None:
         kw.update(resid=(resid[0], resid[1]), ld_resid=resid[2])
+    if beta and not kw and rowscale is None and N >= 1024 and _DX_SPLITK:
+        # an accumulating dX with a long reduction and few output tiles (IPA projections: 3840 x 256 over N = 2048 / 4096
+        # is 240 tiles of 64 x 64 walking 64..128 stages each): split the reduction, the partial tiles add atomically
+        # into the accumulator that is already there
+        lib().gemm(dt, wt, xt, M, K, N, (dl, 1), (wl, 1), xl, a_off=do, b_off=wo, c_off=xo, alpha=alpha,
+                   ksplit=min(8, N // 512))
+        return
     lib().gemm(dt, wt, xt, M, K, N, (dl, 1), (wl, 1), xl, a_off=do, b_off=wo, c_off=xo, beta=beta,
                rowscale=rowscale, alpha=alpha, **kw)
 
