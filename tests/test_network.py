@@ -103,6 +103,10 @@ def test_forward_backward_gpu(hip_lib):
     run_case("cuda", B=2, N=12, blocks=4, seed=0, n_pad=2, n_fixed=3)
     run_case("cuda", B=3, N=40, blocks=4, seed=5)
     run_case("cuda", B=1, N=100, blocks=2, seed=6, n_pad=7, check_grad=False)
+    # odd lengths (mixed-length training, BASELINE configs[3]): pair-row counts that are no multiple of 16 / 64 -- ragged
+    # last tiles of the fused edge kernels, ragged last stage of the grouped weight gradients, unaligned M of the GEMMs
+    run_case("cuda", B=3, N=37, blocks=2, seed=7, n_pad=3)
+    run_case("cuda", B=2, N=101, blocks=1, seed=8)
 
 
 def _golden(dev, name, mode_train=True):
