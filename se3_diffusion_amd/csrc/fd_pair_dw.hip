@@ -164,29 +164,50 @@ __device__ __forceinline__ void dw_block(const FdPairDwItem& it, long row0, long
     }
   };
 
+  // Stages that lie entirely inside the row range are loaded through running pointers without the clamp / select of
+  // load() (it costs ~35 of the ~135 VALU instructions a wave spends per stage, six of them quarter-rate 32-bit
+  // multiplies, and the SIMD's issue port is shared with the MFMAs): the pointers always stand at the next stage.
+  const float* pa = A + ((long)3 * DW_KS + kk) * it.lda + 4 * c4;
+  const float* pb = B + ((long)3 * DW_KS + kk) * it.ldb + 4 * c4;
+  const float* pd = Ad + ((long)3 * DW_KS + kk) * it.ld_add + 4 * c4;
+  const long sa = (long)DW_KS * it.lda, sb = (long)DW_KS * it.ldb, sd = (long)DW_KS * it.ld_add;
+  auto load_fast = [&](float4 (&r)[4], float4& ra) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r[i] = *reinterpret_cast<const float4*>(pa + 128 * i);
+    r[3] = *reinterpret_cast<const float4*>(pb);
+    if (has_add) ra = *reinterpret_cast<const float4*>(pd);
+    pa += sa;
+    pb += sb;
+    if (has_add) pd += sd;
+  };
+
   // ---- pipeline: stage s lives in register set s & 1 (loaded two stages ahead) and ring slot s & 1 ----
   load(rg[0], radd[0], 0);
   load(rg[1], radd[1], 1);
   put(rg[0], radd[0], lds);
   load(rg[0], radd[0], 2);
   __syncthreads();
-  const bool mma_first = true;
-  auto step = [&](int s, float4 (&r)[4], float4& ra) __attribute__((always_inline)) {
-    // r / ra: the register set of stage s + 1 (stages past the end are zeros: see load)
-    // Waves w and w + 4 share a SIMD: one multiplies first and stages second, the other the opposite, so that the split
-    // VALU work of one runs under the MFMAs of the other instead of both queueing for the same pipe in the same phase.
-    if (mma_first) {
-      mma(lds + (s & 1) * DW_STAGE);
-      put(r, ra, lds + ((s + 1) & 1) * DW_STAGE);
-      load(r, ra, s + 3);
-    } else {
-      put(r, ra, lds + ((s + 1) & 1) * DW_STAGE);
-      load(r, ra, s + 3);
-      mma(lds + (s & 1) * DW_STAGE);
-    }
+  // multiply first, stage second: the compiler fills the MFMA shadow with the split of the next stage
+  auto step_fast = [&](int s, float4 (&r)[4], float4& ra) __attribute__((always_inline)) {
+    // r / ra: the register set of stage s + 1, refilled with stage s + 3
+    mma(lds + (s & 1) * DW_STAGE);
+    put(r, ra, lds + ((s + 1) & 1) * DW_STAGE);
+    load_fast(r, ra);
     __syncthreads();
   };
-  for (int s = 0; s < nst; s += 2) {
+  auto step = [&](int s, float4 (&r)[4], float4& ra) __attribute__((always_inline)) {
+    mma(lds + (s & 1) * DW_STAGE);
+    put(r, ra, lds + ((s + 1) & 1) * DW_STAGE);
+    load(r, ra, s + 3);          // (stages past the end are zeros: see load)
+    __syncthreads();
+  };
+  const int nfull = (int)(nrows / DW_KS);      // stages 0 .. nfull-1 are entirely inside the range
+  int s = 0;
+  for (; s + 5 <= nfull; s += 2) {             // both refills (stages s + 3, s + 4) are full stages
+    step_fast(s, rg[1], radd[1]);
+    step_fast(s + 1, rg[0], radd[0]);
+  }
+  for (; s < nst; s += 2) {
     step(s, rg[1], radd[1]);
     step(s + 1, rg[0], radd[0]);   // nst odd: one stage of zeros
   }
