@@ -205,6 +205,13 @@ typedef struct FdPairDwDesc {
 } FdPairDwDesc;
 int fd_pair_dw(const FdPairDwDesc* desc, void* stream);
 
+/* ---- sequence-transformer self-attention, fused (torch.nn.TransformerEncoderLayer.self_attn inside IpaScore,
+ * model/ipa_pytorch.py:584-593; nhead 4, d_model 320): out = softmax(scale * q k^T + key_add) v per (batch, head) in one
+ * launch (se3_diffusion_amd/csrc/fd_seq_attn.hip).  qkv [B*N, 960] = in_proj output [q | k | v]; key_add [B, N] additive
+ * key mask or null; out [B*N, 320]; A_out [B, 4, N, N] optional (the probabilities, for the backward).  N <= 1024. */
+int fd_seq_attn_fwd(const float* qkv, const float* key_add, float* out, float* A_out, float scale, int B, int N,
+                    void* stream);
+
 /* ---- embedder features: score_network.py:14-47,97-148; data/utils.py:570-580 ----
  * tscaled = (t*1e4) as fp32 [B]; tfreq[16], idenom[16], dg_lower[22], dg_upper[22] are the
  * host-computed tables of the reference's own op sequence. */

@@ -148,6 +148,7 @@ _SIGS = {
     "fd_ipa_points_bwd": "pppppppliiiis",
     "fd_ipa_softmax_fwd": "ppppppiis",
     "fd_ipa_attn_fwd": "pppppppiis",
+    "fd_seq_attn_fwd": "ppppfiis",
     "fd_ipa_attn_bwd": "ppppppppppppiis",
     "fd_ipa_softmax_bwd": "ppppppppppiis",
     "fd_ipa_kpts_bwd": "pppppiis",

@@ -98,6 +98,7 @@ _FUSED_EMBED = os.environ.get("FD_EMBED_FUSED", "1") != "0"
 # per block -- one (b, i) row per block serialises its phases at 2 blocks per CU), so it is opt-in
 FUSED_IPA_PAIR = os.environ.get("FD_IPA_PAIR_FUSED", "0") != "0"
 FUSED_IPA_ATTN = os.environ.get("FD_IPA_ATTN_FUSED", "1") != "0"   # softmax + o_pair per query row in one launch
+FUSED_SEQ_ATTN = os.environ.get("FD_SEQ_ATTN_FUSED", "1") != "0"   # sequence-transformer attention in one launch
 
 
 def fused_embed():
@@ -334,19 +335,25 @@ def ln_skip_bwd(P, G, b, sv, du0, dx1, dinit):
 
 
 # --------------------------------------------------------------------------- transformer layer
-def tfmr_layer_fwd(P, pre, x, key_add, B, N):
+def tfmr_layer_fwd(P, pre, x, key_add, B, N, save=True):
     dev = x
     R = B * N
     L = lib()
     qkv = empty((R, 3 * TD), dev)
     ops.linear(mv(x), mv(P[f"{pre}.self_attn.in_proj_weight"]), P[f"{pre}.self_attn.in_proj_bias"], mv(qkv), R, 3 * TD, TD)
-    A = empty((B, TH, N, N), dev)
-    L.gemm(qkv, qkv, A, N, N, THD, (3 * TD, 1), (1, 3 * TD), N, b_off=TD, batch=B * TH, bdiv=TH,
-           a_bs=(N * 3 * TD, THD), b_bs=(N * 3 * TD, THD), c_bs=(TH * N * N, N * N), alpha=1.0 / math.sqrt(THD))
-    L.call("fd_row_softmax_fwd", A, key_add, B * TH * N, N, TH * N)
     o = empty((R, TD), dev)
-    L.gemm(A, qkv, o, N, THD, N, (N, 1), (3 * TD, 1), TD, b_off=2 * TD, batch=B * TH, bdiv=TH,
-           a_bs=(TH * N * N, N * N), b_bs=(N * 3 * TD, THD), c_bs=(N * TD, THD))
+    if FUSED_SEQ_ATTN:
+        # scores + key mask + softmax + value product of every (batch, head) in one launch; the probabilities reach HBM
+        # only when a backward pass will need them
+        A = empty((B, TH, N, N), dev) if save else None
+        L.call("fd_seq_attn_fwd", qkv, key_add, o, A, 1.0 / math.sqrt(THD), B, N)
+    else:
+        A = empty((B, TH, N, N), dev)
+        L.gemm(qkv, qkv, A, N, N, THD, (3 * TD, 1), (1, 3 * TD), N, b_off=TD, batch=B * TH, bdiv=TH,
+               a_bs=(N * 3 * TD, THD), b_bs=(N * 3 * TD, THD), c_bs=(TH * N * N, N * N), alpha=1.0 / math.sqrt(THD))
+        L.call("fd_row_softmax_fwd", A, key_add, B * TH * N, N, TH * N)
+        L.gemm(A, qkv, o, N, THD, N, (N, 1), (3 * TD, 1), TD, b_off=2 * TD, batch=B * TH, bdiv=TH,
+               a_bs=(TH * N * N, N * N), b_bs=(N * 3 * TD, THD), c_bs=(N * TD, THD))
     t1 = empty((R, TD), dev)
     ops.linear(mv(o), mv(P[f"{pre}.self_attn.out_proj.weight"]), P[f"{pre}.self_attn.out_proj.bias"], mv(t1), R, TD, TD, resid=mv(x))
     y1 = empty((R, TD), dev); m1 = empty((R,), dev); r1 = empty((R,), dev)

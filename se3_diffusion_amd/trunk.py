@@ -388,7 +388,7 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
             u0 = u
             sv_t = []
             for l in range(2):
-                u, s_ = nw.tfmr_layer_fwd(P, f"score_model.trunk.seq_tfmr_{b}.layers.{l}", u, key_add, B, N)
+                u, s_ = nw.tfmr_layer_fwd(P, f"score_model.trunk.seq_tfmr_{b}.layers.{l}", u, key_add, B, N, save=save)
                 sv_t.append(s_)
             if tfmr_bool_mask:
                 u2 = empty((R, TD), dev)

@@ -37,6 +37,13 @@ SHAPES = [
     ("ipa_proj NT t2", 3840, 6816, 256, True, True, 2, 1),
     ("ipa_out NT", 3840, 256, 2688, True, True, 2, 1),
     ("z_to_40 NT", P, 40, 128, True, True, 3, 1),
+    ("z_to_40 NT t2", P, 40, 128, True, True, 2, 1),
+    ("z_to_40 NT t10", P, 40, 128, True, True, 10, 1),
+    ("dz_from_40 NN beta t10", P, 128, 40, True, False, 10, 1),
+    ("z_to_40 NT t4", P, 40, 128, True, True, 4, 1),
+    ("z_to_40 NT t1", P, 40, 128, True, True, 1, 1),
+    ("dz_from_40 NN beta t1", P, 128, 40, True, False, 1, 1),
+    ("dz_from_40 NN beta t2", P, 128, 40, True, False, 2, 1),
     ("sample N=128 proj", 128, 6816, 256, True, True, 2, 1),
     ("sample edge W2 N=128", 16384, 384, 384, True, True, 1, 1),
     ("sample edge W2 N=128 t2", 16384, 384, 384, True, True, 2, 1),
