@@ -141,6 +141,8 @@ typedef struct FdEdgeMlpDesc {
   int backward;
   float eps;
   int blocks;            /* 0 = one persistent block per CU (256) */
+  long ld_pq;            /* row stride of p1 / q1 (0 = 384) */
+  long ld_pqf;           /* row stride of pf / qf (0 = 128) */
 } FdEdgeMlpDesc;
 int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream);
 

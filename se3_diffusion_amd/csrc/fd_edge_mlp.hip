@@ -98,6 +98,9 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
   const int lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
   const long rows = d.rows;
+  // row strides of the per-residue terms (0 = dense [B*nres, 384] / [B*nres, 128]; a caller that forms all four with one
+  // GEMM passes the width of that GEMM's output)
+  const long ld_pq = d.ld_pq > 0 ? d.ld_pq : EM_H, ld_pqf = d.ld_pqf > 0 ? d.ld_pqf : EM_C;
   const int ntiles = (int)((rows + EM_ROWS - 1) / EM_ROWS);
   const int G = (int)gridDim.x, first = (int)blockIdx.x;
   if (first >= ntiles) return;
@@ -191,8 +194,8 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc1[nb][e];
         if (!BWD) {
-          const float4 a = *reinterpret_cast<const float4*>(d.p1 + qi * EM_H + col);
-          const float4 bq = *reinterpret_cast<const float4*>(d.q1 + qj * EM_H + col);
+          const float4 a = *reinterpret_cast<const float4*>(d.p1 + qi * ld_pq + col);
+          const float4 bq = *reinterpret_cast<const float4*>(d.q1 + qj * ld_pq + col);
           v[0] += a.x + bq.x; v[1] += a.y + bq.y; v[2] += a.z + bq.z; v[3] += a.w + bq.w;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
@@ -286,8 +289,8 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) {
         const int col = 16 * nb + 4 * g;
-        const float4 pa = *reinterpret_cast<const float4*>(d.pf + qi * EM_C + col);
-        const float4 qa = *reinterpret_cast<const float4*>(d.qf + qj * EM_C + col);
+        const float4 pa = *reinterpret_cast<const float4*>(d.pf + qi * ld_pqf + col);
+        const float4 qa = *reinterpret_cast<const float4*>(d.qf + qj * ld_pqf + col);
         acc3[nb][0] += pa.x + qa.x; acc3[nb][1] += pa.y + qa.y; acc3[nb][2] += pa.z + qa.z; acc3[nb][3] += pa.w + qa.w;
         s += (acc3[nb][0] + acc3[nb][1]) + (acc3[nb][2] + acc3[nb][3]);
         if (d.y != nullptr && rok)

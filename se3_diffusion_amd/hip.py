@@ -82,6 +82,7 @@ class FdEdgeMlpDesc(Structure):
         ("pf", c_void_p), ("qf", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("rowscale", c_void_p),
         ("y", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("out", c_void_p),
         ("rows", c_long), ("nres", c_int), ("backward", c_int), ("eps", c_float), ("blocks", c_int),
+        ("ld_pq", c_long), ("ld_pqf", c_long),
     ]
 
 

@@ -260,7 +260,7 @@ def edge_mlp_pack(W1, W2, Wf, backward=False, out=None):
 
 def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, qf=None, gamma=None, beta=None,
              rowscale=None, gate1=None, gate2=None, save1=None, save2=None, y=None, mean=None, rstd=None,
-             backward=False, blocks=0):
+             backward=False, blocks=0, ld_pq=0, ld_pqf=0):
     d = hip.FdEdgeMlpDesc()
     tens = []
     for name, t in (("x", x), ("img", img), ("p1", p1), ("q1", q1), ("bias2", bias2), ("gate1", gate1), ("gate2", gate2),
@@ -270,6 +270,7 @@ def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, 
         if t is not None:
             tens.append(t)
     d.rows, d.nres, d.backward, d.eps, d.blocks = int(rows), int(nres), int(bool(backward)), 1e-5, int(blocks)
+    d.ld_pq, d.ld_pqf = int(ld_pq), int(ld_pqf)
     L = lib()
     stream = L._stream(tens)
     prof = L.gemm_profile

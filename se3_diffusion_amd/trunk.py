@@ -62,6 +62,7 @@ def _edge_mlp_image(P, pre, cache, backward=False):
 _FUSED_EDGE = os.environ.get("FD_EDGE_FUSED", "1") != "0"
 
 
+_FOLD_NODE_TERMS = os.environ.get("FD_FOLD_NODE_TERMS", "1") != "0"   # sampling: per-residue terms of the edge transition in 1 GEMM
 _ZERO_ARENA = os.environ.get("FD_ZERO_ARENA", "1") != "0"   # one memset for the backward pass's zero-initialised sums
 _GROUPED_DW = os.environ.get("FD_PAIR_DW", "1") != "0"   # grouped weight-gradient kernel (fd_pair_dw) behind the fused chain
 
@@ -80,17 +81,40 @@ def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None):
     dev = z
     R, Pn = B * N, B * N * N
     W1, Wf = P[f"{pre}.trunk.0.weight"], P[f"{pre}.final_layer.weight"]
-    e = empty((R, CE), dev)
-    ops.linear(mv(n3), mv(P[f"{pre}.initial_embed.weight"]), P[f"{pre}.initial_embed.bias"], mv(e), R, CE, CS)
-    # node halves of the two concat-linears: W [z | e_i | e_j] = W_z z + (W_i e)_i + (W_j e)_j
-    P1 = empty((R, EH), dev); Q1 = empty((R, EH), dev); Pf = empty((R, CZ), dev); Qf = empty((R, CZ), dev)
-    ops.linear(mv(e), (W1, CZ, EH), None, mv(P1), R, EH, CE)
-    ops.linear(mv(e), (W1, CZ + CE, EH), P[f"{pre}.trunk.0.bias"], mv(Q1), R, EH, CE)
-    ops.linear(mv(e), (Wf, CZ, EH), None, mv(Pf), R, CZ, CE)
-    ops.linear(mv(e), (Wf, CZ + CE, EH), P[f"{pre}.final_layer.bias"], mv(Qf), R, CZ, CE)
+    kw = {}
+    if cache is not None and not save and _FOLD_NODE_TERMS:
+        # static weights (sampling): the per-residue terms P1 | Q1 | Pf | Qf = [W1_i; W1_j; Wf_i; Wf_j] (W_init n3 + b_init)
+        # (+ b1, b_f) are ONE GEMM of n3 against a matrix folded once per trajectory (5 launches -> 1); the fused kernel
+        # reads the four column blocks of its [R, 1024] output through their row stride
+        key = ("et_fold", pre)
+        if key not in cache:
+            Wi, bi = P[f"{pre}.initial_embed.weight"], P[f"{pre}.initial_embed.bias"]
+            Wcat = torch.cat([W1[:, CZ:CZ + CE], W1[:, CZ + CE:], Wf[:, CZ:CZ + CE], Wf[:, CZ + CE:]], 0).contiguous()
+            Wfold = empty((2 * EH + 2 * CZ, CS), dev)
+            ops.linear(mv(Wcat), mv(Wi.t().contiguous()), None, mv(Wfold), 2 * EH + 2 * CZ, CS, CE)
+            bvec = torch.cat([torch.zeros_like(P[f"{pre}.trunk.0.bias"]), P[f"{pre}.trunk.0.bias"],
+                              torch.zeros_like(P[f"{pre}.final_layer.bias"]), P[f"{pre}.final_layer.bias"]]).contiguous()
+            bfold = empty((1, 2 * EH + 2 * CZ), dev)
+            ops.linear(mv(bi.view(1, CE)), mv(Wcat), bvec, mv(bfold), 1, 2 * EH + 2 * CZ, CE)
+            cache[key] = (Wfold, bfold.view(-1))
+        Wfold, bfold = cache[key]
+        LDT = 2 * EH + 2 * CZ
+        PQ = empty((R, LDT), dev)
+        ops.linear(mv(n3), mv(Wfold), bfold, mv(PQ), R, LDT, CS)
+        P1, Q1, Pf, Qf = PQ[:, 0:], PQ[:, EH:], PQ[:, 2 * EH:], PQ[:, 2 * EH + CZ:]
+        kw = dict(ld_pq=LDT, ld_pqf=LDT)
+        e = None
+    else:
+        e = empty((R, CE), dev)
+        ops.linear(mv(n3), mv(P[f"{pre}.initial_embed.weight"]), P[f"{pre}.initial_embed.bias"], mv(e), R, CE, CS)
+        # node halves of the two concat-linears: W [z | e_i | e_j] = W_z z + (W_i e)_i + (W_j e)_j
+        P1 = empty((R, EH), dev); Q1 = empty((R, EH), dev); Pf = empty((R, CZ), dev); Qf = empty((R, CZ), dev)
+        ops.linear(mv(e), (W1, CZ, EH), None, mv(P1), R, EH, CE)
+        ops.linear(mv(e), (W1, CZ + CE, EH), P[f"{pre}.trunk.0.bias"], mv(Q1), R, EH, CE)
+        ops.linear(mv(e), (Wf, CZ, EH), None, mv(Pf), R, CZ, CE)
+        ops.linear(mv(e), (Wf, CZ + CE, EH), P[f"{pre}.final_layer.bias"], mv(Qf), R, CZ, CE)
     img = _edge_mlp_image(P, pre, cache)
     z2 = empty((Pn, CZ), dev)
-    kw = {}
     if save:
         h1 = empty((Pn, EH), dev); h2 = empty((Pn, EH), dev); y = empty((Pn, CZ), dev)
         mean = empty((Pn,), dev); rstd = empty((Pn,), dev)
