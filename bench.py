@@ -310,7 +310,7 @@ def main():
     from se3_diffusion_amd.optim import FlatAdam
     # Adam (torch.optim.Adam's rule, lr 1e-4 as train_se3_diffusion.py:139) over flat parameter / gradient / moment
     # buffers: param.grad are views of ONE buffer (single RCCL all-reduce), the update is one launch
-    opt = FlatAdam(model.parameters(), lr=1e-4)
+    opt = FlatAdam(model.parameters(), lr=1e-4, adjacent=model.flat_layout_groups())
     grads = opt
     model.accumulate_into_grad = True      # backward kernels accumulate straight into the flat all-reduce buffer
     overlap = None

@@ -115,6 +115,19 @@ class ScoreNetwork(nn.Module):
     def _apply_mask(self, aatype_diff, aatype_0, diff_mask):
         return diff_mask * aatype_diff + (1 - diff_mask) * aatype_0
 
+    def flat_layout_groups(self):
+        """Parameter groups that a flat optimiser (optim.FlatAdam(adjacent=...)) should lay out back to back: IPA's
+        linear_b / down_z weights and biases are read by the kernels as ONE [40, 128] matrix / [40] vector."""
+        groups = []
+        named = dict(self.named_parameters())
+        b = 0
+        while f"score_model.trunk.ipa_{b}.linear_b.weight" in named:
+            pre = f"score_model.trunk.ipa_{b}"
+            groups.append((named[f"{pre}.linear_b.weight"], named[f"{pre}.down_z.weight"]))
+            groups.append((named[f"{pre}.linear_b.bias"], named[f"{pre}.down_z.bias"]))
+            b += 1
+        return groups
+
     def forward(self, input_feats):
         """input_feats: res_mask[B,N], fixed_mask[B,N], seq_idx[B,N], t[B], sc_ca_t[B,N,3],
         rigids_t[B,N,7], torsion_angles_sin_cos[B,N,7,2] (extra keys ignored)."""

@@ -178,6 +178,24 @@ def pair_mask(mask, B, N):
     return em
 
 
+def _adjacent_view(a, b, shape):
+    """One tensor over a and b when b starts where a ends in the same storage (16-byte aligned start), else None."""
+    if (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.device == b.device
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and a.storage_offset() + a.numel() == b.storage_offset() and a.data_ptr() % 16 == 0):
+        strides, st = [], 1
+        for d in reversed(shape):
+            strides.append(st)
+            st *= d
+        return a.detach().as_strided(shape, tuple(reversed(strides)))
+    return None
+
+
+def _joined(a, b, shape):
+    v = _adjacent_view(a, b, shape)
+    return v if v is not None else torch.cat([a, b], 0).contiguous()
+
+
 # --------------------------------------------------------------------------- IPA
 def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
     """x1 = s + mask * IPA(s, z, T).  s: matrix view [R,256]."""
@@ -202,8 +220,10 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
     if cache is not None and ("W40", pre) in cache:
         W40, b40 = cache[("W40", pre)]
     else:
-        W40 = torch.cat([P[f"{pre}.linear_b.weight"], P[f"{pre}.down_z.weight"]], 0).contiguous()   # tiny pack
-        b40 = torch.cat([P[f"{pre}.linear_b.bias"], P[f"{pre}.down_z.bias"]], 0).contiguous()
+        # [linear_b ; down_z] as one [40, 128] operand: a view when the two parameters lie back to back (optim.FlatAdam with
+        # ScoreNetwork.flat_layout_groups()), a tiny pack otherwise
+        W40 = _joined(P[f"{pre}.linear_b.weight"], P[f"{pre}.down_z.weight"], (ZB, CZ))
+        b40 = _joined(P[f"{pre}.linear_b.bias"], P[f"{pre}.down_z.bias"], (ZB,))
         if cache is not None:
             cache[("W40", pre)] = (W40, b40)
     fused = FUSED_IPA_PAIR and N <= 512
@@ -300,12 +320,19 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True):
     if not fused:
         ops.linear_dx(mv(dzb), mv(sv["W40"]), mv(dz), Pn, ZB, CZ, beta=True)
     if G is not None:
-        if not fused:
-            dW40 = zeros((ZB, CZ), dev); db40 = zeros((ZB,), dev)
-            ops.linear_dw(mv(dzb), mv(z), mv(dW40), Pn, ZB, CZ)
-            ops.bias_grad(mv(dzb), db40, Pn, ZB)
-        G[f"{pre}.linear_b.weight"] += dW40[:H]; G[f"{pre}.down_z.weight"] += dW40[H:]
-        G[f"{pre}.linear_b.bias"] += db40[:H]; G[f"{pre}.down_z.bias"] += db40[H:]
+        gW = _adjacent_view(G[f"{pre}.linear_b.weight"], G[f"{pre}.down_z.weight"], (ZB, CZ))
+        gb = _adjacent_view(G[f"{pre}.linear_b.bias"], G[f"{pre}.down_z.bias"], (ZB,))
+        if not fused and gW is not None and gb is not None:
+            # the two gradients lie back to back in the flat gradient buffer: accumulate into them as one [40, 128] matrix
+            ops.linear_dw(mv(dzb), mv(z), mv(gW), Pn, ZB, CZ)
+            ops.bias_grad(mv(dzb), gb, Pn, ZB)
+        else:
+            if not fused:
+                dW40 = zeros((ZB, CZ), dev); db40 = zeros((ZB,), dev)
+                ops.linear_dw(mv(dzb), mv(z), mv(dW40), Pn, ZB, CZ)
+                ops.bias_grad(mv(dzb), db40, Pn, ZB)
+            G[f"{pre}.linear_b.weight"] += dW40[:H]; G[f"{pre}.down_z.weight"] += dW40[H:]
+            G[f"{pre}.linear_b.bias"] += db40[:H]; G[f"{pre}.down_z.bias"] += db40[H:]
     # projections: ds += dproj_slice W ; dW += dproj_slice^T s
     for name, off, n in (("linear_q", 0, 2048), ("linear_kv", 2048, 4096), ("linear_q_points", 6144, 192),
                          ("linear_kv_points", 6336, 480)):

@@ -3,7 +3,7 @@
 The reference trains with ``torch.optim.Adam(model.parameters(), lr=1e-4)`` (experiments/train_se3_diffusion.py:139);
 over 282 parameter tensors that is 8 multi-tensor launches (0.76 ms of a 37 ms step on MI355X).  ``FlatAdam`` keeps
 parameters, gradients and both moments in four flat fp32 buffers -- every ``p.data`` / ``p.grad`` is a view at a
-256-byte offset, so the GEMM kernels keep their 16-byte operand paths and the data-parallel all-reduce is one message -- and applies
+256-byte offset (16-byte inside an ``adjacent`` group), so the GEMM kernels keep their 16-byte operand paths and the data-parallel all-reduce is one message -- and applies
 the same update rule with one kernel.  ``state_dict`` / ``load_state_dict`` use torch.optim.Adam's layout, so
 checkpoints written by either optimiser load into the other.
 """
@@ -18,16 +18,32 @@ _ALIGN = 64   # elements: 256-byte aligned views
 
 
 class FlatAdam:
-    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, adjacent=None):
+        """adjacent: groups (tuples) of parameters to lay out back to back without padding, in the given order, at the
+        position of the group's first member (ScoreNetwork.flat_layout_groups(): weights that one kernel reads as one
+        matrix, e.g. IPA's [linear_b ; down_z]).  The state_dict order stays that of `params`."""
         self.params = [p for p in params if p.requires_grad]
         assert self.params, "no trainable parameters"
         assert all(p.dtype == torch.float32 for p in self.params), "fp32 parameters only"
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         dev = self.params[0].device
-        self.offsets, off = [], 0
+        group_of = {}
+        for grp in (adjacent or ()):
+            grp = [p for p in grp if p.requires_grad]
+            assert all(p.numel() % 4 == 0 for p in grp[:-1]), "grouped parameters must keep their successors 16-byte aligned"
+            for p in grp:
+                group_of[id(p)] = grp
+        placed, off = {}, 0
         for p in self.params:
-            self.offsets.append(off)
-            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            if id(p) in placed:
+                continue
+            for q in group_of.get(id(p), [p]):       # (a group is placed when its first member comes up)
+                if id(q) in placed:
+                    continue
+                placed[id(q)] = off
+                off += q.numel()
+            off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.offsets = [placed[id(p)] for p in self.params]
         self.numel = off
         self.flat_p = torch.zeros(off, device=dev)
         self.flat_g = torch.zeros(off, device=dev)

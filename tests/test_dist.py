@@ -148,7 +148,10 @@ def _sn_worker(rank, world, port, q, emu_path, mode):
     names = [n for n, _ in model.named_parameters()]
     if mode == "flat":
         from se3_diffusion_amd.optim import FlatAdam
-        opt = FlatAdam(model.parameters(), lr=1e-3)
+        # (linear_b / down_z of every IPA block back to back: the kernels read and accumulate them as one [40, 128] matrix)
+        opt = FlatAdam(model.parameters(), lr=1e-3, adjacent=model.flat_layout_groups())
+        pb, pz = model.score_model.trunk["ipa_0"].linear_b.weight, model.score_model.trunk["ipa_0"].down_z.weight
+        assert pb.data_ptr() + 4 * pb.numel() == pz.data_ptr() and pb.grad.data_ptr() + 4 * pb.numel() == pz.grad.data_ptr()
         model.accumulate_into_grad = True                       # gradients are written straight into the all-reduce buffer
         hook = fdist.OverlapAllReduce(model, opt)               # per-group all-reduce from inside the backward (bench.py, N > 1)
         model._fd_grad_ready = hook.ready
