@@ -98,7 +98,8 @@ _FUSED_EMBED = os.environ.get("FD_EMBED_FUSED", "1") != "0"
 # per block -- one (b, i) row per block serialises its phases at 2 blocks per CU), so it is opt-in
 FUSED_IPA_PAIR = os.environ.get("FD_IPA_PAIR_FUSED", "0") != "0"
 FUSED_IPA_ATTN = os.environ.get("FD_IPA_ATTN_FUSED", "1") != "0"   # softmax + o_pair per query row in one launch
-FUSED_SEQ_ATTN = os.environ.get("FD_SEQ_ATTN_FUSED", "1") != "0"   # sequence-transformer attention in one launch
+FUSED_SEQ_ATTN = os.environ.get("FD_SEQ_ATTN_FUSED", "0") != "0"   # sequence-transformer attention in one launch (opt-in:
+# 1-2 % slower than the three launches at every size measured)
 
 
 def fused_embed():
