@@ -134,6 +134,11 @@ def side(fn, tensors, rows):
     _SIDE["used"] = True
 
 
+def side_active(t, rows):
+    """Would side(fn, (t, ...), rows) move fn to the gradient side stream?"""
+    return bool(_SIDE["on"] and t.is_cuda and rows <= SIDE_MAX_ROWS)
+
+
 def grad_stream(device):
     """The gradient side stream of `device` (None when disabled or not a GPU): work queued on it after side_sync()
     runs behind every gradient launch issued so far on either stream."""

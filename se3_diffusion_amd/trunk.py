@@ -64,6 +64,7 @@ _FUSED_EDGE = os.environ.get("FD_EDGE_FUSED", "1") != "0"
 
 _FOLD_NODE_TERMS = os.environ.get("FD_FOLD_NODE_TERMS", "1") != "0"   # sampling: per-residue terms of the edge transition in 1 GEMM
 _ZERO_ARENA = os.environ.get("FD_ZERO_ARENA", "1") != "0"   # one memset for the backward pass's zero-initialised sums
+_PAIR_DW_BLOCKS = int(os.environ.get("FD_PAIR_DW_BLOCKS", "160"))   # blocks of fd_pair_dw beside the main stream (0 = 256)
 _GROUPED_DW = os.environ.get("FD_PAIR_DW", "1") != "0"   # grouped weight-gradient kernel (fd_pair_dw) behind the fused chain
 
 
@@ -200,7 +201,11 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
                      for j in range(3)]
             items.append(dict(A=(dh1, 0, EH), B=(z, 0, CZ), C=(gW1, 0, EH)))
             items.append(dict(A=(h2, 0, EH), A_add=(z, 0, CZ), B=(dy, 0, CZ), C=(gWf, 0, EH), trans=True))
-            ops.side(lambda: ops.pair_dw(items, Pn), (dh2, dh1, h1, h2, z, dy), Pn)
+            # On the side stream the grouped kernel takes 160 of the 256 CUs (32 row ranges x 5 tiles): it then runs 1.6x longer
+            # but BESIDE the ~100 latency-bound node-level / IPA launches the main stream issues next, instead of holding
+            # every CU while they queue behind it (27.1 -> 26.5 ms per step; 128 / 192 / 256 blocks: 26.6 / 26.6 / 27.1)
+            nblk = _PAIR_DW_BLOCKS if ops.side_active(dh2, Pn) else 0
+            ops.side(lambda: ops.pair_dw(items, Pn, blocks=nblk), (dh2, dh1, h1, h2, z, dy), Pn)
         else:
             _lin_grads(G, f"{pre}.trunk.2.weight", f"{pre}.trunk.2.bias", mv(dh2), mv(h1), Pn, EH, EH)
         del dh2
