@@ -249,6 +249,9 @@ def feature_tables(device, index_embed_size=32, num_bins=22, min_bin=1e-5, max_b
 # ---------------------------------------------------------------------------
 # fused edge transition (csrc/fd_edge_mlp.hip)
 # ---------------------------------------------------------------------------
+_EDGE_BLOCKS = int(os.environ.get("FD_EDGE_BLOCKS", "0"))   # persistent blocks of the fused edge kernels (0 = 512)
+
+
 def edge_mlp_pack(W1, W2, Wf, backward=False, out=None):
     """Pack the edge-transition weights (trunk.0 [384,384], trunk.2 [384,384], final_layer [128,384]) into the bf16-plane
     image fd_edge_mlp streams.  backward=True packs the transposes (dX chain)."""
@@ -274,7 +277,7 @@ def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, 
         setattr(d, name, None if t is None else t.data_ptr())
         if t is not None:
             tens.append(t)
-    d.rows, d.nres, d.backward, d.eps, d.blocks = int(rows), int(nres), int(bool(backward)), 1e-5, int(blocks)
+    d.rows, d.nres, d.backward, d.eps, d.blocks = int(rows), int(nres), int(bool(backward)), 1e-5, int(blocks or _EDGE_BLOCKS)
     d.ld_pq, d.ld_pqf = int(ld_pq), int(ld_pqf)
     L = lib()
     stream = L._stream(tens)
