@@ -125,6 +125,9 @@ class ScoreNetwork(nn.Module):
             pre = f"score_model.trunk.ipa_{b}"
             groups.append((named[f"{pre}.linear_b.weight"], named[f"{pre}.down_z.weight"]))
             groups.append((named[f"{pre}.linear_b.bias"], named[f"{pre}.down_z.bias"]))
+            proj = ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")     # one [6816, 256] projection of s
+            groups.append(tuple(named[f"{pre}.{n}.weight"] for n in proj))
+            groups.append(tuple(named[f"{pre}.{n}.bias"] for n in proj))
             b += 1
         return groups
 

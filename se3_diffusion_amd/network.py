@@ -179,17 +179,38 @@ def pair_mask(mask, B, N):
     return em
 
 
-def _adjacent_view(a, b, shape):
-    """One tensor over a and b when b starts where a ends in the same storage (16-byte aligned start), else None."""
-    if (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.device == b.device
-            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
-            and a.storage_offset() + a.numel() == b.storage_offset() and a.data_ptr() % 16 == 0):
-        strides, st = [], 1
-        for d in reversed(shape):
-            strides.append(st)
-            st *= d
-        return a.detach().as_strided(shape, tuple(reversed(strides)))
-    return None
+def _adjacent_view(a, b, shape, *more):
+    """One tensor over a, b (, more...) when each starts where its predecessor ends in the same storage (16-byte aligned
+    start), else None."""
+    ts = (a, b) + more
+    for x, y in zip(ts[:-1], ts[1:]):
+        if not (x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype and x.device == y.device
+                and x.untyped_storage().data_ptr() == y.untyped_storage().data_ptr()
+                and x.storage_offset() + x.numel() == y.storage_offset()):
+            return None
+    if a.data_ptr() % 16 != 0:
+        return None
+    strides, st = [], 1
+    for d in reversed(shape):
+        strides.append(st)
+        st *= d
+    return a.detach().as_strided(shape, tuple(reversed(strides)))
+
+
+_PROJ = ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")
+_PROJ_MERGE = os.environ.get("FD_PROJ_MERGE", "0") != "0"   # opt-in: measured 27.12 vs 27.02 ms per step (no gain)
+
+
+def _proj_views(P, pre):
+    """([6816, 256] weight, [6816] bias) over IPA's four projections of s when they lie back to back, else None."""
+    if not _PROJ_MERGE:
+        return None
+    try:
+        W = _adjacent_view(*(P[f"{pre}.{n}.weight"] for n in _PROJ[:2]), (LDP, CS), *(P[f"{pre}.{n}.weight"] for n in _PROJ[2:]))
+        b = _adjacent_view(*(P[f"{pre}.{n}.bias"] for n in _PROJ[:2]), (LDP,), *(P[f"{pre}.{n}.bias"] for n in _PROJ[2:]))
+    except KeyError:
+        return None
+    return None if W is None or b is None else (W, b)
 
 
 def _joined(a, b, shape):
@@ -210,6 +231,10 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
             cache[("Wproj", pre)] = (torch.cat([P[f"{pre}.{n}.weight"] for n in names], 0).contiguous(),
                                      torch.cat([P[f"{pre}.{n}.bias"] for n in names], 0).contiguous())
         Wp, bp = cache[("Wproj", pre)]
+        ops.linear(s, mv(Wp), bp, mv(proj), R, LDP, CS)
+    elif _proj_views(P, pre) is not None:
+        # the four projection weights lie back to back (optim.FlatAdam + flat_layout_groups): one GEMM as in sampling
+        Wp, bp = _proj_views(P, pre)
         ops.linear(s, mv(Wp), bp, mv(proj), R, LDP, CS)
     else:
         ops.linear(s, mv(P[f"{pre}.linear_q.weight"]), P[f"{pre}.linear_q.bias"], (proj, 0, LDP), R, H * C, CS)
@@ -335,6 +360,13 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True):
             G[f"{pre}.linear_b.weight"] += dW40[:H]; G[f"{pre}.down_z.weight"] += dW40[H:]
             G[f"{pre}.linear_b.bias"] += db40[:H]; G[f"{pre}.down_z.bias"] += db40[H:]
     # projections: ds += dproj_slice W ; dW += dproj_slice^T s
+    pv = _proj_views(P, pre)
+    gv = _proj_views(G, pre) if G is not None else None
+    if pv is not None and gv is not None:
+        # one [6816, 256] weight, one gradient: a single dX GEMM over the 6816 columns and a single dW GEMM
+        ops.linear_dx(mv(dproj), mv(pv[0]), ds, R, LDP, CS, beta=True)
+        ops.side(lambda: ops.linear_dw(mv(dproj), s, mv(gv[0]), R, LDP, CS, db=gv[1]), (dproj, s[0]), R)
+        return
     for name, off, n in (("linear_q", 0, 2048), ("linear_kv", 2048, 4096), ("linear_q_points", 6144, 192),
                          ("linear_kv_points", 6336, 480)):
         ops.linear_dx((dproj, off, LDP), mv(P[f"{pre}.{name}.weight"]), ds, R, n, CS, beta=True)
