@@ -129,6 +129,15 @@ __global__ __launch_bounds__(256) void ipa_points_bwd_kernel(const float* __rest
 // ---------------------------------------------------------------- softmax
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
+// the 8 query / key points of one (residue, head): 24 contiguous floats at a 96-byte stride -> six 16-byte loads
+__device__ __forceinline__ void load_pts(float (&v)[PQ * 3], const float* __restrict__ src) {
+#pragma unroll
+  for (int i = 0; i < PQ * 3 / 4; ++i) {
+    const float4 t = *reinterpret_cast<const float4*>(src + 4 * i);
+    v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+  }
+}
+
 __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict__ S, const float* __restrict__ zb,
                                                               const float* __restrict__ qp,
                                                               const float* __restrict__ kp,
@@ -155,7 +164,8 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict_
     float mx = -INFINITY;
     for (int j = lane; j < N; j += 64) {
       const long bj = (long)b * N + j;
-      const float* ksrc = kp + (bj * H + h) * (PQ * 3);
+      float ksrc[PQ * 3];
+      load_pts(ksrc, kp + (bj * H + h) * (PQ * 3));
       float pt = 0.f;
 #pragma unroll
       for (int p = 0; p < PQ; ++p) {
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict_
 // dL = A * (dA - sum_j A dA) written over dA; d(zb bias) = sqrt(1/3) dL; dqp_i; d head_w
 // FUSED (fd_ipa_attn_bwd): the o_pair backward of the same (b, i) row first -- dzb[:, 8:40] = sum_h A dout and
 // dA += dout . pair_z -- with A and the updated dA held in LDS (one launch, one pass over A and one over dA less).
-template <bool FUSED>
+template <bool FUSED, int NMAX>
 __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __restrict__ A, float* __restrict__ dA,
                                                               const float* __restrict__ qp,
                                                               const float* __restrict__ kp,
@@ -203,8 +213,9 @@ __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __res
                                                               float* __restrict__ dzb, float* __restrict__ dqp,
                                                               float* __restrict__ hw_part, const float* __restrict__ zb,
                                                               const float* __restrict__ dfeats, int N) {
-  __shared__ float dl_s[H][MAXN];
-  __shared__ float Ai[FUSED ? H : 1][FUSED ? MAXN : 1];
+  // (NMAX = 256 for N <= 256: 17 KB of LDS instead of 66 KB, three blocks per CU instead of two)
+  __shared__ float dl_s[H][NMAX];
+  __shared__ float Ai[FUSED ? H : 1][FUSED ? NMAX : 1];
   __shared__ float dout[H][CZ4];
   const long bi = blockIdx.x;
   const int b = (int)(bi / N), i = (int)(bi % N);
@@ -257,7 +268,8 @@ __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __res
       const float dl = Arow[j] * (dAin[j] - dot);
       dArow[j] = dl;
       dl_s[h][j] = dl;
-      const float* ksrc = kp + (((long)b * N + j) * H + h) * (PQ * 3);
+      float ksrc[PQ * 3];
+      load_pts(ksrc, kp + (((long)b * N + j) * H + h) * (PQ * 3));
       float d2 = 0.f;
 #pragma unroll
       for (int k = 0; k < PQ * 3; ++k) {
@@ -505,8 +517,14 @@ extern "C" int fd_ipa_softmax_bwd(const float* A, float* dA, const float* qp, co
                                   void* stream) {
   FD_CHECK_ARG(N <= MAXN, "fd_ipa_softmax_bwd: N=%d exceeds %d", N, MAXN);
   if (B == 0 || N == 0) return FD_OK;
-  hipLaunchKernelGGL(ipa_softmax_bwd_kernel<false>, dim3((unsigned)((long)B * N)), dim3(256), 0, (hipStream_t)stream, A,
-                     dA, qp, kp, head_w, dzb, dqp, hw_part, (const float*)nullptr, (const float*)nullptr, N);
+  if (N <= 256)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_bwd_kernel<false, 256>), dim3((unsigned)((long)B * N)), dim3(256), 0,
+                       (hipStream_t)stream, A, dA, qp, kp, head_w, dzb, dqp, hw_part, (const float*)nullptr,
+                       (const float*)nullptr, N);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_bwd_kernel<false, MAXN>), dim3((unsigned)((long)B * N)), dim3(256), 0,
+                       (hipStream_t)stream, A, dA, qp, kp, head_w, dzb, dqp, hw_part, (const float*)nullptr,
+                       (const float*)nullptr, N);
   FD_CHECK_LAUNCH("fd_ipa_softmax_bwd");
   {
     int rc = fd_colsum_acc(hw_part, H, (long)B * N, H, dhead_w, stream);
@@ -521,8 +539,12 @@ extern "C" int fd_ipa_attn_bwd(const float* A, float* dA, const float* zb, const
   FD_CHECK_ARG(N <= MAXN, "fd_ipa_attn_bwd: N=%d exceeds %d", N, MAXN);
   FD_CHECK_ARG(zb && dfeats, "fd_ipa_attn_bwd: zb / dfeats are required");
   if (B == 0 || N == 0) return FD_OK;
-  hipLaunchKernelGGL(ipa_softmax_bwd_kernel<true>, dim3((unsigned)((long)B * N)), dim3(256), 0, (hipStream_t)stream, A,
-                     dA, qp, kp, head_w, dzb, dqp, hw_part, zb, dfeats, N);
+  if (N <= 256)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_bwd_kernel<true, 256>), dim3((unsigned)((long)B * N)), dim3(256), 0,
+                       (hipStream_t)stream, A, dA, qp, kp, head_w, dzb, dqp, hw_part, zb, dfeats, N);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_bwd_kernel<true, MAXN>), dim3((unsigned)((long)B * N)), dim3(256), 0,
+                       (hipStream_t)stream, A, dA, qp, kp, head_w, dzb, dqp, hw_part, zb, dfeats, N);
   FD_CHECK_LAUNCH("fd_ipa_attn_bwd");
   {
     int rc = fd_colsum_acc(hw_part, H, (long)B * N, H, dhead_w, stream);
