@@ -138,6 +138,11 @@ __device__ __forceinline__ void load_pts(float (&v)[PQ * 3], const float* __rest
   }
 }
 
+// SLAB (N <= NMAX = 256): the row's [N, 40] block of zb -- one contiguous 160 N bytes -- is copied to LDS with whole-line
+// float4 loads and both the bias column of the logits and the 32 o_pair columns are served from there; the direct reads
+// (4 bytes at a 160-byte stride for the bias, 128 of every 160 bytes for o_pair) fetched about twice the bytes they used.
+constexpr int ZPAD = ZB + 1;    // floats per zb row in LDS (41: conflict-free for lanes along j and along the columns)
+template <int NMAX, bool SLAB>
 __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict__ S, const float* __restrict__ zb,
                                                               const float* __restrict__ qp,
                                                               const float* __restrict__ kp,
@@ -146,10 +151,21 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict_
                                                               int N) {
   // feats != nullptr: o_pair of the same (b, i) row is taken from the probabilities while they are in LDS
   // (fd_ipa_attn_fwd: one launch and one pass over A less than softmax + opair)
-  __shared__ float lg[H][MAXN];
+  __shared__ float lg[H][NMAX];
+  __shared__ float zs[SLAB ? NMAX * ZPAD : 1];
   const long bi = blockIdx.x;
   const int b = (int)(bi / N), i = (int)(bi % N);
   const int lane = fd::lane_id(), wave = fd::wave_id();
+  if (SLAB) {
+    const float4* src = reinterpret_cast<const float4*>(zb + bi * N * ZB);     // (N * 40 floats: a multiple of 4, 16-byte aligned)
+    for (int e = (int)threadIdx.x; e < N * (ZB / 4); e += 256) {
+      const float4 v = src[e];
+      const int j = e / (ZB / 4), c = 4 * (e % (ZB / 4));
+      float* d = zs + j * ZPAD + c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+  }
   const float mi = mask[bi];
   const float sq13 = sqrtf(1.0f / 3.0f);
   const float gscale = sqrtf(1.0f / (3.0f * ((float)PQ * 9.0f / 2.0f)));
@@ -172,7 +188,7 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict_
         const float dx = q[3 * p] - ksrc[3 * p], dy = q[3 * p + 1] - ksrc[3 * p + 1], dz = q[3 * p + 2] - ksrc[3 * p + 2];
         pt += (dx * dx + dy * dy + dz * dz) * gamma;
       }
-      float a = Srow[j] + sq13 * zb[(bi * N + j) * ZB + h];
+      float a = Srow[j] + sq13 * (SLAB ? zs[j * ZPAD + h] : zb[(bi * N + j) * ZB + h]);
       a = a + pt * (-0.5f);
       a = a + 1e5f * (mi * mask[bj] - 1.f);
       lg[h][j] = a;
@@ -195,9 +211,14 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict_
   if (feats != nullptr) {
     __syncthreads();
     const int h = (int)threadIdx.x / CZ4, c = (int)threadIdx.x % CZ4;
-    const float* z = zb + bi * N * ZB + H + c;
     float acc = 0.f;
-    for (int j = 0; j < N; ++j) acc += lg[h][j] * z[(long)j * ZB];
+    if (SLAB) {
+      const float* z = zs + H + c;
+      for (int j = 0; j < N; ++j) acc += lg[h][j] * z[j * ZPAD];
+    } else {
+      const float* z = zb + bi * N * ZB + H + c;
+      for (int j = 0; j < N; ++j) acc += lg[h][j] * z[(long)j * ZB];
+    }
     feats[bi * LDF + F_PAIR + h * CZ4 + c] = acc;
   }
 }
@@ -205,7 +226,7 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict_
 // dL = A * (dA - sum_j A dA) written over dA; d(zb bias) = sqrt(1/3) dL; dqp_i; d head_w
 // FUSED (fd_ipa_attn_bwd): the o_pair backward of the same (b, i) row first -- dzb[:, 8:40] = sum_h A dout and
 // dA += dout . pair_z -- with A and the updated dA held in LDS (one launch, one pass over A and one over dA less).
-template <bool FUSED, int NMAX>
+template <bool FUSED, int NMAX, bool SLAB = false>
 __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __restrict__ A, float* __restrict__ dA,
                                                               const float* __restrict__ qp,
                                                               const float* __restrict__ kp,
@@ -217,6 +238,9 @@ __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __res
   __shared__ float dl_s[H][NMAX];
   __shared__ float Ai[FUSED ? H : 1][FUSED ? NMAX : 1];
   __shared__ float dout[H][CZ4];
+  // SLAB (FUSED, N <= NMAX): the row's [N, 40] block of zb comes in, and its block of dzb goes out, as ONE contiguous
+  // run of whole lines through this LDS image (pitch 41 floats); zb's o_pair columns are consumed before dzb overwrites them
+  __shared__ float zs[SLAB ? NMAX * ZPAD : 1];
   const long bi = blockIdx.x;
   const int b = (int)(bi / N), i = (int)(bi % N);
   const int lane = fd::lane_id(), wave = fd::wave_id();
@@ -228,23 +252,35 @@ __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __res
       Ai[h][j] = A[(((long)b * H + h) * N + i) * N + j];
     }
     dout[threadIdx.x / CZ4][threadIdx.x % CZ4] = dfeats[bi * LDF + F_PAIR + threadIdx.x];
+    if (SLAB) {
+      const float4* src = reinterpret_cast<const float4*>(zb + bi * N * ZB);
+      for (int e = (int)threadIdx.x; e < N * (ZB / 4); e += 256) {
+        const float4 v = src[e];
+        float* d = zs + (e / (ZB / 4)) * ZPAD + 4 * (e % (ZB / 4));
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
     __syncthreads();
+    // dA[b,h,i,j] + sum_c dout[h][c] * pair_z[b,i,j,c]
+    for (int e = (int)threadIdx.x; e < H * N; e += 256) {
+      const int h = e / N, j = e % N;
+      const float* z = SLAB ? zs + j * ZPAD + H : zb + (bi * N + j) * ZB + H;
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < CZ4; ++c) acc += dout[h][c] * z[c];
+      dl_s[h][j] = dA[(((long)b * H + h) * N + i) * N + j] + acc;
+    }
+    if (SLAB) __syncthreads();   // every read of the zb image is done before dzb goes into it
     // d pair_z[b,i,j,c] = sum_h A[h][j] * dout[h][c]
     for (int e = (int)threadIdx.x; e < N * CZ4; e += 256) {
       const int j = e / CZ4, c = e % CZ4;
       float acc = 0.f;
 #pragma unroll
       for (int h = 0; h < H; ++h) acc += Ai[h][j] * dout[h][c];
-      dzb[(bi * N + j) * ZB + H + c] = acc;
-    }
-    // dA[b,h,i,j] + sum_c dout[h][c] * pair_z[b,i,j,c]
-    for (int e = (int)threadIdx.x; e < H * N; e += 256) {
-      const int h = e / N, j = e % N;
-      const float* z = zb + (bi * N + j) * ZB + H;
-      float acc = 0.f;
-#pragma unroll
-      for (int c = 0; c < CZ4; ++c) acc += dout[h][c] * z[c];
-      dl_s[h][j] = dA[(((long)b * H + h) * N + i) * N + j] + acc;
+      if (SLAB)
+        zs[j * ZPAD + H + c] = acc;
+      else
+        dzb[(bi * N + j) * ZB + H + c] = acc;
     }
     __syncthreads();
   }
@@ -296,7 +332,18 @@ __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __res
   __syncthreads();
   for (int e = (int)threadIdx.x; e < N * H; e += 256) {
     const int j = e / H, h = e % H;
-    dzb[(bi * N + j) * ZB + h] = sq13 * dl_s[h][j];
+    if (SLAB)
+      zs[j * ZPAD + h] = sq13 * dl_s[h][j];
+    else
+      dzb[(bi * N + j) * ZB + h] = sq13 * dl_s[h][j];
+  }
+  if (SLAB) {
+    __syncthreads();
+    float4* dst = reinterpret_cast<float4*>(dzb + bi * N * ZB);
+    for (int e = (int)threadIdx.x; e < N * (ZB / 4); e += 256) {
+      const float* d = zs + (e / (ZB / 4)) * ZPAD + 4 * (e % (ZB / 4));
+      dst[e] = make_float4(d[0], d[1], d[2], d[3]);
+    }
   }
 }
 
@@ -492,8 +539,8 @@ extern "C" int fd_ipa_softmax_fwd(float* S, const float* zb, const float* qp, co
                                   const float* mask, int B, int N, void* stream) {
   FD_CHECK_ARG(N <= MAXN, "fd_ipa_softmax_fwd: N=%d exceeds %d", N, MAXN);
   if (B == 0 || N == 0) return FD_OK;
-  hipLaunchKernelGGL(ipa_softmax_fwd_kernel, dim3((unsigned)((long)B * N)), dim3(256), 0, (hipStream_t)stream, S, zb,
-                     qp, kp, head_w, mask, (float*)nullptr, N);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_fwd_kernel<MAXN, false>), dim3((unsigned)((long)B * N)), dim3(256), 0,
+                     (hipStream_t)stream, S, zb, qp, kp, head_w, mask, (float*)nullptr, N);
   FD_CHECK_LAUNCH("fd_ipa_softmax_fwd");
   return FD_OK;
 }
@@ -503,8 +550,15 @@ extern "C" int fd_ipa_attn_fwd(float* S, const float* zb, const float* qp, const
   FD_CHECK_ARG(N <= MAXN, "fd_ipa_attn_fwd: N=%d exceeds %d", N, MAXN);
   FD_CHECK_ARG(feats != nullptr, "fd_ipa_attn_fwd: feats is required");
   if (B == 0 || N == 0) return FD_OK;
-  hipLaunchKernelGGL(ipa_softmax_fwd_kernel, dim3((unsigned)((long)B * N)), dim3(256), 0, (hipStream_t)stream, S, zb,
-                     qp, kp, head_w, mask, feats, N);
+  if (N <= 128 && fd_aligned16(zb))
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_fwd_kernel<128, true>), dim3((unsigned)((long)B * N)), dim3(256), 0,
+                       (hipStream_t)stream, S, zb, qp, kp, head_w, mask, feats, N);
+  else if (N <= 256 && fd_aligned16(zb))
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_fwd_kernel<256, true>), dim3((unsigned)((long)B * N)), dim3(256), 0,
+                       (hipStream_t)stream, S, zb, qp, kp, head_w, mask, feats, N);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_fwd_kernel<MAXN, false>), dim3((unsigned)((long)B * N)), dim3(256), 0,
+                       (hipStream_t)stream, S, zb, qp, kp, head_w, mask, feats, N);
   FD_CHECK_LAUNCH("fd_ipa_attn_fwd");
   return FD_OK;
 }
@@ -539,7 +593,14 @@ extern "C" int fd_ipa_attn_bwd(const float* A, float* dA, const float* zb, const
   FD_CHECK_ARG(N <= MAXN, "fd_ipa_attn_bwd: N=%d exceeds %d", N, MAXN);
   FD_CHECK_ARG(zb && dfeats, "fd_ipa_attn_bwd: zb / dfeats are required");
   if (B == 0 || N == 0) return FD_OK;
-  if (N <= 256)
+  const bool al = fd_aligned16(zb) && fd_aligned16(dzb);
+  if (N <= 128 && al)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_bwd_kernel<true, 128, true>), dim3((unsigned)((long)B * N)), dim3(256), 0,
+                       (hipStream_t)stream, A, dA, qp, kp, head_w, dzb, dqp, hw_part, zb, dfeats, N);
+  else if (N <= 256 && al)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_bwd_kernel<true, 256, true>), dim3((unsigned)((long)B * N)), dim3(256), 0,
+                       (hipStream_t)stream, A, dA, qp, kp, head_w, dzb, dqp, hw_part, zb, dfeats, N);
+  else if (N <= 256)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_bwd_kernel<true, 256>), dim3((unsigned)((long)B * N)), dim3(256), 0,
                        (hipStream_t)stream, A, dA, qp, kp, head_w, dzb, dqp, hw_part, zb, dfeats, N);
   else
