@@ -42,6 +42,12 @@ namespace {
 
 constexpr int EM_UNITS = 128;              // units per tile
 constexpr int EM_NSTAGE = EM_UNITS / EM_UPS;
+#ifndef EM_RING
+// LDS stages of the weight stream.  3 (the copy runs two stages ahead behind a counted vmcnt wait) makes the kernel 2-3 %
+// faster on its own (1.47 vs 1.51 ms forward with saves) but costs 144 KB of LDS per CU, and the training step then loses
+// the overlap with the gradient side stream: 29.0 vs 26.0 ms per step on one box.  2 is shipped.
+#define EM_RING 2
+#endif
 constexpr int EM_H = 384, EM_C = 128;
 
 struct EmMat {
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256) void edge_mlp_pack16_kernel(EmMat A1, EmMat A2
 
 template <bool BWD>
 __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpDesc d) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * EM_STAGE];
+  __shared__ __attribute__((aligned(16))) char lds[EM_RING * EM_STAGE];
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
   int issued = 0, consumed = 0;
   auto issue_stage = [&]() {
     const char* src = img_lane + (long)(issued % EM_NSTAGE) * EM_STAGE;
-    char* dst = lds_wave + (issued & 1) * EM_STAGE;
+    char* dst = lds_wave + (issued % EM_RING) * EM_STAGE;
     fd::glds16x4(src, dst);
     fd::glds16x2(src + 4096, dst + 4096);
     ++issued;
@@ -121,9 +127,16 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
   // begin the next stage: its copy (issued one stage ago) has landed and is visible to the block; every wave is done
   // with the previous stage, whose buffer takes the copy after next.  Returns the stage's LDS address + 16 * lane.
   auto stage_begin = [&]() -> const char* {
-    fd::wait_vmem();
+    // EM_RING == 3: the copy of the stage AFTER this one (6 LDS-DMA instructions per wave, issued during the previous
+    // stage) may stay in flight across the barrier -- vmcnt retires in issue order, so "at most 6 outstanding" means this
+    // stage's copy, issued before them, has landed (any other memory operation issued since only makes the wait stricter)
+    // (no younger copy in flight -- the last stage of the launch: wait for everything)
+    if (EM_RING == 3 && issued > consumed + 1)
+      fd::wait_vmem_keep6();
+    else
+      fd::wait_vmem();
     __syncthreads();
-    const char* cur = lds + (consumed & 1) * EM_STAGE + lane * 16;
+    const char* cur = lds + (consumed % EM_RING) * EM_STAGE + lane * 16;
     ++consumed;
     return cur;
   };
@@ -133,6 +146,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
     if (issued < total_stages) issue_stage();
   };
   issue_stage();
+  if (EM_RING == 3 && total_stages > 1) issue_stage();
 
   for (int ti = 0; ti < nmine; ++ti) {
     const long row = ((long)first + (long)ti * G) * EM_ROWS + wave * 16 + m;

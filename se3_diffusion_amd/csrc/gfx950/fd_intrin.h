@@ -112,6 +112,11 @@ __device__ __forceinline__ uint2 lds_read_tr16(const void* p) {
 // s_waitcnt vmcnt(0): every vector-memory operation of this wave (loads, stores, LDS-DMA) has completed
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// s_waitcnt vmcnt(6): at most the six most recently issued vector-memory operations of this wave are still outstanding
+// (gfx9 retires loads, stores and LDS-DMA in issue order on this counter): with the six LDS-DMA instructions of the NEXT
+// stage issued last, the current stage's copy has landed while the next one stays in flight
+__device__ __forceinline__ void wait_vmem_keep6() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+
 // the instruction scheduler moves nothing across this point (pins a software-pipelined order)
 __device__ __forceinline__ void sched_pin() { __builtin_amdgcn_sched_barrier(0); }
 

@@ -150,6 +150,7 @@ static inline void glds16x4(const void* g_lane, void* lds_wave_base) {
     memcpy(static_cast<char*>(lds_wave_base) + 1024 * k + 16 * hipemu::g_cur->lane, static_cast<const char*>(g_lane) + 1024 * k, 16);
 }
 static inline void wait_vmem() {}
+static inline void wait_vmem_keep6() {}
 
 static inline void raise_wave_priority() {}
 
