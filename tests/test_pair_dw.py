@@ -12,18 +12,22 @@ from se3_diffusion_amd import ops
 def _case(dev, rows, seed, lda=384):
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
-    t = dict(d2=rn(rows, lda)[:, :384], h1=rn(rows, 384), d1=rn(rows, 384), z=rn(rows, 128), h2=rn(rows, 384), dy=rn(rows, 128))
-    return {k: v.to(dev) for k, v in t.items()}
+    wide = rn(rows, lda).to(dev)                      # d2 = 384 columns of a wider tensor when lda > 384 (row stride lda)
+    t = dict(h1=rn(rows, 384), d1=rn(rows, 384), z=rn(rows, 128), h2=rn(rows, 384), dy=rn(rows, 128))
+    t = {k: v.to(dev) for k, v in t.items()}
+    t["d2"] = wide[:, 64:448] if lda > 384 else wide
+    return t
 
 
-def _run(dev, rows, seed=0, blocks=0, accumulate=False):
-    t = _case(dev, rows, seed)
+def _run(dev, rows, seed=0, blocks=0, accumulate=False, lda=384):
+    t = _case(dev, rows, seed, lda)
     mk = (lambda *s: torch.randn(*s, device=dev)) if accumulate else (lambda *s: torch.zeros(*s, device=dev))
     gW2, gb2, gW1, gWf = mk(384, 384), mk(384), mk(384, 384), mk(128, 384)
     ref0 = {k: v.double().cpu().clone() for k, v in dict(gW2=gW2, gb2=gb2, gW1=gW1, gWf=gWf).items()}
     d2 = t["d2"]
     lda = d2.stride(0)
-    items = [dict(A=(d2, 0, lda), B=(t["h1"], 128 * j, 384), C=(gW2, 128 * j, 384), colsum=gb2 if j == 0 else None)
+    d2v = (d2, 0, lda)                                 # (a column slice is addressed by its own data pointer + the row stride)
+    items = [dict(A=d2v, B=(t["h1"], 128 * j, 384), C=(gW2, 128 * j, 384), colsum=gb2 if j == 0 else None)
              for j in range(3)]
     items.append(dict(A=(t["d1"], 0, 384), B=(t["z"], 0, 128), C=(gW1, 0, 384)))
     # final layer: y = Wf (h2 + [z | e_i | e_j]) -> dWf = dy^T h2 with dy^T z added to its first 128 columns
@@ -46,6 +50,7 @@ def _run(dev, rows, seed=0, blocks=0, accumulate=False):
 def test_pair_dw_emu(use_emu):
     _run("cpu", rows=150, blocks=8)                         # one group: 9 full stages + a ragged one
     _run("cpu", rows=200, seed=1, blocks=16, accumulate=True)   # three row ranges; C accumulates
+    _run("cpu", rows=90, seed=2, blocks=8, lda=512)             # A = a column slice of a wider tensor
 
 
 @pytest.mark.gpu
@@ -55,3 +60,5 @@ def test_pair_dw_gpu(hip_lib):
     _run("cuda", rows=101 * 101, seed=2, accumulate=True)     # odd row count: ragged last stage
     _run("cuda", rows=2 * 128 * 128, seed=3)
     _run("cuda", rows=30 * 128 * 128, seed=4)                 # the training shape
+    _run("cuda", rows=30 * 128 * 128, seed=5, blocks=160)     # ... on 160 CUs, as the training step launches it
+    _run("cuda", rows=5000, seed=6, lda=512)                  # A = a column slice of a wider tensor
