@@ -252,6 +252,13 @@ int fd_ipa_attn_bwd(const float* A, float* dA, const float* zb, const float* dfe
                     const float* head_w, float* dzb, float* dqp, float* dkp, float* dhead_w, float* hw_part, int B,
                     int N, void* stream);
 
+/* zb[p, 0:40] = W40[0:40, 0:128] z[p, 0:128] + b40 over the pair rows (linear_b and down_z in one streaming pass over z,
+ * ipa_pytorch.py:380-386,455): W40 resident in registers; b40 may be null */
+int fd_ipa_zb(const float* z, const float* W40, const float* b40, float* zb, long rows, void* stream);
+/* dz[p, 0:128] (+)= dzb[p, 0:40] W40[0:40, 0:128] over the pair rows (autograd of linear_b / down_z w.r.t. z,
+ * ipa_pytorch.py:380-386,455-457): streaming kernel, W40 resident in registers */
+int fd_ipa_dz_acc(const float* dzb, const float* W40, float* dz, long rows, int accumulate, void* stream);
+
 /* dkp[b,j,h,:] = gamma_h sum_i dLogits[b,h,i,j] (qp[b,i,h,:] - kp[b,j,h,:]) (the key-side point gradient) */
 int fd_ipa_kpts_bwd(const float* dL, const float* qp, const float* kp, const float* head_w, float* dkp, int B, int N,
                     void* stream);

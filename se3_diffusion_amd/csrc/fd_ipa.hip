@@ -502,7 +502,131 @@ __global__ __launch_bounds__(256) void ipa_opair_bwd_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------- dz (+)= dzb W40
+// The pair-bias / down_z part of IPA's gradient w.r.t. the pair tensor: dz[p, :] (+)= dzb[p, 0:40] W40[0:40, 0:128] over
+// the B*N*N pair rows (autograd of linear_b and down_z, ipa_pytorch.py:380-386,455-457).  583 MB of traffic for 5 GFLOP:
+// a streaming kernel.  Every wave owns 32-row tiles; W40 (20 KB) lives in its registers as MFMA B fragments for the whole
+// launch, the dzb tile goes global -> registers directly in MFMA A layout (as fd_gemm tile 5), v_mfma_f32_32x32x2_f32
+// (exact fp32), and the 32 x 128 result is added to dz with 128-byte row segments per lane half.  No LDS, no barrier.
+__global__ __launch_bounds__(256) void ipa_dz_acc_kernel(const float* __restrict__ dzb, const float* __restrict__ W40,
+                                                         float* __restrict__ dz, long rows, int accumulate) {
+  const int lane = fd::lane_id(), wave = fd::wave_id();
+  const int h = lane >> 5, l31 = lane & 31;
+  // B fragments: W40[k = 8 g + 4 h + t][n = 32 nt + l31]
+  float w[ZB / 8][4][4];
+#pragma unroll
+  for (int g = 0; g < ZB / 8; ++g)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) w[g][t][nt] = W40[(8 * g + 4 * h + t) * 128 + 32 * nt + l31];
+  const long ntiles = (rows + 31) / 32;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    const long r0 = tile * 32;
+    const long ra = (r0 + l31 < rows) ? r0 + l31 : rows - 1;
+    float4 a[ZB / 8];
+#pragma unroll
+    for (int g = 0; g < ZB / 8; ++g) a[g] = *reinterpret_cast<const float4*>(dzb + ra * ZB + 8 * g + 4 * h);
+    // the accumulators start from the old values of dz (fetched beside the dzb tile, under the MFMAs of the previous
+    // tile's tail): the read-modify-write costs no dependent load -> add -> store chain per element
+    f32x16 acc[4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long row = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float* o = dz + (row < rows ? row : rows - 1) * 128 + l31;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt][r] = accumulate ? o[32 * nt] : 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < ZB / 8; ++g) {
+      const float av[4] = {a[g].x, a[g].y, a[g].z, a[g].w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = fd::mfma_32x32x2(av[t], w[g][t][nt], acc[nt]);
+    }
+    // D: reg r -> row (r & 3) + 8 (r >> 2) + 4 h, column l31 of n-tile nt
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long row = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < rows) {
+        float* o = dz + row * 128 + l31;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) o[32 * nt] = acc[nt][r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- zb = z W40^T + b40
+// linear_b and down_z of the pair tensor in one streaming pass (ipa_pytorch.py:380-386,455): zb[p, 0:40] =
+// W40[0:40, 0:128] z[p, :] + b40.  Same structure as ipa_dz_acc_kernel: W40 as MFMA B fragments in registers for the whole
+// launch (two column tiles: 32 + 8 of 32 used), the z tile straight from global memory in A layout, fp32 MFMA.
+__global__ __launch_bounds__(256) void ipa_zb_kernel(const float* __restrict__ z, const float* __restrict__ W40,
+                                                     const float* __restrict__ b40, float* __restrict__ zb, long rows) {
+  const int lane = fd::lane_id(), wave = fd::wave_id();
+  const int h = lane >> 5, l31 = lane & 31;
+  // B fragments: B[k][n] = W40[n][k], k = 8 g + 4 h + t contiguous in memory -> one float4 per (g, column tile)
+  float4 w[16][2];
+  const int n1 = 32 + (l31 < ZB - 32 ? l31 : ZB - 33);        // second tile: columns 32..39, the other lanes duplicate 39
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    w[g][0] = *reinterpret_cast<const float4*>(W40 + l31 * 128 + 8 * g + 4 * h);
+    w[g][1] = *reinterpret_cast<const float4*>(W40 + n1 * 128 + 8 * g + 4 * h);
+  }
+  const float bias0 = b40 ? b40[l31] : 0.f, bias1 = b40 ? b40[n1] : 0.f;
+  const long ntiles = (rows + 31) / 32;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    const long r0 = tile * 32;
+    const long ra = (r0 + l31 < rows) ? r0 + l31 : rows - 1;
+    float4 a[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) a[g] = *reinterpret_cast<const float4*>(z + ra * 128 + 8 * g + 4 * h);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = bias0; acc1[r] = bias1; }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      acc0 = fd::mfma_32x32x2(a[g].x, w[g][0].x, acc0); acc1 = fd::mfma_32x32x2(a[g].x, w[g][1].x, acc1);
+      acc0 = fd::mfma_32x32x2(a[g].y, w[g][0].y, acc0); acc1 = fd::mfma_32x32x2(a[g].y, w[g][1].y, acc1);
+      acc0 = fd::mfma_32x32x2(a[g].z, w[g][0].z, acc0); acc1 = fd::mfma_32x32x2(a[g].z, w[g][1].z, acc1);
+      acc0 = fd::mfma_32x32x2(a[g].w, w[g][0].w, acc0); acc1 = fd::mfma_32x32x2(a[g].w, w[g][1].w, acc1);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long row = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < rows) {
+        zb[row * ZB + l31] = acc0[r];
+        if (l31 < ZB - 32) zb[row * ZB + 32 + l31] = acc1[r];
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int fd_ipa_zb(const float* z, const float* W40, const float* b40, float* zb, long rows, void* stream) {
+  FD_CHECK_ARG(z && W40 && zb, "fd_ipa_zb: null operand");
+  FD_CHECK_ARG(fd_aligned16(z) && fd_aligned16(W40), "fd_ipa_zb: z / W40 must be 16-byte aligned");
+  if (rows == 0) return FD_OK;
+  long g = ((rows + 31) / 32 + 3) / 4;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(ipa_zb_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, z, W40, b40, zb, rows);
+  FD_CHECK_LAUNCH("fd_ipa_zb");
+  return FD_OK;
+}
+
+extern "C" int fd_ipa_dz_acc(const float* dzb, const float* W40, float* dz, long rows, int accumulate, void* stream) {
+  FD_CHECK_ARG(dzb && W40 && dz, "fd_ipa_dz_acc: null operand");
+  FD_CHECK_ARG(fd_aligned16(dzb), "fd_ipa_dz_acc: dzb must be 16-byte aligned");
+  if (rows == 0) return FD_OK;
+  const long tiles = (rows + 31) / 32;
+  long g = (tiles + 3) / 4;
+  if (g > 2048) g = 2048;                      // 8 blocks per CU: the waves walk their tiles, W40 stays in registers
+  hipLaunchKernelGGL(ipa_dz_acc_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, dzb, W40, dz, rows, accumulate);
+  FD_CHECK_LAUNCH("fd_ipa_dz_acc");
+  return FD_OK;
+}
 
 #define CHECK_DIMS(fn)                                                                                         \
   FD_CHECK_ARG(nheads == H && c_hidden == C && n_qk == PQ && n_v == PV,                                         \

@@ -153,6 +153,8 @@ _SIGS = {
     "fd_ipa_attn_bwd": "ppppppppppppiis",
     "fd_ipa_softmax_bwd": "ppppppppppiis",
     "fd_ipa_kpts_bwd": "pppppiis",
+    "fd_ipa_dz_acc": "ppplis",
+    "fd_ipa_zb": "ppppls",
     "fd_ipa_pair_fwd": "pppppppppiis",
     "fd_ipa_pair_bwd": "pppppppppp" + "i" + "pppppp" + "iis",
     "fd_ipa_opt_fwd": "ppppls",

@@ -98,6 +98,8 @@ _FUSED_EMBED = os.environ.get("FD_EMBED_FUSED", "1") != "0"
 # per block -- one (b, i) row per block serialises its phases at 2 blocks per CU), so it is opt-in
 FUSED_IPA_PAIR = os.environ.get("FD_IPA_PAIR_FUSED", "0") != "0"
 FUSED_IPA_ATTN = os.environ.get("FD_IPA_ATTN_FUSED", "1") != "0"   # softmax + o_pair per query row in one launch
+DZ_STREAM = os.environ.get("FD_IPA_DZ_STREAM", "1") != "0"   # dz += dzb W40 by the streaming kernel instead of fd_gemm
+ZB_STREAM = os.environ.get("FD_IPA_ZB_STREAM", "0") != "0"   # zb = z W40^T by its streaming sibling (slower: MFMA-bound)
 FUSED_SEQ_ATTN = os.environ.get("FD_SEQ_ATTN_FUSED", "0") != "0"   # sequence-transformer attention in one launch (opt-in:
 # 1-2 % slower than the three launches at every size measured)
 
@@ -264,7 +266,10 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
         L.call("fd_ipa_pair_fwd", A, z, W40, b40, qp, kp, P[f"{pre}.head_weights"], mask, feats, B, N)
     else:
         zb = empty((Pn, ZB), dev)
-        ops.linear(mv(z), mv(W40), b40, mv(zb), Pn, ZB, CZ)
+        if ZB_STREAM and W40.is_contiguous():
+            L.call("fd_ipa_zb", z, W40, b40, zb, Pn)          # (opt-in: 130 vs 119 us for the 128x32-tile GEMM at B=30 x N=128)
+        else:
+            ops.linear(mv(z), mv(W40), b40, mv(zb), Pn, ZB, CZ)
         if FUSED_IPA_ATTN:
             # logits + softmax (A in place) + o_pair (the pair part of feats) of every query row in one launch
             L.call("fd_ipa_attn_fwd", A, zb, qp, kp, P[f"{pre}.head_weights"], mask, feats, B, N)
@@ -344,7 +349,10 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True):
     L.call("fd_ipa_points_bwd", proj, quat, dqp, dkp, dvp, dproj, dframe, R, H, C, PQ, PV)
     # z path: dz += dzb W40 ; dW40 += dzb^T z
     if not fused:
-        ops.linear_dx(mv(dzb), mv(sv["W40"]), mv(dz), Pn, ZB, CZ, beta=True)
+        if DZ_STREAM and sv["W40"].is_contiguous():
+            L.call("fd_ipa_dz_acc", dzb, sv["W40"], dz, Pn, int(bool(dz_accumulate)))
+        else:
+            ops.linear_dx(mv(dzb), mv(sv["W40"]), mv(dz), Pn, ZB, CZ, beta=bool(dz_accumulate))
     if G is not None:
         gW = _adjacent_view(G[f"{pre}.linear_b.weight"], G[f"{pre}.down_z.weight"], (ZB, CZ))
         gb = _adjacent_view(G[f"{pre}.linear_b.bias"], G[f"{pre}.down_z.bias"], (ZB,))

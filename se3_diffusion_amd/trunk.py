@@ -496,8 +496,8 @@ def _backward(P, G, sv, d_out, notify):
         ds = zeros((R, CS), dev)
         dz_acc = dz_in is not None
         if dz_in is None:
-            # last block: no edge transition behind this IPA, its z gradient IS dz (the fused pair pass assigns)
-            dz_in = empty((Pn, CZ), dev) if (st["ipa"]["zb"] is None) else zeros((Pn, CZ), dev)
+            # last block: no edge transition behind this IPA, its z gradient IS dz (ipa_bwd assigns)
+            dz_in = empty((Pn, CZ), dev)
         with rng(f"ipa_{b}.bwd"):
             nw.ipa_bwd(P, G, f"score_model.trunk.ipa_{b}", st["ipa"], dx1, mv(ds), dz_in, dframe, dz_accumulate=dz_acc)
         # fold the IPA frame gradients (dL/dR, dL/dt of the block's input frame) into (dq, dt)

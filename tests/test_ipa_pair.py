@@ -93,3 +93,49 @@ def test_ipa_pair_gpu(hip_lib):
     _run("cuda", B=1, N=200, seed=2)       # NMAX = 256 instantiation
     _run("cuda", B=1, N=512, seed=3)       # NMAX = 512
     _run("cuda", B=5, N=150, seed=4)       # more rows than persistent blocks -> several rows per block
+
+
+def _dz_acc(dev, rows, seed=0):
+    """dz (+)= dzb W40 (fd_ipa_dz_acc) against float64, accumulate and assign, ragged last tile"""
+    g = torch.Generator().manual_seed(seed)
+    dzb, W40, dz0 = (torch.randn(rows, ZB, generator=g).to(dev), (torch.randn(ZB, CZ, generator=g) * 0.1).to(dev),
+                     torch.randn(rows, CZ, generator=g).to(dev))
+    ref = dzb.double().cpu() @ W40.double().cpu()
+    for acc in (1, 0):
+        dz = dz0.clone()
+        lib().call("fd_ipa_dz_acc", dzb, W40, dz, rows, acc)
+        want = ref + (dz0.double().cpu() if acc else 0)
+        assert float((dz.double().cpu() - want).abs().max() / want.abs().max()) < 2e-6
+
+
+def test_ipa_dz_acc_emu(use_emu):
+    _dz_acc("cpu", 100)
+    _dz_acc("cpu", 32 * 9, seed=1)
+
+
+@pytest.mark.gpu
+def test_ipa_dz_acc_gpu(hip_lib):
+    _dz_acc("cuda", 100)
+    _dz_acc("cuda", 70 * 70 * 2, seed=1)
+    _dz_acc("cuda", 30 * 128 * 128, seed=2)
+
+
+def _zb(dev, rows, seed=0):
+    """zb = z W40^T + b40 (fd_ipa_zb) against float64, ragged last tile"""
+    g = torch.Generator().manual_seed(seed)
+    z, W40, b40 = torch.randn(rows, CZ, generator=g).to(dev), (torch.randn(ZB, CZ, generator=g) * 0.1).to(dev), torch.randn(ZB, generator=g).to(dev)
+    zb = torch.full((rows, ZB), 7.0, device=dev)
+    lib().call("fd_ipa_zb", z, W40, b40, zb, rows)
+    ref = z.double().cpu() @ W40.double().cpu().T + b40.double().cpu()
+    assert float((zb.double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+def test_ipa_zb_emu(use_emu):
+    _zb("cpu", 100)
+
+
+@pytest.mark.gpu
+def test_ipa_zb_gpu(hip_lib):
+    _zb("cuda", 100)
+    _zb("cuda", 70 * 70 * 2, seed=1)
+    _zb("cuda", 30 * 128 * 128, seed=2)
