@@ -363,6 +363,11 @@ def main():
 
     for i in range(a.warmup):
         step(i)
+    if a.mixed_n:
+        # every length of the timed schedule once, untimed: a new length means new kernel variants (first use of a code
+        # object), allocator growth and per-length caches -- on a fresh box that was half of a 12-step timed region
+        for i in range(a.warmup, a.warmup + a.steps):
+            step(i)
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):

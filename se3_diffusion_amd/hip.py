@@ -21,6 +21,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfd_hip.so")
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 class FdError(RuntimeError):
     pass
 
@@ -225,6 +228,10 @@ class FdLib:
         for t in tensors:
             if not t.is_cuda:
                 raise FdError("HIP kernel called with a CPU tensor; the hot path has no CPU fallback")
+        # (torch.cuda.current_stream() costs ~8 us of Python per call -- 5 ms of host time per training step; the raw
+        # handle of the same current stream is a C call)
+        if _RAW_STREAM is not None:
+            return _RAW_STREAM(tensors[0].device.index if tensors else torch.cuda.current_device())
         return torch.cuda.current_stream().cuda_stream
 
     def call(self, name: str, *args):

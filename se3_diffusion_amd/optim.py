@@ -61,7 +61,11 @@ class FlatAdam:
         optimiser's back -- model.zero_grad() (set_to_none=True by default), module.to() / _apply -- would otherwise
         leave flat_g all-zero while autograd fills fresh tensors: the step would run on zeros without an error.
         A stray gradient / parameter value is copied into its view first, so nothing is lost."""
+        bp, bg = self.flat_p.data_ptr(), self.flat_g.data_ptr()
         for p, o in zip(self.params, self.offsets):
+            g = p.grad
+            if p.data_ptr() == bp + 4 * o and g is not None and g.data_ptr() == bg + 4 * o:
+                continue                                   # (the common case: two pointer reads per parameter)
             n = p.numel()
             if p.data.data_ptr() != self.flat_p.data_ptr() + 4 * o:
                 view = self.flat_p[o:o + n].view_as(p)
