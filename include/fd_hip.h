@@ -226,8 +226,10 @@ int fd_edge_feats(const long* seq_idx, const float* tscaled, const float* fixed,
 /* ---- Invariant Point Attention, non-GEMM parts: ipa_pytorch.py:303-471 ----
  * layouts in se3_diffusion_amd/csrc/fd_ipa.hip.  Built for base.yaml dims
  * (no_heads 8, c_hidden 256, no_qk_points 8, no_v_points 12). */
+/* kp_soa (may be null): a second copy of the key points as [B, 8, 24, n_res] (R = B * n_res rows), the layout the
+ * attention kernels read with one lane per key */
 int fd_ipa_points_fwd(const float* proj, const float* quat, const float* trans, float* qp, float* kp, float* vp,
-                      long R, int nheads, int c_hidden, int n_qk, int n_v, void* stream);
+                      float* kp_soa, int n_res, long R, int nheads, int c_hidden, int n_qk, int n_v, void* stream);
 int fd_ipa_points_bwd(const float* proj, const float* quat, const float* dqp, const float* dkp, const float* dvp,
                       float* dproj, float* dframe, long R, int nheads, int c_hidden, int n_qk, int n_v,
                       void* stream);
@@ -245,12 +247,13 @@ int fd_ipa_opair_bwd(const float* A, const float* zb, const float* dfeats, float
                      void* stream);
 
 /* softmax + o_pair of a query row in one launch (fd_ipa_softmax_fwd followed by fd_ipa_opair_fwd, bit-identical), and
- * their backward (fd_ipa_opair_bwd followed by fd_ipa_softmax_bwd): the probabilities / the updated dA stay in LDS */
-int fd_ipa_attn_fwd(float* S, const float* zb, const float* qp, const float* kp, const float* head_w,
-                    const float* mask, float* feats, int B, int N, void* stream);
+ * their backward (fd_ipa_opair_bwd followed by fd_ipa_softmax_bwd): the probabilities / the updated dA stay in LDS.
+ * kp_soa (may be null): fd_ipa_points_fwd's [B, 8, 24, N] copy of kp; when given, the key points are read from it */
+int fd_ipa_attn_fwd(float* S, const float* zb, const float* qp, const float* kp, const float* kp_soa,
+                    const float* head_w, const float* mask, float* feats, int B, int N, void* stream);
 int fd_ipa_attn_bwd(const float* A, float* dA, const float* zb, const float* dfeats, const float* qp, const float* kp,
-                    const float* head_w, float* dzb, float* dqp, float* dkp, float* dhead_w, float* hw_part, int B,
-                    int N, void* stream);
+                    const float* kp_soa, const float* head_w, float* dzb, float* dqp, float* dkp, float* dhead_w,
+                    float* hw_part, int B, int N, void* stream);
 
 /* zb[p, 0:40] = W40[0:40, 0:128] z[p, 0:128] + b40 over the pair rows (linear_b and down_z in one streaming pass over z,
  * ipa_pytorch.py:380-386,455): W40 resident in registers; b40 may be null */

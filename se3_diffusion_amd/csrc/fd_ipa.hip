@@ -52,7 +52,10 @@ __global__ __launch_bounds__(256) void ipa_points_fwd_kernel(const float* __rest
                                                              const float* __restrict__ quat,
                                                              const float* __restrict__ trans,
                                                              float* __restrict__ qp, float* __restrict__ kp,
-                                                             float* __restrict__ vp, long R_) {
+                                                             float* __restrict__ vp, float* __restrict__ kp_soa, int N,
+                                                             long R_) {
+  // kp_soa != nullptr: a second copy of the key points as [B, H, 24, N] -- the attention kernels walk the keys with one
+  // lane per j, and 24 floats at a 768-byte lane stride cost them half their time (64 lines per 16-byte load)
   const long total = R_ * (NQP + NKVP);
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long r = e / (NQP + NKVP);
@@ -61,6 +64,7 @@ __global__ __launch_bounds__(256) void ipa_points_fwd_kernel(const float* __rest
     const float* pr = proj + r * LDP;
     float x, y, z;
     float* dst;
+    int soa_h = 0, soa_p = -1;
     if (pi < NQP) {
       x = pr[QP_OFF + pi]; y = pr[QP_OFF + NQP + pi]; z = pr[QP_OFF + 2 * NQP + pi];
       dst = qp + (r * NQP + pi) * 3;
@@ -69,11 +73,18 @@ __global__ __launch_bounds__(256) void ipa_points_fwd_kernel(const float* __rest
       x = pr[KVP_OFF + pk]; y = pr[KVP_OFF + NKVP + pk]; z = pr[KVP_OFF + 2 * NKVP + pk];
       const int h = pk / (PQ + PV), p = pk % (PQ + PV);
       dst = p < PQ ? kp + ((r * H + h) * PQ + p) * 3 : vp + ((r * H + h) * PV + (p - PQ)) * 3;
+      if (p < PQ) { soa_h = h; soa_p = p; }
     }
     const float* t = trans + r * 3;
-    dst[0] = R.r[0] * x + R.r[1] * y + R.r[2] * z + t[0];
-    dst[1] = R.r[3] * x + R.r[4] * y + R.r[5] * z + t[1];
-    dst[2] = R.r[6] * x + R.r[7] * y + R.r[8] * z + t[2];
+    const float g0 = R.r[0] * x + R.r[1] * y + R.r[2] * z + t[0];
+    const float g1 = R.r[3] * x + R.r[4] * y + R.r[5] * z + t[1];
+    const float g2 = R.r[6] * x + R.r[7] * y + R.r[8] * z + t[2];
+    dst[0] = g0; dst[1] = g1; dst[2] = g2;
+    if (kp_soa != nullptr && soa_p >= 0) {
+      const long b = r / N, j = r % N;
+      float* d = kp_soa + ((b * H + soa_h) * (PQ * 3) + 3 * soa_p) * N + j;
+      d[0] = g0; d[N] = g1; d[2 * (long)N] = g2;
+    }
   }
 }
 
@@ -138,6 +149,12 @@ __device__ __forceinline__ void load_pts(float (&v)[PQ * 3], const float* __rest
   }
 }
 
+// the same 24 floats of key j from the [B, H, 24, N] copy: 24 loads, each one contiguous run over the lanes of a wave
+__device__ __forceinline__ void load_pts_soa(float (&v)[PQ * 3], const float* __restrict__ src, int N) {
+#pragma unroll
+  for (int k = 0; k < PQ * 3; ++k) v[k] = src[(long)k * N];
+}
+
 // SLAB (N <= NMAX = 256): the row's [N, 40] block of zb -- one contiguous 160 N bytes -- is copied to LDS with whole-line
 // float4 loads and both the bias column of the logits and the 32 o_pair columns are served from there; the direct reads
 // (4 bytes at a 160-byte stride for the bias, 128 of every 160 bytes for o_pair) fetched about twice the bytes they used.
@@ -146,6 +163,7 @@ template <int NMAX, bool SLAB>
 __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict__ S, const float* __restrict__ zb,
                                                               const float* __restrict__ qp,
                                                               const float* __restrict__ kp,
+                                                              const float* __restrict__ kp_soa,
                                                               const float* __restrict__ head_w,
                                                               const float* __restrict__ mask, float* __restrict__ feats,
                                                               int N) {
@@ -181,7 +199,10 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict_
     for (int j = lane; j < N; j += 64) {
       const long bj = (long)b * N + j;
       float ksrc[PQ * 3];
-      load_pts(ksrc, kp + (bj * H + h) * (PQ * 3));
+      if (kp_soa != nullptr)
+        load_pts_soa(ksrc, kp_soa + ((long)b * H + h) * (PQ * 3) * N + j, N);
+      else
+        load_pts(ksrc, kp + (bj * H + h) * (PQ * 3));
       float pt = 0.f;
 #pragma unroll
       for (int p = 0; p < PQ; ++p) {
@@ -230,6 +251,7 @@ template <bool FUSED, int NMAX, bool SLAB = false>
 __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __restrict__ A, float* __restrict__ dA,
                                                               const float* __restrict__ qp,
                                                               const float* __restrict__ kp,
+                                                              const float* __restrict__ kp_soa,
                                                               const float* __restrict__ head_w,
                                                               float* __restrict__ dzb, float* __restrict__ dqp,
                                                               float* __restrict__ hw_part, const float* __restrict__ zb,
@@ -305,7 +327,10 @@ __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __res
       dArow[j] = dl;
       dl_s[h][j] = dl;
       float ksrc[PQ * 3];
-      load_pts(ksrc, kp + (((long)b * N + j) * H + h) * (PQ * 3));
+      if (kp_soa != nullptr)
+        load_pts_soa(ksrc, kp_soa + ((long)b * H + h) * (PQ * 3) * N + j, N);
+      else
+        load_pts(ksrc, kp + (((long)b * N + j) * H + h) * (PQ * 3));
       float d2 = 0.f;
 #pragma unroll
       for (int k = 0; k < PQ * 3; ++k) {
@@ -639,11 +664,14 @@ static unsigned grid1d(long n) {
 }
 
 extern "C" int fd_ipa_points_fwd(const float* proj, const float* quat, const float* trans, float* qp, float* kp,
-                                 float* vp, long R_, int nheads, int c_hidden, int n_qk, int n_v, void* stream) {
+                                 float* vp, float* kp_soa, int n_res, long R_, int nheads, int c_hidden, int n_qk,
+                                 int n_v, void* stream) {
   CHECK_DIMS("fd_ipa_points_fwd");
   if (R_ == 0) return FD_OK;
+  FD_CHECK_ARG(kp_soa == nullptr || (n_res > 0 && R_ % n_res == 0),
+               "fd_ipa_points_fwd: kp_soa needs the residue count per backbone (R=%ld, n_res=%d)", R_, n_res);
   hipLaunchKernelGGL(ipa_points_fwd_kernel, dim3(grid1d(R_ * (NQP + NKVP))), dim3(256), 0, (hipStream_t)stream, proj,
-                     quat, trans, qp, kp, vp, R_);
+                     quat, trans, qp, kp, vp, kp_soa, n_res > 0 ? n_res : 1, R_);
   FD_CHECK_LAUNCH("fd_ipa_points_fwd");
   return FD_OK;
 }
@@ -664,25 +692,25 @@ extern "C" int fd_ipa_softmax_fwd(float* S, const float* zb, const float* qp, co
   FD_CHECK_ARG(N <= MAXN, "fd_ipa_softmax_fwd: N=%d exceeds %d", N, MAXN);
   if (B == 0 || N == 0) return FD_OK;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_fwd_kernel<MAXN, false>), dim3((unsigned)((long)B * N)), dim3(256), 0,
-                     (hipStream_t)stream, S, zb, qp, kp, head_w, mask, (float*)nullptr, N);
+                     (hipStream_t)stream, S, zb, qp, kp, (const float*)nullptr, head_w, mask, (float*)nullptr, N);
   FD_CHECK_LAUNCH("fd_ipa_softmax_fwd");
   return FD_OK;
 }
 
-extern "C" int fd_ipa_attn_fwd(float* S, const float* zb, const float* qp, const float* kp, const float* head_w,
-                               const float* mask, float* feats, int B, int N, void* stream) {
+extern "C" int fd_ipa_attn_fwd(float* S, const float* zb, const float* qp, const float* kp, const float* kp_soa,
+                               const float* head_w, const float* mask, float* feats, int B, int N, void* stream) {
   FD_CHECK_ARG(N <= MAXN, "fd_ipa_attn_fwd: N=%d exceeds %d", N, MAXN);
   FD_CHECK_ARG(feats != nullptr, "fd_ipa_attn_fwd: feats is required");
   if (B == 0 || N == 0) return FD_OK;
   if (N <= 128 && fd_aligned16(zb))
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_fwd_kernel<128, true>), dim3((unsigned)((long)B * N)), dim3(256), 0,
-                       (hipStream_t)stream, S, zb, qp, kp, head_w, mask, feats, N);
+                       (hipStream_t)stream, S, zb, qp, kp, kp_soa, head_w, mask, feats, N);
   else if (N <= 256 && fd_aligned16(zb))
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_fwd_kernel<256, true>), dim3((unsigned)((long)B * N)), dim3(256), 0,
-                       (hipStream_t)stream, S, zb, qp, kp, head_w, mask, feats, N);
+                       (hipStream_t)stream, S, zb, qp, kp, kp_soa, head_w, mask, feats, N);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_fwd_kernel<MAXN, false>), dim3((unsigned)((long)B * N)), dim3(256), 0,
-                       (hipStream_t)stream, S, zb, qp, kp, head_w, mask, feats, N);
+                       (hipStream_t)stream, S, zb, qp, kp, kp_soa, head_w, mask, feats, N);
   FD_CHECK_LAUNCH("fd_ipa_attn_fwd");
   return FD_OK;
 }
@@ -697,11 +725,11 @@ extern "C" int fd_ipa_softmax_bwd(const float* A, float* dA, const float* qp, co
   if (B == 0 || N == 0) return FD_OK;
   if (N <= 256)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_bwd_kernel<false, 256>), dim3((unsigned)((long)B * N)), dim3(256), 0,
-                       (hipStream_t)stream, A, dA, qp, kp, head_w, dzb, dqp, hw_part, (const float*)nullptr,
+                       (hipStream_t)stream, A, dA, qp, kp, (const float*)nullptr, head_w, dzb, dqp, hw_part, (const float*)nullptr,
                        (const float*)nullptr, N);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_bwd_kernel<false, MAXN>), dim3((unsigned)((long)B * N)), dim3(256), 0,
-                       (hipStream_t)stream, A, dA, qp, kp, head_w, dzb, dqp, hw_part, (const float*)nullptr,
+                       (hipStream_t)stream, A, dA, qp, kp, (const float*)nullptr, head_w, dzb, dqp, hw_part, (const float*)nullptr,
                        (const float*)nullptr, N);
   FD_CHECK_LAUNCH("fd_ipa_softmax_bwd");
   {
@@ -712,24 +740,24 @@ extern "C" int fd_ipa_softmax_bwd(const float* A, float* dA, const float* qp, co
 }
 
 extern "C" int fd_ipa_attn_bwd(const float* A, float* dA, const float* zb, const float* dfeats, const float* qp,
-                               const float* kp, const float* head_w, float* dzb, float* dqp, float* dkp,
-                               float* dhead_w, float* hw_part, int B, int N, void* stream) {
+                               const float* kp, const float* kp_soa, const float* head_w, float* dzb, float* dqp,
+                               float* dkp, float* dhead_w, float* hw_part, int B, int N, void* stream) {
   FD_CHECK_ARG(N <= MAXN, "fd_ipa_attn_bwd: N=%d exceeds %d", N, MAXN);
   FD_CHECK_ARG(zb && dfeats, "fd_ipa_attn_bwd: zb / dfeats are required");
   if (B == 0 || N == 0) return FD_OK;
   const bool al = fd_aligned16(zb) && fd_aligned16(dzb);
   if (N <= 128 && al)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_bwd_kernel<true, 128, true>), dim3((unsigned)((long)B * N)), dim3(256), 0,
-                       (hipStream_t)stream, A, dA, qp, kp, head_w, dzb, dqp, hw_part, zb, dfeats, N);
+                       (hipStream_t)stream, A, dA, qp, kp, kp_soa, head_w, dzb, dqp, hw_part, zb, dfeats, N);
   else if (N <= 256 && al)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_bwd_kernel<true, 256, true>), dim3((unsigned)((long)B * N)), dim3(256), 0,
-                       (hipStream_t)stream, A, dA, qp, kp, head_w, dzb, dqp, hw_part, zb, dfeats, N);
+                       (hipStream_t)stream, A, dA, qp, kp, kp_soa, head_w, dzb, dqp, hw_part, zb, dfeats, N);
   else if (N <= 256)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_bwd_kernel<true, 256>), dim3((unsigned)((long)B * N)), dim3(256), 0,
-                       (hipStream_t)stream, A, dA, qp, kp, head_w, dzb, dqp, hw_part, zb, dfeats, N);
+                       (hipStream_t)stream, A, dA, qp, kp, kp_soa, head_w, dzb, dqp, hw_part, zb, dfeats, N);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_bwd_kernel<true, MAXN>), dim3((unsigned)((long)B * N)), dim3(256), 0,
-                       (hipStream_t)stream, A, dA, qp, kp, head_w, dzb, dqp, hw_part, zb, dfeats, N);
+                       (hipStream_t)stream, A, dA, qp, kp, kp_soa, head_w, dzb, dqp, hw_part, zb, dfeats, N);
   FD_CHECK_LAUNCH("fd_ipa_attn_bwd");
   {
     int rc = fd_colsum_acc(hw_part, H, (long)B * N, H, dhead_w, stream);

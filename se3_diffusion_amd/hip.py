@@ -148,12 +148,12 @@ _SIGS = {
     "fd_add2d": "plpllifs",
     "fd_node_feats": "ppppppiis",
     "fd_edge_feats": "pppppppppiis",
-    "fd_ipa_points_fwd": "ppppppliiiis",
+    "fd_ipa_points_fwd": "pppppppiliiiis",
     "fd_ipa_points_bwd": "pppppppliiiis",
     "fd_ipa_softmax_fwd": "ppppppiis",
-    "fd_ipa_attn_fwd": "pppppppiis",
+    "fd_ipa_attn_fwd": "ppppppppiis",
     "fd_seq_attn_fwd": "ppppfiis",
-    "fd_ipa_attn_bwd": "ppppppppppppiis",
+    "fd_ipa_attn_bwd": "pppppppppppppiis",
     "fd_ipa_softmax_bwd": "ppppppppppiis",
     "fd_ipa_kpts_bwd": "pppppiis",
     "fd_ipa_dz_acc": "ppplis",

@@ -100,6 +100,7 @@ FUSED_IPA_PAIR = os.environ.get("FD_IPA_PAIR_FUSED", "0") != "0"
 FUSED_IPA_ATTN = os.environ.get("FD_IPA_ATTN_FUSED", "1") != "0"   # softmax + o_pair per query row in one launch
 DZ_STREAM = os.environ.get("FD_IPA_DZ_STREAM", "1") != "0"   # dz += dzb W40 by the streaming kernel instead of fd_gemm
 ZB_STREAM = os.environ.get("FD_IPA_ZB_STREAM", "0") != "0"   # zb = z W40^T by its streaming sibling (slower: MFMA-bound)
+KP_SOA = os.environ.get("FD_IPA_KP_SOA", "1") != "0"   # the attention kernels read the key points from a [B,8,24,N] copy
 FUSED_SEQ_ATTN = os.environ.get("FD_SEQ_ATTN_FUSED", "0") != "0"   # sequence-transformer attention in one launch (opt-in:
 # 1-2 % slower than the three launches at every size measured)
 
@@ -244,7 +245,9 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
         ops.linear(s, mv(P[f"{pre}.linear_q_points.weight"]), P[f"{pre}.linear_q_points.bias"], (proj, 6144, LDP), R, 192, CS)
         ops.linear(s, mv(P[f"{pre}.linear_kv_points.weight"]), P[f"{pre}.linear_kv_points.bias"], (proj, 6336, LDP), R, 480, CS)
     qp = empty((R, H, PQ * 3), dev); kp = empty((R, H, PQ * 3), dev); vp = empty((R, H, PV * 3), dev)
-    lib().call("fd_ipa_points_fwd", proj, quat, trans, qp, kp, vp, R, H, C, PQ, PV)
+    # (the copy serves fd_ipa_attn_fwd/bwd only: the unfused softmax kernels and the fused pair pass read kp)
+    kpT = empty((B, H, PQ * 3, N), dev) if KP_SOA and FUSED_IPA_ATTN and not (FUSED_IPA_PAIR and N <= 512) else None
+    lib().call("fd_ipa_points_fwd", proj, quat, trans, qp, kp, vp, kpT, N, R, H, C, PQ, PV)
     if cache is not None and ("W40", pre) in cache:
         W40, b40 = cache[("W40", pre)]
     else:
@@ -272,7 +275,7 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
             ops.linear(mv(z), mv(W40), b40, mv(zb), Pn, ZB, CZ)
         if FUSED_IPA_ATTN:
             # logits + softmax (A in place) + o_pair (the pair part of feats) of every query row in one launch
-            L.call("fd_ipa_attn_fwd", A, zb, qp, kp, P[f"{pre}.head_weights"], mask, feats, B, N)
+            L.call("fd_ipa_attn_fwd", A, zb, qp, kp, kpT, P[f"{pre}.head_weights"], mask, feats, B, N)
         else:
             L.call("fd_ipa_softmax_fwd", A, zb, qp, kp, P[f"{pre}.head_weights"], mask, B, N)
     L.gemm(A, proj, feats, N, C, N, (N, 1), (LDP, 1), LDF, b_off=2048 + C, batch=B * H, bdiv=H,
@@ -286,7 +289,7 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
     x1 = empty((R, CS), dev)
     ops.linear(mv(feats), mv(P[f"{pre}.linear_out.weight"]), P[f"{pre}.linear_out.bias"], mv(x1), R, CS, LDF,
                rowscale=mask, resid=s)
-    sv = dict(s=s, z=z, quat=quat, trans=trans, mask=mask, proj=proj, qp=qp, kp=kp, vp=vp, W40=W40, b40=b40, zb=zb, A=A,
+    sv = dict(s=s, z=z, quat=quat, trans=trans, mask=mask, proj=proj, qp=qp, kp=kp, kpT=kpT, vp=vp, W40=W40, b40=b40, zb=zb, A=A,
               feats=feats, B=B, N=N)
     return x1, sv
 
@@ -336,7 +339,8 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True):
         # o_pair backward + softmax backward (dA becomes dLogits) + point / bias / head-weight grads
         dzb = empty((Pn, ZB), dev)
         if FUSED_IPA_ATTN:
-            L.call("fd_ipa_attn_bwd", A, dA, zb, dfeats, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, hw_part, B, N)
+            L.call("fd_ipa_attn_bwd", A, dA, zb, dfeats, qp, kp, sv["kpT"], P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw,
+                   hw_part, B, N)
         else:
             L.call("fd_ipa_opair_bwd", A, zb, dfeats, dA, dzb, B, N)
             L.call("fd_ipa_softmax_bwd", A, dA, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, hw_part, B, N)

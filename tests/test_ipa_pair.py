@@ -28,12 +28,30 @@ def rel(a, b):
     return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
 
 
+def _points_soa(dev, B, N, seed):
+    """fd_ipa_points_fwd's second copy of the key points ([B, 8, 24, N]) holds exactly kp's values."""
+    g = torch.Generator().manual_seed(seed)
+    R = B * N
+    proj = torch.randn(R, 6816, generator=g).to(dev)
+    quat = torch.nn.functional.normalize(torch.randn(R, 4, generator=g), dim=-1).to(dev)
+    trans = torch.randn(R, 3, generator=g).to(dev)
+    out = [torch.empty(R, H, n * 3, device=dev) for n in (PQ, PQ, 12)]
+    ref = [torch.empty(R, H, n * 3, device=dev) for n in (PQ, PQ, 12)]
+    kpT = torch.full((B, H, PQ * 3, N), float("nan"), device=dev)
+    lib().call("fd_ipa_points_fwd", proj, quat, trans, *ref, None, 0, R, H, 256, PQ, 12)
+    lib().call("fd_ipa_points_fwd", proj, quat, trans, *out, kpT, N, R, H, 256, PQ, 12)
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    assert torch.equal(kpT, ref[1].reshape(B, N, H, PQ * 3).permute(0, 2, 3, 1))
+
+
 def _run(dev, B, N, seed=0):
     t = _inputs(dev, B, N, seed)
     L = lib()
     R, P = B * N, B * N * N
     e = lambda *s: torch.empty(*s, device=dev)
     zer = lambda *s: torch.zeros(*s, device=dev)
+    _points_soa(dev, B, N, seed)
     # ---- forward ----
     zb = e(P, ZB)
     ops.linear(mv(t["z"]), mv(t["W40"]), t["b40"], mv(zb), P, ZB, CZ)
@@ -44,7 +62,13 @@ def _run(dev, B, N, seed=0):
     # softmax + o_pair in one launch (fd_ipa_attn_fwd, the shipped path): the same arithmetic, bit for bit
     S_a = t["S0"].clone()
     f_a = zer(R, LDF)
-    L.call("fd_ipa_attn_fwd", S_a, zb, t["qp"], t["kp"], t["hw"], t["mask"], f_a, B, N)
+    L.call("fd_ipa_attn_fwd", S_a, zb, t["qp"], t["kp"], None, t["hw"], t["mask"], f_a, B, N)
+    assert torch.equal(S_a, S_u) and torch.equal(f_a, f_u)
+    # ... and with the key points read from the [B, 8, 24, N] copy (what the network passes)
+    kpT = t["kp"].reshape(B, N, H, PQ * 3).permute(0, 2, 3, 1).contiguous()
+    S_a = t["S0"].clone()
+    f_a = zer(R, LDF)
+    L.call("fd_ipa_attn_fwd", S_a, zb, t["qp"], t["kp"], kpT, t["hw"], t["mask"], f_a, B, N)
     assert torch.equal(S_a, S_u) and torch.equal(f_a, f_u)
     S_f = t["S0"].clone()
     f_f = zer(R, LDF)
@@ -61,10 +85,14 @@ def _run(dev, B, N, seed=0):
     # o_pair backward + softmax backward in one launch (fd_ipa_attn_bwd): bit-identical to the pair of launches
     dA_a, dzb_a = t["dA0"].clone(), e(P, ZB)
     dqp_a, dkp_a, dhw_a, part_a = e(R, H, PQ * 3), e(R, H, PQ * 3), zer(H), e(R, H)
-    L.call("fd_ipa_attn_bwd", S_u, dA_a, zb, t["dfeats"], t["qp"], t["kp"], t["hw"], dzb_a, dqp_a, dkp_a, dhw_a, part_a, B, N)
-    for name, got, want in (("dA", dA_a, dA_u), ("dzb", dzb_a, dzb), ("dqp", dqp_a, dqp_u), ("dkp", dkp_a, dkp_u)):
-        assert torch.equal(got, want), name
-    assert rel(dhw_a, dhw_u) < 1e-5          # (column sums of per-row partials: atomics, order not fixed)
+    for soa in (None, kpT):
+        dA_a, dzb_a = t["dA0"].clone(), e(P, ZB)
+        dqp_a, dkp_a, dhw_a, part_a = e(R, H, PQ * 3), e(R, H, PQ * 3), zer(H), e(R, H)
+        L.call("fd_ipa_attn_bwd", S_u, dA_a, zb, t["dfeats"], t["qp"], t["kp"], soa, t["hw"], dzb_a, dqp_a, dkp_a, dhw_a,
+               part_a, B, N)
+        for name, got, want in (("dA", dA_a, dA_u), ("dzb", dzb_a, dzb), ("dqp", dqp_a, dqp_u), ("dkp", dkp_a, dkp_u)):
+            assert torch.equal(got, want), (name, soa is not None)
+        assert rel(dhw_a, dhw_u) < 1e-5          # (column sums of per-row partials: atomics, order not fixed)
     dz_u = t["dz0"].clone()
     ops.linear_dx(mv(dzb), mv(t["W40"]), mv(dz_u), P, ZB, CZ, beta=True)
     dW_u, db_u = zer(ZB, CZ), zer(ZB)

@@ -34,12 +34,16 @@ def main():
     L = lib()
     t1 = timeit(lambda: L.call("fd_ipa_softmax_fwd", S, zb, qp, kp, hw, mask, B, N))
     t2 = timeit(lambda: L.call("fd_ipa_opair_fwd", S, zb, feats, B, N))
-    t3 = timeit(lambda: L.call("fd_ipa_attn_fwd", S, zb, qp, kp, hw, mask, feats, B, N))
+    kpT = kp.reshape(B, N, H, PQ * 3).permute(0, 2, 3, 1).contiguous()
+    t3 = timeit(lambda: L.call("fd_ipa_attn_fwd", S, zb, qp, kp, None, hw, mask, feats, B, N))
+    t3s = timeit(lambda: L.call("fd_ipa_attn_fwd", S, zb, qp, kp, kpT, hw, mask, feats, B, N))
     L.call("fd_ipa_softmax_fwd", S, zb, qp, kp, hw, mask, B, N)
     dA, dzb = dA0.clone(), torch.empty(P, ZB, device=dev)
     dqp, dkp, dhw, part = torch.empty(R, H, PQ * 3, device=dev), torch.empty(R, H, PQ * 3, device=dev), torch.zeros(H, device=dev), torch.empty(R, H, device=dev)
-    t4 = timeit(lambda: L.call("fd_ipa_attn_bwd", S, dA, zb, dfeats, qp, kp, hw, dzb, dqp, dkp, dhw, part, B, N))
-    print(f"B={B} N={N}: softmax_fwd {t1:.1f} us | opair_fwd {t2:.1f} us | attn_fwd (both) {t3:.1f} us | attn_bwd (+kpts, colsum) {t4:.1f} us")
+    t4 = timeit(lambda: L.call("fd_ipa_attn_bwd", S, dA, zb, dfeats, qp, kp, None, hw, dzb, dqp, dkp, dhw, part, B, N))
+    t4s = timeit(lambda: L.call("fd_ipa_attn_bwd", S, dA, zb, dfeats, qp, kp, kpT, hw, dzb, dqp, dkp, dhw, part, B, N))
+    print(f"B={B} N={N}: softmax_fwd {t1:.1f} us | opair_fwd {t2:.1f} us | attn_fwd (both) {t3:.1f} us, key points from the "
+          f"[B,8,24,N] copy {t3s:.1f} us | attn_bwd (+kpts, colsum) {t4:.1f} us, with the copy {t4s:.1f} us")
 
 
 if __name__ == "__main__":
