@@ -188,16 +188,18 @@ int fd_edge_embed(const FdEdgeEmbedDesc* desc, void* stream);
  * Split-bf16 arithmetic (fp32-accurate, as fd_gemm tile 4); C accumulates atomically. */
 #define FD_PAIR_DW_MAX_ITEMS 8
 typedef struct FdPairDwItem {
-  const float* A;       /* [rows, 384], row stride lda: its columns index m */
+  const float* A;       /* [rows, 384] ([rows, 128] when a_bands == 1), row stride lda: its columns index m */
   long lda;
   const float* A_add;   /* optional [rows, 128], row stride ld_add: added to columns 0..127 of A */
   long ld_add;
-  const float* B;       /* [rows, 128], row stride ldb: its columns index n */
+  const float* B;       /* [rows, 128] ([rows, b_cols] when b_cols > 0), row stride ldb: its columns index n */
   long ldb;
   float* C;             /* trans == 0: C[m * ldc + n] += ...; trans != 0: C[n * ldc + m] += ... */
   long ldc;
   float* a_colsum;      /* optional [384]: += sum_p A[p, :] (+ A_add) -- the bias gradient when A is dY */
   int trans;
+  int a_bands;          /* 0 or 3: A has 384 columns; 1: A has 128 columns (a 128 x 128 tile; no trans / A_add) */
+  int b_cols;           /* 0: B has 128 columns; else its column count (a multiple of 4, <= 128): C has b_cols columns */
 } FdPairDwItem;
 typedef struct FdPairDwDesc {
   FdPairDwItem item[FD_PAIR_DW_MAX_ITEMS];

@@ -62,7 +62,9 @@ __device__ __forceinline__ T* dw_global(T* p) {
   return (T*)(__attribute__((address_space(1))) T*)p;
 }
 
-template <bool TRANS, bool HAS_ADD, bool HAS_CS>
+// NA = 128-column bands of A (3: the 384 x 128 tile; 1: a 128 x 128 tile -- the 128-wide layers of the edge embedder --
+// where wave (wm, wn) owns ONE A panel and 12 MFMAs per stage)
+template <int NA, bool TRANS, bool HAS_ADD, bool HAS_CS>
 __device__ __forceinline__ void dw_block(const FdPairDwItem& it, long row0, long row1, char* lds) {
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -76,6 +78,11 @@ __device__ __forceinline__ void dw_block(const FdPairDwItem& it, long row0, long
   wofs[3] = (12 + (c4 >> 3)) * DW_PSTRIDE + kk * 64 + (c4 & 7) * 8;
   constexpr bool has_add = HAS_ADD, has_cs = HAS_CS;
 
+  // B with fewer than 128 columns (b_cols: the 120 input features of the embedder's first layer): the lanes of the missing
+  // columns read column 0 instead and stage zeros; their C columns are not written
+  const int nb = it.b_cols > 0 ? it.b_cols : 128;
+  const bool bok = 4 * c4 < nb;
+  const int cb = bok ? 4 * c4 : 0;
   const float* __restrict__ A = dw_global(it.A) + row0 * it.lda;
   const float* __restrict__ B = dw_global(it.B) + row0 * it.ldb;
   const float* __restrict__ Ad = has_add ? dw_global(it.A_add) + row0 * it.ld_add : A;
@@ -84,10 +91,10 @@ __device__ __forceinline__ void dw_block(const FdPairDwItem& it, long row0, long
   const long nrows = row1 - row0;
   const int nst = (int)((nrows + DW_KS - 1) / DW_KS);
 
-  float4 rg[2][4], radd[2];
-  float csum[3][4];
+  float4 rg[2][4], radd[2];      // slots 0 .. NA-1: the bands of A, slot 3: B
+  float csum[NA][4];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < NA; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) csum[i][e] = 0.f;
 
@@ -101,13 +108,14 @@ __device__ __forceinline__ void dw_block(const FdPairDwItem& it, long row0, long
     const long kc = ok ? k : last;
     const float* a = A + kc * it.lda + 4 * c4;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const float4 v = *reinterpret_cast<const float4*>(a + 128 * i);
       r[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
     }
     {
-      const float4 v = *reinterpret_cast<const float4*>(B + kc * it.ldb + 4 * c4);
-      r[3] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+      const float4 v = *reinterpret_cast<const float4*>(B + kc * it.ldb + cb);
+      const bool okb = ok && bok;
+      r[3] = make_float4(okb ? v.x : 0.f, okb ? v.y : 0.f, okb ? v.z : 0.f, okb ? v.w : 0.f);
     }
     if (has_add) {
       const float4 v = *reinterpret_cast<const float4*>(Ad + kc * it.ld_add + 4 * c4);
@@ -118,10 +126,11 @@ __device__ __forceinline__ void dw_block(const FdPairDwItem& it, long row0, long
     if (has_add) { r[0].x += ra.x; r[0].y += ra.y; r[0].z += ra.z; r[0].w += ra.w; }
     if (has_cs) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { csum[i][0] += r[i].x; csum[i][1] += r[i].y; csum[i][2] += r[i].z; csum[i][3] += r[i].w; }
+      for (int i = 0; i < NA; ++i) { csum[i][0] += r[i].x; csum[i][1] += r[i].y; csum[i][2] += r[i].z; csum[i][3] += r[i].w; }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if (i >= NA && i != 3) continue;
       uint2 s0, s1, s2;
       dw_split4(r[i], s0, s1, s2);
       *reinterpret_cast<uint2*>(dst + wofs[i]) = s0;
@@ -130,13 +139,13 @@ __device__ __forceinline__ void dw_block(const FdPairDwItem& it, long row0, long
     }
   };
 
-  // ---- MFMA side: wave (wm, wn) owns A panels 3wm..3wm+2 and B panels 2wn, 2wn+1 ----
+  // ---- MFMA side: wave (wm, wn) owns A panels NA wm .. NA wm + NA - 1 and B panels 2wn, 2wn+1 ----
   const int i16 = lane & 15, half = (lane >> 4) & 1, kg = lane >> 5;
   const int lofs = (8 * kg + (i16 >> 2)) * 64 + half * 32 + (i16 & 3) * 8;
-  const int a_rd = (3 * wm) * DW_PSTRIDE + lofs, b_rd = (12 + 2 * wn) * DW_PSTRIDE + lofs;
-  f32x16 acc[3][2];
+  const int a_rd = (NA * wm) * DW_PSTRIDE + lofs, b_rd = (12 + 2 * wn) * DW_PSTRIDE + lofs;
+  f32x16 acc[NA][2];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < NA; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -150,13 +159,13 @@ __device__ __forceinline__ void dw_block(const FdPairDwItem& it, long row0, long
       for (int j = 0; j < 2; ++j) fb[j][s] = dw_read8(st + b_rd + j * DW_PSTRIDE + s * DW_PLANE);
 #pragma unroll
     for (int sa = 2; sa >= 0; --sa) {   // the small terms first
-      uint4 fa[3];
+      uint4 fa[NA];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) fa[i] = dw_read8(st + a_rd + i * DW_PSTRIDE + sa * DW_PLANE);
+      for (int i = 0; i < NA; ++i) fa[i] = dw_read8(st + a_rd + i * DW_PSTRIDE + sa * DW_PLANE);
 #pragma unroll
       for (int sb = 2 - sa; sb >= 0; --sb)
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NA; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[i][j] = TRANS ? fd::mfma_32x32x16_bf16(fb[j][sb], fa[i], acc[i][j])
@@ -168,13 +177,16 @@ __device__ __forceinline__ void dw_block(const FdPairDwItem& it, long row0, long
   // load() (it costs ~35 of the ~135 VALU instructions a wave spends per stage, six of them quarter-rate 32-bit
   // multiplies, and the SIMD's issue port is shared with the MFMAs): the pointers always stand at the next stage.
   const float* pa = A + ((long)3 * DW_KS + kk) * it.lda + 4 * c4;
-  const float* pb = B + ((long)3 * DW_KS + kk) * it.ldb + 4 * c4;
+  const float* pb = B + ((long)3 * DW_KS + kk) * it.ldb + cb;
   const float* pd = Ad + ((long)3 * DW_KS + kk) * it.ld_add + 4 * c4;
   const long sa = (long)DW_KS * it.lda, sb = (long)DW_KS * it.ldb, sd = (long)DW_KS * it.ld_add;
   auto load_fast = [&](float4 (&r)[4], float4& ra) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) r[i] = *reinterpret_cast<const float4*>(pa + 128 * i);
-    r[3] = *reinterpret_cast<const float4*>(pb);
+    for (int i = 0; i < NA; ++i) r[i] = *reinterpret_cast<const float4*>(pa + 128 * i);
+    {
+      const float4 v = *reinterpret_cast<const float4*>(pb);
+      r[3] = make_float4(bok ? v.x : 0.f, bok ? v.y : 0.f, bok ? v.z : 0.f, bok ? v.w : 0.f);
+    }
     if (has_add) ra = *reinterpret_cast<const float4*>(pd);
     pa += sa;
     pb += sb;
@@ -215,21 +227,21 @@ __device__ __forceinline__ void dw_block(const FdPairDwItem& it, long row0, long
   // ---- flush: C (+)= acc, atomically (every row range adds its part) ----
   const int h = lane >> 5, l31 = lane & 31;
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < NA; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
         // !TRANS: D[row = m][col = n]; TRANS: D[row = n][col = m]
-        const int m = (3 * wm + i) * 32 + (TRANS ? l31 : rr);
+        const int m = (NA * wm + i) * 32 + (TRANS ? l31 : rr);
         const int n = (2 * wn + j) * 32 + (TRANS ? rr : l31);
         float* c = TRANS ? C + (long)n * it.ldc + m : C + (long)m * it.ldc + n;
-        atomicAdd(c, acc[i][j][r]);
+        if (n < nb) atomicAdd(c, acc[i][j][r]);
       }
   if (has_cs) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) atomicAdd(colsum + 4 * (c4 + 32 * i) + e, csum[i][e]);
   }
@@ -253,16 +265,23 @@ __global__ __launch_bounds__(DW_THREADS, 1) void pair_dw_kernel(FdPairDwDesc d) 
 #pragma unroll
   for (int t = 1; t < FD_PAIR_DW_MAX_ITEMS; ++t)
     if (item == t) it = d.item[t];
+  if (it.a_bands == 1) {   // 128 x 128 tile: plain or with the bias gradient
+    if (it.a_colsum)
+      dw_block<1, false, false, true>(it, row0, row1, lds);
+    else
+      dw_block<1, false, false, false>(it, row0, row1, lds);
+    return;
+  }
   const int mode = (it.trans ? 4 : 0) | (it.A_add ? 2 : 0) | (it.a_colsum ? 1 : 0);
   switch (mode) {
-    case 0: dw_block<false, false, false>(it, row0, row1, lds); break;
-    case 1: dw_block<false, false, true>(it, row0, row1, lds); break;
-    case 2: dw_block<false, true, false>(it, row0, row1, lds); break;
-    case 3: dw_block<false, true, true>(it, row0, row1, lds); break;
-    case 4: dw_block<true, false, false>(it, row0, row1, lds); break;
-    case 5: dw_block<true, false, true>(it, row0, row1, lds); break;
-    case 6: dw_block<true, true, false>(it, row0, row1, lds); break;
-    default: dw_block<true, true, true>(it, row0, row1, lds); break;
+    case 0: dw_block<3, false, false, false>(it, row0, row1, lds); break;
+    case 1: dw_block<3, false, false, true>(it, row0, row1, lds); break;
+    case 2: dw_block<3, false, true, false>(it, row0, row1, lds); break;
+    case 3: dw_block<3, false, true, true>(it, row0, row1, lds); break;
+    case 4: dw_block<3, true, false, false>(it, row0, row1, lds); break;
+    case 5: dw_block<3, true, false, true>(it, row0, row1, lds); break;
+    case 6: dw_block<3, true, true, false>(it, row0, row1, lds); break;
+    default: dw_block<3, true, true, true>(it, row0, row1, lds); break;
   }
 }
 
@@ -278,12 +297,16 @@ extern "C" int fd_pair_dw(const FdPairDwDesc* desc, void* stream_) {
   for (int t = 0; t < d.nitems; ++t) {
     const FdPairDwItem& it = d.item[t];
     FD_CHECK_ARG(it.A && it.B && it.C, "fd_pair_dw: item %d: null operand", t);
-    FD_CHECK_ARG(fd_aligned16(it.A) && fd_aligned16(it.B) && (it.lda & 3) == 0 && (it.ldb & 3) == 0 && it.lda >= 384 &&
-                     it.ldb >= 128,
-                 "fd_pair_dw: item %d: A [rows,384] / B [rows,128] must be 16-byte aligned with row strides %% 4 == 0", t);
+    FD_CHECK_ARG(it.a_bands == 0 || it.a_bands == 1 || it.a_bands == 3, "fd_pair_dw: item %d: a_bands must be 1 or 3", t);
+    const int am = it.a_bands == 1 ? 128 : 384;
+    FD_CHECK_ARG(it.a_bands != 1 || (!it.trans && !it.A_add), "fd_pair_dw: item %d: a 128-column A takes no trans / A_add", t);
+    FD_CHECK_ARG(fd_aligned16(it.A) && fd_aligned16(it.B) && (it.lda & 3) == 0 && (it.ldb & 3) == 0 && it.lda >= am,
+                 "fd_pair_dw: item %d: A [rows,%d] / B [rows,128] must be 16-byte aligned with row strides %% 4 == 0", t, am);
     FD_CHECK_ARG(!it.A_add || (fd_aligned16(it.A_add) && (it.ld_add & 3) == 0 && it.ld_add >= 128),
                  "fd_pair_dw: item %d: A_add [rows,128] must be 16-byte aligned with a row stride %% 4 == 0", t);
-    FD_CHECK_ARG(it.ldc >= (it.trans ? 384 : 128), "fd_pair_dw: item %d: ldc too small", t);
+    FD_CHECK_ARG(it.b_cols >= 0 && it.b_cols <= 128 && (it.b_cols & 3) == 0, "fd_pair_dw: item %d: b_cols must be 0 (= 128) or a multiple of 4 up to 128", t);
+    FD_CHECK_ARG(it.ldb >= (it.b_cols > 0 ? it.b_cols : 128), "fd_pair_dw: item %d: ldb too small", t);
+    FD_CHECK_ARG(it.ldc >= (it.trans ? am : (it.b_cols > 0 ? it.b_cols : 128)), "fd_pair_dw: item %d: ldc too small", t);
   }
   int blocks = d.blocks > 0 ? d.blocks : 256;   // MI355X: one persistent block per CU
   blocks &= ~7;

@@ -110,7 +110,7 @@ PAIR_DW_MAX_ITEMS = 8
 class FdPairDwItem(Structure):
     _fields_ = [
         ("A", c_void_p), ("lda", c_long), ("A_add", c_void_p), ("ld_add", c_long), ("B", c_void_p), ("ldb", c_long),
-        ("C", c_void_p), ("ldc", c_long), ("a_colsum", c_void_p), ("trans", c_int),
+        ("C", c_void_p), ("ldc", c_long), ("a_colsum", c_void_p), ("trans", c_int), ("a_bands", c_int), ("b_cols", c_int),
     ]
 
 

@@ -51,10 +51,25 @@ def check_conf(conf):
 
 
 # --------------------------------------------------------------------------- param grads
+# opt-in: the 128-wide pair-row weight gradients of the edge embedder on fd_pair_dw's 128 x 128 tile.  Measured SLOWER than
+# the 64 x 64 fp32 tiles of fd_gemm inside the step (26.5 / 26.6 / 27.5 ms with 128 / 64 / 32 blocks vs 25.9 ms): a wave has
+# 12 MFMAs per 16-row stage between barriers, and every block flushes a full 128 x 128 tile of atomics
+_EMBED_DW_GROUPED = os.environ.get("FD_EMBED_DW", "0") != "0"
+_EMBED_DW_BLOCKS = int(os.environ.get("FD_EMBED_DW_BLOCKS", "128"))
+
+
 def _lin_grads(G, wname, bname, dy, x, M, N, K, w_off=0, w_ld=None):
     if G is None:
         return
     db = G[bname] if (bname is not None and bname in G) else None
+    if (_EMBED_DW_GROUPED and M >= 65536 and N == 128 and K <= 128 and K % 4 == 0 and w_off == 0 and w_ld is None
+            and wname in G and not lib().exact_f32):
+        # a 128-wide pair-row layer (the edge embedder's, score_network.py:67-86): the grouped split-bf16 kernel on a
+        # 128 x 128 tile instead of the 64 x 64 fp32 tiles of fd_gemm
+        W = G[wname]
+        item = dict(A=dy, B=x, C=(W, 0, K), colsum=db, a_bands=1, b_cols=0 if K == 128 else K)
+        ops.side(lambda: ops.pair_dw([item], M, blocks=_EMBED_DW_BLOCKS), (dy[0], x[0]), M)
+        return
     # node-level calls run on the gradient side stream (ops.side): dy / x must not be written again by the caller
     if wname in G:
         W = G[wname]
@@ -100,6 +115,7 @@ FUSED_IPA_PAIR = os.environ.get("FD_IPA_PAIR_FUSED", "0") != "0"
 FUSED_IPA_ATTN = os.environ.get("FD_IPA_ATTN_FUSED", "1") != "0"   # softmax + o_pair per query row in one launch
 DZ_STREAM = os.environ.get("FD_IPA_DZ_STREAM", "1") != "0"   # dz += dzb W40 by the streaming kernel instead of fd_gemm
 ZB_STREAM = os.environ.get("FD_IPA_ZB_STREAM", "0") != "0"   # zb = z W40^T by its streaming sibling (slower: MFMA-bound)
+_ZB_DW_SIDE = os.environ.get("FD_IPA_ZB_DW_SIDE", "1") != "0"
 KP_SOA = os.environ.get("FD_IPA_KP_SOA", "1") != "0"   # the attention kernels read the key points from a [B,8,24,N] copy
 FUSED_SEQ_ATTN = os.environ.get("FD_SEQ_ATTN_FUSED", "0") != "0"   # sequence-transformer attention in one launch (opt-in:
 # 1-2 % slower than the three launches at every size measured)
@@ -362,8 +378,14 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True):
         gb = _adjacent_view(G[f"{pre}.linear_b.bias"], G[f"{pre}.down_z.bias"], (ZB,))
         if not fused and gW is not None and gb is not None:
             # the two gradients lie back to back in the flat gradient buffer: accumulate into them as one [40, 128] matrix
-            ops.linear_dw(mv(dzb), mv(z), mv(gW), Pn, ZB, CZ)
-            ops.bias_grad(mv(dzb), gb, Pn, ZB)
+            # (on the gradient side stream: 135 us per block that nothing on the dX chain waits for)
+            def _grads_zb():
+                ops.linear_dw(mv(dzb), mv(z), mv(gW), Pn, ZB, CZ)
+                ops.bias_grad(mv(dzb), gb, Pn, ZB)
+            if _ZB_DW_SIDE:
+                ops.side(_grads_zb, (dzb, z), Pn)
+            else:
+                _grads_zb()
         else:
             if not fused:
                 dW40 = zeros((ZB, CZ), dev); db40 = zeros((ZB,), dev)

@@ -337,7 +337,8 @@ def pair_dw(items, rows, blocks=0):
     """One launch for up to 8 tiles  C[m, n] += sum_p (A[p, m] + [m < 128] A_add[p, m]) B[p, n]  (m < 384, n < 128).
 
     items: dicts with A=(tensor, offset, ld) [rows,384], B=(tensor, offset, ld) [rows,128], C=(tensor, offset, ld) and
-    optionally A_add=(tensor, offset, ld) [rows,128], colsum=tensor [384], trans=bool (C[n, m])."""
+    optionally A_add=(tensor, offset, ld) [rows,128], colsum=tensor [384], trans=bool (C[n, m]); a_bands=1: A is
+    [rows,128] (a 128 x 128 tile); b_cols=k: B is [rows,k], k % 4 == 0 (C has k columns)."""
     d = hip.FdPairDwDesc()
     tens = []
     assert 1 <= len(items) <= hip.PAIR_DW_MAX_ITEMS
@@ -356,6 +357,8 @@ def pair_dw(items, rows, blocks=0):
         cs = it.get("colsum")
         e.a_colsum = None if cs is None else hip._ptr(cs)
         e.trans = int(bool(it.get("trans", False)))
+        e.a_bands = int(it.get("a_bands", 3))
+        e.b_cols = int(it.get("b_cols", 0))
     d.nitems, d.rows, d.blocks = len(items), int(rows), int(blocks)
     L = lib()
     stream = L._stream(tens)
@@ -367,6 +370,7 @@ def pair_dw(items, rows, blocks=0):
         e0.record(torch.cuda.current_stream())
         L._check(L.cdll.fd_pair_dw(hip.ctypes.byref(d), stream), "fd_pair_dw")
         e1.record(torch.cuda.current_stream())
-        prof.append((9, False, False, 2.0 * int(rows) * 384 * 128 * len(items), e0, e1, (384, 128 * len(items), int(rows), 1, 0, 0, 0, 1)))
+        flops = sum(2.0 * int(rows) * 128 * int(it.get("a_bands", 3)) * (int(it.get("b_cols", 0)) or 128) for it in items)
+        prof.append((9, False, False, flops, e0, e1, (384, 128 * len(items), int(rows), 1, 0, 0, 0, 1)))
         return
     L._check(L.cdll.fd_pair_dw(hip.ctypes.byref(d), stream), "fd_pair_dw")

@@ -47,7 +47,29 @@ def _run(dev, rows, seed=0, blocks=0, accumulate=False, lda=384):
     assert torch.equal(gW1[:, 128:].double().cpu(), ref0["gW1"][:, 128:])
 
 
+def _run_narrow(dev, rows, seed=0, blocks=0):
+    """a_bands = 1 (A [rows,128]: a 128 x 128 tile) and b_cols = 120 (B [rows,120], C [128,120]) -- the edge embedder's layers
+    (score_network.py:67-86): dW4 = dh3^T h2 (+ bias gradient), dW2 = dh2^T h1, dW0 = dh1^T x with x the 120 input features."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    dh3, dh2, dh1, h2, h1, x = rn(rows, 128), rn(rows, 128), rn(rows, 128), rn(rows, 128), rn(rows, 128), rn(rows, 120)
+    gW4, gb4, gW2, gb2, gW0, gb0 = rn(128, 128), rn(128), rn(128, 128), rn(128), rn(128, 120), rn(128)
+    ref = [t.double().cpu().clone() for t in (gW4, gb4, gW2, gb2, gW0, gb0)]
+    items = [dict(A=(dh3, 0, 128), B=(h2, 0, 128), C=(gW4, 0, 128), colsum=gb4, a_bands=1),
+             dict(A=(dh2, 0, 128), B=(h1, 0, 128), C=(gW2, 0, 128), colsum=gb2, a_bands=1),
+             dict(A=(dh1, 0, 128), B=(x, 0, 120), C=(gW0, 0, 120), colsum=gb0, a_bands=1, b_cols=120)]
+    ops.pair_dw(items, rows, blocks=blocks)
+    d = lambda t: t.double().cpu()
+    want = [ref[0] + d(dh3).T @ d(h2), ref[1] + d(dh3).sum(0), ref[2] + d(dh2).T @ d(h1), ref[3] + d(dh2).sum(0),
+            ref[4] + d(dh1).T @ d(x), ref[5] + d(dh1).sum(0)]
+    for got, w, name in zip((gW4, gb4, gW2, gb2, gW0, gb0), want, ("W4", "b4", "W2", "b2", "W0", "b0")):
+        err = float((d(got) - w).abs().max() / w.abs().max())
+        assert err < 5e-6, (name, err, rows, blocks)
+
+
 def test_pair_dw_emu(use_emu):
+    _run_narrow("cpu", rows=150, blocks=8)
+    _run_narrow("cpu", rows=77, seed=1, blocks=16)
     _run("cpu", rows=150, blocks=8)                         # one group: 9 full stages + a ragged one
     _run("cpu", rows=200, seed=1, blocks=16, accumulate=True)   # three row ranges; C accumulates
     _run("cpu", rows=90, seed=2, blocks=8, lda=512)             # A = a column slice of a wider tensor
@@ -62,3 +84,6 @@ def test_pair_dw_gpu(hip_lib):
     _run("cuda", rows=30 * 128 * 128, seed=4)                 # the training shape
     _run("cuda", rows=30 * 128 * 128, seed=5, blocks=160)     # ... on 160 CUs, as the training step launches it
     _run("cuda", rows=5000, seed=6, lda=512)                  # A = a column slice of a wider tensor
+    _run_narrow("cuda", rows=150, blocks=8)
+    _run_narrow("cuda", rows=101 * 101, seed=1)
+    _run_narrow("cuda", rows=30 * 128 * 128, seed=2)

@@ -52,6 +52,22 @@ def main():
             agg[k][1] += 1
         for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
             print(f"  q{k[0]}  {v[0] / 1e3:9.1f} us  n={v[1]:3d}  {k[1]}")
+    # timeline of that step: every dispatch in start order -- offset from the step start, duration, the idle time before it
+    # on its own queue, and the side-queue kernels running at its start
+    if len(marks) > 4 and len(sys.argv) > 2:
+        a, b = marks[3], marks[4]
+        seg = rows[a + 1:b + 1]
+        t0 = rows[a][1]
+        mainq = max(set(q for _, _, _, q in seg), key=lambda q: sum(1 for r in seg if r[3] == q))
+        last_end = {}
+        with open(sys.argv[2], "w") as f:
+            for s_, e_, n_, q_ in seg:
+                gap = s_ - last_end.get(q_, t0)
+                last_end[q_] = e_
+                co = [n2.replace("(anonymous namespace)::", "")[:24] for s2, e2, n2, q2 in seg if q2 != q_ and s2 <= s_ < e2]
+                name = n_.replace("(anonymous namespace)::", "").replace("void ", "")[:78]
+                f.write(f"{(s_ - t0) / 1e6:8.3f} ms  {'M' if q_ == mainq else 's'}  {(e_ - s_) / 1e3:8.1f} us  gap {gap / 1e3:7.1f}  {name}"
+                        + (f"   || {', '.join(co)}" if co else "") + "\n")
 
 
 if __name__ == "__main__":
