@@ -177,9 +177,32 @@ def embed_fwd(P, feats, B, N, cache=None, save=True):
     return node, edge, dict(node=sv_n, edge=sv_e, emask=emask)
 
 
+_EMBED_REGEN_EARLY = os.environ.get("FD_EMBED_REGEN_EARLY", "1") != "0"
+
+
+def embed_regen_early(sv, G):
+    """The [P,120] pair features the first-layer weight gradient of the fused edge embedder needs are a function of the
+    inputs alone: regenerate them at the START of the backward pass on the gradient side stream (idle then) instead of on
+    the main stream at its end, where nothing is left to hide the 146 us behind."""
+    se = sv["edge"]
+    if (not _EMBED_REGEN_EARLY or G is None or se is None or se.get("x") is not None or "regen" not in se
+            or _EMBED_DW_GROUPED):
+        return
+    seq, tscaled, fixed, sc, B, N = se["regen"]
+    Pn = B * N * N
+    if not ops.side_active(sc, Pn):
+        return            # (its only reader, the weight gradient, would run on the main stream)
+    tfreq, idenom, lower, upper = ops.feature_tables(sc.device)
+    ef = empty((Pn, 120), sc)
+    ops.side(lambda: lib().call("fd_edge_feats", seq, tscaled, fixed, sc, tfreq, idenom, lower, upper, ef, B, N), (ef,), Pn)
+    se["x_early"] = ef
+
+
 def embed_bwd(P, G, sv, dnode, dedge):
     mlp3_ln_bwd(P, G, "embedding_layer.node_embedder", sv["node"], dnode)
     se = sv["edge"]
+    if se.get("x_early") is not None:
+        se = dict(se, x=mv(se.pop("x_early")))     # (read by the side stream only: mlp3_ln_bwd's last _lin_grads)
     if se.get("x") is None:
         seq, tscaled, fixed, sc, B, N = se["regen"]
         tfreq, idenom, lower, upper = ops.feature_tables(dedge.device)

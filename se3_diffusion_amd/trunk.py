@@ -466,6 +466,7 @@ def _backward(P, G, sv, d_out, notify):
     f = sv["feats"]
     dev = sv["mask"]
     dnode = zeros((R, CS), dev)
+    nw.embed_regen_early(sv["embed"], G)
     with rng("heads.bwd"):
         dq, dt = heads_bwd(P, G, sv["heads"], f, d_out, dnode)
     notify("heads")
