@@ -117,8 +117,8 @@ DZ_STREAM = os.environ.get("FD_IPA_DZ_STREAM", "1") != "0"   # dz += dzb W40 by 
 ZB_STREAM = os.environ.get("FD_IPA_ZB_STREAM", "0") != "0"   # zb = z W40^T by its streaming sibling (slower: MFMA-bound)
 _ZB_DW_SIDE = os.environ.get("FD_IPA_ZB_DW_SIDE", "1") != "0"
 KP_SOA = os.environ.get("FD_IPA_KP_SOA", "1") != "0"   # the attention kernels read the key points from a [B,8,24,N] copy
-FUSED_SEQ_ATTN = os.environ.get("FD_SEQ_ATTN_FUSED", "0") != "0"   # sequence-transformer attention in one launch (opt-in:
-# 1-2 % slower than the three launches at every size measured)
+FUSED_SEQ_ATTN = os.environ.get("FD_SEQ_ATTN_FUSED", "1") != "0"   # sequence-transformer attention in one launch (with the
+# merged projections below: 26.12 vs 26.58 ms per training step; neutral in sampling)
 
 
 def fused_embed():
@@ -240,7 +240,7 @@ def _adjacent_view(a, b, shape, *more):
 
 
 _PROJ = ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")
-_PROJ_MERGE = os.environ.get("FD_PROJ_MERGE", "0") != "0"   # opt-in: measured 27.12 vs 27.02 ms per step (no gain)
+_PROJ_MERGE = os.environ.get("FD_PROJ_MERGE", "1") != "0"   # (needs the back-to-back layout of optim.FlatAdam(adjacent=...))
 
 
 def _proj_views(P, pre):
