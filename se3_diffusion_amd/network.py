@@ -116,6 +116,7 @@ FUSED_IPA_ATTN = os.environ.get("FD_IPA_ATTN_FUSED", "1") != "0"   # softmax + o
 DZ_STREAM = os.environ.get("FD_IPA_DZ_STREAM", "1") != "0"   # dz += dzb W40 by the streaming kernel instead of fd_gemm
 ZB_STREAM = os.environ.get("FD_IPA_ZB_STREAM", "0") != "0"   # zb = z W40^T by its streaming sibling (slower: MFMA-bound)
 _ZB_DW_SIDE = os.environ.get("FD_IPA_ZB_DW_SIDE", "1") != "0"
+SEQ_ATTN_MIN_ROWS = int(os.environ.get("FD_SEQ_ATTN_MIN_ROWS", "1024"))
 KP_SOA = os.environ.get("FD_IPA_KP_SOA", "1") != "0"   # the attention kernels read the key points from a [B,8,24,N] copy
 FUSED_SEQ_ATTN = os.environ.get("FD_SEQ_ATTN_FUSED", "1") != "0"   # sequence-transformer attention in one launch (with the
 # merged projections below: 26.12 vs 26.58 ms per training step; neutral in sampling)
@@ -459,9 +460,10 @@ def tfmr_layer_fwd(P, pre, x, key_add, B, N, save=True):
     qkv = empty((R, 3 * TD), dev)
     ops.linear(mv(x), mv(P[f"{pre}.self_attn.in_proj_weight"]), P[f"{pre}.self_attn.in_proj_bias"], mv(qkv), R, 3 * TD, TD)
     o = empty((R, TD), dev)
-    if FUSED_SEQ_ATTN:
+    if FUSED_SEQ_ATTN and R >= SEQ_ATTN_MIN_ROWS:
         # scores + key mask + softmax + value product of every (batch, head) in one launch; the probabilities reach HBM
-        # only when a backward pass will need them
+        # only when a backward pass will need them.  (Below ~1,000 residue rows its B x 4 x N/32 blocks are too few: a
+        # lone N = 256 backbone samples 2-5 % slower with it; B = 32 x N = 128 is 2 % faster, the training step 1 %.)
         A = empty((B, TH, N, N), dev) if save else None
         L.call("fd_seq_attn_fwd", qkv, key_add, o, A, 1.0 / math.sqrt(THD), B, N)
     else:

@@ -20,8 +20,8 @@ from se3_diffusion_amd.optim import FlatAdam  # noqa: E402
 
 
 def _step(dev, B, N, blocks, merge, seq_fused):
-    was = nw._PROJ_MERGE, nw.FUSED_SEQ_ATTN
-    nw._PROJ_MERGE, nw.FUSED_SEQ_ATTN = merge, seq_fused
+    was = nw._PROJ_MERGE, nw.FUSED_SEQ_ATTN, nw.SEQ_ATTN_MIN_ROWS
+    nw._PROJ_MERGE, nw.FUSED_SEQ_ATTN, nw.SEQ_ATTN_MIN_ROWS = merge, seq_fused, 0      # (0: the fused kernel at any size)
     try:
         conf = dict(fo.CONF, num_blocks=blocks)
         m = ScoreNetwork(ts.base_model_conf(blocks), diffuser=None)
@@ -40,7 +40,7 @@ def _step(dev, B, N, blocks, merge, seq_fused):
         loss.backward()
         return float(loss.detach()), {n: p.grad.detach().double().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}
     finally:
-        nw._PROJ_MERGE, nw.FUSED_SEQ_ATTN = was
+        nw._PROJ_MERGE, nw.FUSED_SEQ_ATTN, nw.SEQ_ATTN_MIN_ROWS = was
 
 
 def _compare(dev, B, N, blocks):

@@ -5,6 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r02}
 rm -rf $O; mkdir -p $O
+timeout 120 python -m pytest tests/test_switches.py -x -q -m gpu > $O/test_switches.log 2>&1
 python bench.py > $O/bench_train.json 2> $O/bench_train.err
 python bench.py --mixed-n --steps 12 --warmup 3 > $O/bench_mixed_n.json 2> $O/bench_mixed_n.err
 python bench.py --mode sample --n-res 128 --batch 1 --steps 1 --warmup 1 > $O/bench_sample_n128_b1.json 2>/dev/null
@@ -20,9 +21,11 @@ python tools/kernel_stats_md.py $O/kt/p_kernel_stats.csv "training step B=30 x N
 # sampling forward kernels
 rocprofv3 --kernel-trace --stats -d $O/ks -o p --output-format csv -- python bench.py --mode sample --n-res 128 --batch 1 --num-t 100 --steps 1 --warmup 0 --no-graph > $O/ks.log 2>&1
 python tools/kernel_stats_md.py $O/ks/p_kernel_stats.csv "sampling N=128 B=1, 100 steps, eager launches" > $O/sample_n128_b1_kernel_stats.md
+if [ -z "$LITE" ]; then   # (LITE=1: the counter passes are skipped -- kernels unchanged since the last full run)
 bash tools/pmc_edge_mlp.sh > $O/pmc_edge_mlp.txt 2>&1
 bash tools/pmc_step.sh > $O/pmc_step.txt 2>&1
 bash tools/pmc_pair_dw.sh > $O/pmc_pair_dw.txt 2>&1
+fi
 bash tools/prof_gap.sh > $O/step_gap.txt 2>&1
 find $O -name "*.csv" -size +512k -delete
 ls -la $O
