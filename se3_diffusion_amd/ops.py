@@ -169,6 +169,11 @@ def join_grad_stream():
         _SIDE["used"] = False
 
 
+# smallest K_in that sends an N_out = 128 pair-row weight gradient to the 128-row split-bf16 tile (256: the edge
+# transition's; 96 would add the edge embedder's 128 x 128 / 128 x 120 layers)
+_DW_T6_MIN_K = int(os.environ.get("FD_DW_T6_MIN_K", "256"))
+
+
 def linear_dw(dy, x, dW, M, N, K, db=None):
     """dW[N,K] += dy[M,N]^T @ x[M,K]  (reduction over the M rows; split-K); db[N] += sum_m dy[m,:] fused
     into the same kernel (row sums of the A = dy^T operand)."""
@@ -182,7 +187,7 @@ def linear_dw(dy, x, dW, M, N, K, db=None):
         # atomics stay cheap): split-bf16 kernel with the fused row sum
         tile = 4
         blocks = ((N + 255) // 256) * ((K + 127) // 128)
-    elif N == 128 and K >= 256 and M >= 65536 and K % 4 == 0 and al16:
+    elif N == 128 and K >= _DW_T6_MIN_K and M >= 65536 and K % 4 == 0 and al16:
         # N_out = 128: the 128-row shape of the split kernel (0.44 vs 0.52 ms on the 64x64 fp32 tile at K_in = 384)
         tile = 6
         blocks = (K + 127) // 128
