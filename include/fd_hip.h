@@ -209,6 +209,24 @@ typedef struct FdPairDwDesc {
 } FdPairDwDesc;
 int fd_pair_dw(const FdPairDwDesc* desc, void* stream);
 
+/* Block-diagonal form of the same kernel: three independent products over the same pair rows in one pass,
+ *   C_i[m * ldc_i + n] += sum_p A_i[p, m] * B_i[p, n]     i = 0..2, m < 128, n < b_cols_i (0 = 128)
+ * -- the weight gradients of the edge embedder's three Linear layers (autograd of score_network.py:67-86, 194-195);
+ * a_colsum_i [128] (all three or none): += sum_p A_i[p, :], the bias gradients. */
+typedef struct FdPairDwDiagDesc {
+  const float* A[3];    /* [rows, 128], row stride lda[i] */
+  long lda[3];
+  const float* B[3];    /* [rows, b_cols[i]], row stride ldb[i] */
+  long ldb[3];
+  float* C[3];          /* [128, b_cols[i]], row stride ldc[i] */
+  long ldc[3];
+  float* a_colsum[3];
+  int b_cols[3];
+  long rows;            /* B * nres * nres */
+  int blocks;           /* 0 = one persistent block per CU (256) */
+} FdPairDwDiagDesc;
+int fd_pair_dw_diag(const FdPairDwDiagDesc* desc, void* stream);
+
 /* ---- sequence-transformer self-attention, fused (torch.nn.TransformerEncoderLayer.self_attn inside IpaScore,
  * model/ipa_pytorch.py:584-593; nhead 4, d_model 320): out = softmax(scale * q k^T + key_add) v per (batch, head) in one
  * launch (se3_diffusion_amd/csrc/fd_seq_attn.hip).  qkv [B*N, 960] = in_proj output [q | k | v]; key_add [B, N] additive

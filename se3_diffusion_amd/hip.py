@@ -118,6 +118,11 @@ class FdPairDwDesc(Structure):
     _fields_ = [("item", FdPairDwItem * PAIR_DW_MAX_ITEMS), ("nitems", c_int), ("rows", c_long), ("blocks", c_int)]
 
 
+class FdPairDwDiagDesc(Structure):
+    _fields_ = [("A", c_void_p * 3), ("lda", c_long * 3), ("B", c_void_p * 3), ("ldb", c_long * 3), ("C", c_void_p * 3),
+                ("ldc", c_long * 3), ("a_colsum", c_void_p * 3), ("b_cols", c_int * 3), ("rows", c_long), ("blocks", c_int)]
+
+
 def _ptr(t, off=0):
     """Raw address of a tensor (plus an element offset)."""
     if t is None:
@@ -139,6 +144,7 @@ _SIGS = {
     "fd_edge_embed_pack": "pppps",
     "fd_edge_embed": "Ss",
     "fd_pair_dw": "Ss",
+    "fd_pair_dw_diag": "Ss",
     "fd_layernorm_fwd": "plpppplpplifs",
     "fd_layernorm_bwd": "plplpppppl" + "ipplis",
     "fd_colsum_acc": "pllips",

@@ -54,15 +54,20 @@ def check_conf(conf):
 # opt-in: the 128-wide pair-row weight gradients of the edge embedder on fd_pair_dw's 128 x 128 tile.  Measured SLOWER than
 # the 64 x 64 fp32 tiles of fd_gemm inside the step (26.5 / 26.6 / 27.5 ms with 128 / 64 / 32 blocks vs 25.9 ms): a wave has
 # 12 MFMAs per 16-row stage between barriers, and every block flushes a full 128 x 128 tile of atomics
-_EMBED_DW_GROUPED = os.environ.get("FD_EMBED_DW", "0") != "0"
-_EMBED_DW_BLOCKS = int(os.environ.get("FD_EMBED_DW_BLOCKS", "128"))
+# FD_EMBED_DW=diag: all three layers in ONE pass over the pair rows by the block-diagonal form of the kernel (fd_pair_dw_diag:
+# the 384 x 128 tile's MFMA density); built at the end of round 2 on the interpreter only -- not yet run or timed on gfx950.
+_EMBED_DW_MODE = os.environ.get("FD_EMBED_DW", "0")
+_EMBED_DW_GROUPED = _EMBED_DW_MODE not in ("0", "diag")
+_EMBED_DW_DIAG = _EMBED_DW_MODE == "diag"
+_EMBED_DW_BLOCKS = int(os.environ.get("FD_EMBED_DW_BLOCKS", "0" if _EMBED_DW_DIAG else "128"))
+_EMBED_DW_MIN_ROWS = 65536
 
 
 def _lin_grads(G, wname, bname, dy, x, M, N, K, w_off=0, w_ld=None):
     if G is None:
         return
     db = G[bname] if (bname is not None and bname in G) else None
-    if (_EMBED_DW_GROUPED and M >= 65536 and N == 128 and K <= 128 and K % 4 == 0 and w_off == 0 and w_ld is None
+    if (_EMBED_DW_GROUPED and M >= _EMBED_DW_MIN_ROWS and N == 128 and K <= 128 and K % 4 == 0 and w_off == 0 and w_ld is None
             and wname in G and not lib().exact_f32):
         # a 128-wide pair-row layer (the edge embedder's, score_network.py:67-86): the grouped split-bf16 kernel on a
         # 128 x 128 tile instead of the 64 x 64 fp32 tiles of fd_gemm
@@ -98,6 +103,19 @@ def mlp3_ln_bwd(P, G, pre, sv, dy):
     dh3 = empty((M, Cc), dev)
     ops.layernorm_bwd(mv(dy), mv(sv["h3"]), P[f"{pre}.5.weight"], sv["mean"], sv["rstd"], mv(dh3), M, Cc,
                       rowscale=sv["rowscale"], dgamma=G[f"{pre}.5.weight"], dbeta=G[f"{pre}.5.bias"])
+    if (_EMBED_DW_DIAG and G is not None and M >= _EMBED_DW_MIN_ROWS and Cc == 128 and K0 <= 128 and K0 % 4 == 0 and not lib().exact_f32
+            and all(f"{pre}.{l}.{t}" in G for l in (0, 2, 4) for t in ("weight", "bias"))):
+        # the dX chain first, then the three weight + bias gradients in one launch over the pair rows
+        dh2 = empty((M, Cc), dev)
+        ops.linear_dx(mv(dh3), mv(P[f"{pre}.4.weight"]), mv(dh2), M, Cc, Cc, gate=mv(sv["h2"]))
+        dh1 = empty((M, Cc), dev)
+        ops.linear_dx(mv(dh2), mv(P[f"{pre}.2.weight"]), mv(dh1), M, Cc, Cc, gate=mv(sv["h1"]))
+        x = sv["x"]
+        bands = [dict(A=mv(dh3), B=mv(sv["h2"]), C=(G[f"{pre}.4.weight"], 0, Cc), colsum=G[f"{pre}.4.bias"]),
+                 dict(A=mv(dh2), B=mv(sv["h1"]), C=(G[f"{pre}.2.weight"], 0, Cc), colsum=G[f"{pre}.2.bias"]),
+                 dict(A=mv(dh1), B=x, C=(G[f"{pre}.0.weight"], 0, K0), colsum=G[f"{pre}.0.bias"], b_cols=0 if K0 == 128 else K0)]
+        ops.side(lambda: ops.pair_dw_diag(bands, M, blocks=_EMBED_DW_BLOCKS), (dh3, dh2, dh1, sv["h2"], sv["h1"], x[0]), M)
+        return
     _lin_grads(G, f"{pre}.4.weight", f"{pre}.4.bias", mv(dh3), mv(sv["h2"]), M, Cc, Cc)
     dh2 = empty((M, Cc), dev)
     ops.linear_dx(mv(dh3), mv(P[f"{pre}.4.weight"]), mv(dh2), M, Cc, Cc, gate=mv(sv["h2"]))

@@ -338,6 +338,27 @@ def edge_embed(seq_idx, sc_ca, idenom, dg_lower, dg_upper, img, p, q, bias2, bia
 # ---------------------------------------------------------------------------
 # grouped pair-row weight gradients (csrc/fd_pair_dw.hip)
 # ---------------------------------------------------------------------------
+def pair_dw_diag(bands, rows, blocks=0):
+    """Three independent products over the same pair rows in one launch:  C_i[m, n] += sum_p A_i[p, m] B_i[p, n]
+    (m < 128, n < b_cols_i).  bands: three dicts with A=(tensor, offset, ld) [rows,128], B=(tensor, offset, ld)
+    [rows,b_cols], C=(tensor, offset, ld) [128,b_cols], optionally colsum=tensor [128] (all or none), b_cols=k (k % 4 == 0)."""
+    assert len(bands) == 3
+    d = hip.FdPairDwDiagDesc()
+    tens = []
+    for i, it in enumerate(bands):
+        for name, ld in (("A", "lda"), ("B", "ldb"), ("C", "ldc")):
+            ten, off, stride = it[name]
+            getattr(d, name)[i] = hip._ptr(ten, off)
+            getattr(d, ld)[i] = int(stride)
+            tens.append(ten)
+        cs = it.get("colsum")
+        d.a_colsum[i] = None if cs is None else hip._ptr(cs)
+        d.b_cols[i] = int(it.get("b_cols", 0))
+    d.rows, d.blocks = int(rows), int(blocks)
+    L = lib()
+    L._check(L.cdll.fd_pair_dw_diag(hip.ctypes.byref(d), L._stream(tens)), "fd_pair_dw_diag")
+
+
 def pair_dw(items, rows, blocks=0):
     """One launch for up to 8 tiles  C[m, n] += sum_p (A[p, m] + [m < 128] A_add[p, m]) B[p, n]  (m < 384, n < 128).
 

@@ -19,9 +19,12 @@ from se3_diffusion_amd.model.score_network import ScoreNetwork  # noqa: E402
 from se3_diffusion_amd.optim import FlatAdam  # noqa: E402
 
 
-def _step(dev, B, N, blocks, merge, seq_fused):
+def _step(dev, B, N, blocks, merge, seq_fused, embed_dw="0"):
     was = nw._PROJ_MERGE, nw.FUSED_SEQ_ATTN, nw.SEQ_ATTN_MIN_ROWS
+    was_e = nw._EMBED_DW_GROUPED, nw._EMBED_DW_DIAG, nw._EMBED_DW_MIN_ROWS, nw._EMBED_DW_BLOCKS
     nw._PROJ_MERGE, nw.FUSED_SEQ_ATTN, nw.SEQ_ATTN_MIN_ROWS = merge, seq_fused, 0      # (0: the fused kernel at any size)
+    nw._EMBED_DW_GROUPED, nw._EMBED_DW_DIAG, nw._EMBED_DW_MIN_ROWS = embed_dw == "1", embed_dw == "diag", 0
+    nw._EMBED_DW_BLOCKS = 8 if embed_dw != "0" else nw._EMBED_DW_BLOCKS
     try:
         conf = dict(fo.CONF, num_blocks=blocks)
         m = ScoreNetwork(ts.base_model_conf(blocks), diffuser=None)
@@ -41,11 +44,12 @@ def _step(dev, B, N, blocks, merge, seq_fused):
         return float(loss.detach()), {n: p.grad.detach().double().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}
     finally:
         nw._PROJ_MERGE, nw.FUSED_SEQ_ATTN, nw.SEQ_ATTN_MIN_ROWS = was
+        nw._EMBED_DW_GROUPED, nw._EMBED_DW_DIAG, nw._EMBED_DW_MIN_ROWS, nw._EMBED_DW_BLOCKS = was_e
 
 
-def _compare(dev, B, N, blocks):
+def _compare(dev, B, N, blocks, embed_dw="0"):
     l0, g0 = _step(dev, B, N, blocks, False, False)
-    l1, g1 = _step(dev, B, N, blocks, True, True)
+    l1, g1 = _step(dev, B, N, blocks, True, True, embed_dw)
     assert abs(l0 - l1) <= 2e-6 * abs(l0), (l0, l1)
     assert set(g0) == set(g1)
     worst = max(float((g1[n] - g0[n]).abs().max() / (g0[n].abs().max() + 1e-3)) for n in g0 if not n.endswith("linear_b.bias"))
@@ -57,6 +61,9 @@ def _compare(dev, B, N, blocks):
 
 def test_switches_emu(use_emu):
     _compare("cpu", B=2, N=8, blocks=1)
+    # the edge embedder's weight gradients through fd_pair_dw (128 x 128 items) / fd_pair_dw_diag (one pass): both opt-in
+    _compare("cpu", B=2, N=8, blocks=1, embed_dw="1")
+    _compare("cpu", B=2, N=8, blocks=1, embed_dw="diag")
 
 
 @pytest.mark.gpu
