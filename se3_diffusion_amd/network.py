@@ -55,7 +55,8 @@ def check_conf(conf):
 # the 64 x 64 fp32 tiles of fd_gemm inside the step (26.5 / 26.6 / 27.5 ms with 128 / 64 / 32 blocks vs 25.9 ms): a wave has
 # 12 MFMAs per 16-row stage between barriers, and every block flushes a full 128 x 128 tile of atomics
 # FD_EMBED_DW=diag: all three layers in ONE pass over the pair rows by the block-diagonal form of the kernel (fd_pair_dw_diag:
-# the 384 x 128 tile's MFMA density); built at the end of round 2 on the interpreter only -- not yet run or timed on gfx950.
+# the 384 x 128 tile's MFMA density).  Correct on gfx950, but the step is 26.1 ms with it against 25.3 without (26.3 / 26.6 on
+# 128 / 64 blocks): six operand streams per stage put the VALU split, the LDS pipe and the MFMAs all at about the same time.
 _EMBED_DW_MODE = os.environ.get("FD_EMBED_DW", "0")
 _EMBED_DW_GROUPED = _EMBED_DW_MODE not in ("0", "diag")
 _EMBED_DW_DIAG = _EMBED_DW_MODE == "diag"
