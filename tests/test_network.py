@@ -23,10 +23,10 @@ from se3_diffusion_amd import trunk  # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def relerr(a, b):
+def relerr(a, b, floor=1e-12):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
-    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    return float((a - b).abs().max() / (b.abs().max() + floor))
 
 
 def grad_mismatch(g, g_ref, tol=2e-3, floor=2e-5, kink_tol=1e-2, kink_elems=2):
@@ -53,7 +53,7 @@ def quat_align(a, b):
     return torch.cat([a[..., :4] * s, a[..., 4:]], -1)
 
 
-def run_case(dev, B, N, blocks, seed, n_pad=0, n_fixed=0, check_grad=True, tol_out=2e-4, tol_grad=2e-3):
+def run_case(dev, B, N, blocks, seed, n_pad=0, n_fixed=0, check_grad=True, tol_out=2e-4, tol_grad=2e-3, rot_floor=1e-12):
     conf = dict(fo.CONF, num_blocks=blocks)
     P = fo.synth_params(seed=seed, conf=conf)
     feats = fo.synth_feats(B, N, seed=seed, n_pad=n_pad, n_fixed=n_fixed)
@@ -66,7 +66,7 @@ def run_case(dev, B, N, blocks, seed, n_pad=0, n_fixed=0, check_grad=True, tol_o
     for k in ["psi", "trans_score", "atom37", "atom14"]:
         errs[k] = relerr(out[k], ref[k])
         assert errs[k] < tol_out, (k, errs)
-    errs["rot_score"] = relerr(out["rot_score"], ref["rot_score"])
+    errs["rot_score"] = relerr(out["rot_score"], ref["rot_score"], rot_floor)
     assert errs["rot_score"] < 1e-3, errs
     errs["rigids"] = relerr(quat_align(out["rigids"].cpu(), ref["rigids"].detach()), ref["rigids"])
     assert errs["rigids"] < tol_out, errs
@@ -91,6 +91,18 @@ def run_case(dev, B, N, blocks, seed, n_pad=0, n_fixed=0, check_grad=True, tol_o
 
 def test_forward_backward_emu_small(use_emu):
     run_case("cpu", B=1, N=8, blocks=2, seed=3)
+
+
+def test_degenerate_sizes_emu(use_emu):
+    """A single residue, two residues, an example whose residues are all padding, a backbone whose residues are all fixed
+    (motif scaffolding's fixed_mask, score_network.py:181-214): forward and every parameter gradient against the oracle."""
+    run_case("cpu", B=1, N=1, blocks=1, seed=1)
+    run_case("cpu", B=1, N=2, blocks=1, seed=2)
+    run_case("cpu", B=2, N=3, blocks=2, seed=3, n_pad=1)
+    run_case("cpu", B=2, N=5, blocks=1, seed=4, n_pad=5)
+    # all fixed: the frames do not move, the reference's relative rotation is exactly the identity and its rot_score exactly 0;
+    # here it is the fp32 round-off of R0^T R0 (|rot_score| ~ 1e-8): compared on an absolute scale
+    run_case("cpu", B=1, N=4, blocks=1, seed=5, n_fixed=4, rot_floor=1e-3)
 
 
 @pytest.mark.slow
