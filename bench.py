@@ -10,6 +10,9 @@ all-reduce + Adam.  value = residues/s over all ranks, inputs resident in HBM.
   python bench.py --mode sample --n-res 256 --batch 1 --steps 1 --warmup 1        # full 500-step sampling
   python bench.py --mixed-n                                                         # BASELINE configs[3]
 
+Before the W warm-up steps the process runs FD_BENCH_PRIME (default 4) untimed priming steps (code-object loads, allocator
+growth); the timed region is exactly K steps between two barriers.
+
 One JSON line on stdout (rank 0):
   * value / ms_per_step: the training step (the first half of BASELINE.json's metric);
   * config.sampling: the second half -- backbones/s of 500-step reverse diffusion at N = 128 / 256 / 512, from bounded
