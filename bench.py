@@ -317,8 +317,10 @@ def main():
     grads = opt
     model.accumulate_into_grad = True      # backward kernels accumulate straight into the flat all-reduce buffer
     overlap = None
-    if world > 1 and os.environ.get("FD_DP_OVERLAP", "1") != "0":
-        # the all-reduce of a parameter group starts as soon as the backward pass has issued its last gradient launch
+    if world > 1 and os.environ.get("FD_DP_OVERLAP", "0") != "0":
+        # opt-in: the all-reduce of a parameter group starts as soon as the backward pass has issued its last gradient launch.
+        # Off by default: one 69.8 MB all-reduce after the backward is <= 0.8 ms of a ~25 ms step over xGMI, and the
+        # overlapped form has only ever run over gloo (tests/test_dist.py, two processes on one GPU), never over RCCL
         overlap = fdist.OverlapAllReduce(model, opt)
         model._fd_grad_ready = overlap.ready
 

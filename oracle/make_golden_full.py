@@ -5,6 +5,9 @@ from the UNMODIFIED reference (model/score_network.py:170-215, experiments/train
     fwd_n256_b1   full depth, B=1 x N=256: outputs + gradient signatures
     fwd_n512_b1   full depth, B=1 x N=512: outputs (forward only, eval/no-grad and train mode)
     traj_n128     5 reverse-diffusion steps of Experiment.inference_fn's loop at N=128, full depth, injected noise
+    traj_n256     BASELINE configs[2]'s length: 5 reverse steps at B=1 x N=256  } produced by calling the UNMODIFIED
+    traj_n512_b2  BASELINE configs[4]'s length: 5 reverse steps at B=2 x N=512  } Experiment.inference_fn itself (a recording
+                  wrapper around diffuser.reverse snapshots the numpy RNG state to learn the draws it is about to make)
 
 Run in the build container only (needs /root/reference):  python oracle/make_golden_full.py
 The oracle (oracle/framediff_oracle.py) is pinned against the same runs (PINNING_REPORT_FULL.txt).
@@ -143,12 +146,65 @@ def main():
                             final_rigids=feats_t["rigids_t"].numpy(), final_psi=mo["psi"].numpy(), step_rigids=np.stack(per_step))
         print("trajectory golden (N=128) written", flush=True)
 
+    for name, Bt, Nt, num_t, seed in (("traj_n256", 1, 256, 5, 42), ("traj_n512_b2", 2, 512, 5, 43)):
+        if not only or name in only.split(","):
+            t0 = time.time()
+            traj_via_experiment(name, Bt, Nt, num_t, seed)
+            print(f"{name} written ({time.time() - t0:.0f} s)", flush=True)
+
+    if not report:
+        return
     with open(os.path.join(GOLD, "PINNING_REPORT_FULL.txt"), "a" if only else "w") as f:
         f.write("oracle/framediff_oracle.py vs the unmodified reference at shipped sizes (max |a-b| / max |b|)\n")
         f.write(f"torch {torch.__version__} numpy {np.__version__}\n")
         for k, v in report.items():
             f.write(f"{k}: {v}\n")
     print("wrote", GOLD)
+
+
+def traj_via_experiment(name, B, N, num_t, seed, min_t=0.01, noise_scale=0.1):
+    """The reverse loop of the reference's own Experiment.inference_fn (experiments/train_se3_diffusion.py:718-818), called
+    unmodified on the reference's ScoreNetwork / SE3Diffuser.  Recorded: the initial draws of sample_ref, the (rot, trans)
+    normal draws of every diffuser.reverse call (se3_diffuser.py:213-262: rotation first), every step's frames, the last psi."""
+    from hydra.core.hydra_config import HydraConfig
+    HydraConfig.initialized = lambda: False
+    from experiments import train_se3_diffusion as tr
+    base = rl.base_conf(CACHE, num_blocks=4)
+    conf = rl.ns(dict(
+        data=dict(min_t=min_t, num_t=num_t, samples_per_eval_length=1, num_eval_lengths=1),
+        experiment=dict(name="golden", run_id=None, use_ddp=False, use_wandb=False, warm_start=None, use_warm_start_conf=False,
+                        ckpt_dir=None, eval_dir=None, learning_rate=1e-4, num_parameters=None, batch_size=B,
+                        trans_loss_weight=1.0, rot_loss_weight=0.5, rot_loss_t_threshold=0.2, separate_rot_loss=True,
+                        trans_x0_threshold=1.0, coordinate_scaling=0.1, bb_atom_loss_weight=1.0, bb_atom_loss_t_filter=0.25,
+                        dist_mat_loss_weight=1.0, dist_mat_loss_t_filter=0.25, aux_loss_weight=0.25, noise_scale=1.0)))
+    conf.diffuser, conf.model = base.diffuser, base.model
+    exp = tr.Experiment(conf=conf)
+    assert type(exp.model).__module__ == "model.score_network" and type(exp.diffuser).__module__ == "data.se3_diffuser"
+    exp.model.load_state_dict(fo.synth_params(seed=seed, conf=dict(fo.CONF, num_blocks=4)), strict=True)
+    exp.model.eval()
+    np.random.seed(1000 + seed)
+    zr = np.random.randn(B * N, 3); ur = np.random.rand(B * N); zt = np.random.normal(size=(B * N, 3))
+    np.random.seed(1000 + seed)
+    rig_init = exp.diffuser.sample_ref(n_samples=B * N, as_tensor_7=True)["rigids_t"].reshape(B, N, 7)
+    feats = dict(res_mask=torch.ones(B, N), fixed_mask=torch.zeros(B, N), seq_idx=torch.arange(1, N + 1)[None].repeat(B, 1),
+                 torsion_angles_sin_cos=torch.zeros(B, N, 7, 2), sc_ca_t=torch.zeros(B, N, 3), rigids_t=rig_init.clone())
+    noises = []
+    orig_reverse = exp.diffuser.reverse
+
+    def recording_reverse(*a, **kw):
+        st = np.random.get_state()
+        noises.append((np.random.normal(size=(B, N, 3)), np.random.normal(size=(B, N, 3))))
+        np.random.set_state(st)
+        return orig_reverse(*a, **kw)
+    exp.diffuser.reverse = recording_reverse
+    out = exp.inference_fn(feats, num_t=num_t, min_t=min_t, aux_traj=True, noise_scale=noise_scale)
+    rt = np.asarray(out["rigid_traj"])[::-1]            # inference_fn flips the trajectory: back to init, step 1, ...
+    assert rt.shape == (num_t + 1, B, N, 7) and np.abs(rt[0] - rig_init.numpy()).max() == 0.0
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), B=B, N=N, num_t=num_t, min_t=min_t, noise_scale=noise_scale, seed=seed,
+                        blocks=4, init_randn=zr, init_rand=ur, init_normal=zt, rig_init=rig_init.numpy(),
+                        z_rot=np.stack([n[0] for n in noises]), z_trans=np.stack([n[1] for n in noises]),
+                        final_rigids=rt[-1].astype(np.float32), final_psi=out["psi_pred"][0].numpy(),
+                        step_rigids=rt[1:].astype(np.float32))
 
 
 if __name__ == "__main__":

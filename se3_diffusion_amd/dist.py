@@ -46,18 +46,28 @@ class FlatGrads:
             self.offsets.append(off)
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
+        self._dirty = False      # the buffer holds a gradient all_reduce_mean() already shipped (see rebind)
 
     def rebind(self):
         """p.grad must stay a view of the flat buffer: model.zero_grad() (set_to_none=True by default) or
         module.to() replace it, after which autograd would fill fresh tensors and the all-reduce would ship zeros.
-        A stray gradient is added into its view, then the view is bound again."""
+        A stray gradient goes into its view, then the view is bound again: it REPLACES the view's content while the
+        buffer still holds the previous step's reduced gradient (nobody called zero() on this object since: the
+        model.zero_grad()-only loop; a parameter left at .grad = None gets a zeroed view), and is added otherwise
+        (same rule as optim.FlatAdam.rebind)."""
         base = self.flat.data_ptr()
         for p, o in zip(self.params, self.offsets):
             if p.grad is None:
-                p.grad = self.flat[o:o + p.numel()].view_as(p)
+                view = self.flat[o:o + p.numel()].view_as(p)
+                if self._dirty:
+                    view.zero_()
+                p.grad = view
             elif p.grad.data_ptr() != base + 4 * o:
                 view = self.flat[o:o + p.numel()].view_as(p)
-                view.add_(p.grad.to(view.dtype))
+                if self._dirty:
+                    view.copy_(p.grad.to(view.dtype))
+                else:
+                    view.add_(p.grad.to(view.dtype))
                 p.grad = view
 
     def zero(self):
@@ -66,6 +76,7 @@ class FlatGrads:
         for p in self.params:
             if p.grad is not None and not (base <= p.grad.data_ptr() < end):
                 p.grad = None
+        self._dirty = False
         self.rebind()
 
     def all_reduce_mean(self):
@@ -73,6 +84,7 @@ class FlatGrads:
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
+        self._dirty = True
 
 
 class OverlapAllReduce:
@@ -115,6 +127,14 @@ class OverlapAllReduce:
     def ready(self, tag):
         if not (dist.is_initialized() and dist.get_world_size() > 1) or tag not in self.spans:
             return
+        if tag in self.done:
+            # a second backward before finish() (gradient accumulation) would all-reduce a chunk that already holds the
+            # cross-rank sum: refuse instead of shipping a wrong gradient
+            raise RuntimeError(f"OverlapAllReduce.ready({tag!r}) called twice before finish(): gradient accumulation over "
+                               "several backward passes is not supported by the overlapped all-reduce (use "
+                               "FlatAdam.all_reduce_mean() after the last backward instead)")
+        if not self.done and hasattr(self.flat, "rebind"):
+            self.flat.rebind()        # stray .grad tensors go into their views BEFORE anything is reduced
         from . import ops
         lo, hi = self.spans[tag]
         chunk = self.buf[lo:hi]
@@ -128,8 +148,8 @@ class OverlapAllReduce:
 
     def finish(self):
         """After backward(): reduce whatever the hook was not called for, wait, average."""
-        if hasattr(self.flat, "rebind"):
-            self.flat.rebind()
+        if not self.done and hasattr(self.flat, "rebind"):
+            self.flat.rebind()        # (hook never fired: nothing has been reduced yet, strays may still be folded in)
         if not (dist.is_initialized() and dist.get_world_size() > 1):
             return
         for tag in self.spans:
@@ -140,6 +160,8 @@ class OverlapAllReduce:
             h.wait()
         self.handles, self.done = [], set()
         self.buf.div_(dist.get_world_size())
+        if hasattr(self.flat, "_dirty"):
+            self.flat._dirty = True
 
 
 def broadcast_params(module, src=0):

@@ -94,10 +94,11 @@ def linear_dx(dy, W, dx, M, N, K, *, beta=False, gate=None, rowscale=None, alpha
         kw.update(gate=(gate[0], gate[1]), ld_gate=gate[2])
     if resid is not None:
         kw.update(resid=(resid[0], resid[1]), ld_resid=resid[2])
-    if beta and not kw and rowscale is None and N >= 1024 and _DX_SPLITK:
+    if beta and not kw and rowscale is None and N >= 1024 and _DX_SPLITK and not lib().exact_f32:
         # an accumulating dX with a long reduction and few output tiles (IPA projections: 3840 x 256 over N = 2048 / 4096
         # is 240 tiles of 64 x 64 walking 64..128 stages each): split the reduction, the partial tiles add atomically
-        # into the accumulator that is already there
+        # into the accumulator that is already there (order-nondeterministic: off in exact-fp32 mode, whose contract is a
+        # bitwise reproducible fmaf chain)
         lib().gemm(dt, wt, xt, M, K, N, (dl, 1), (wl, 1), xl, a_off=do, b_off=wo, c_off=xo, alpha=alpha,
                    ksplit=min(8, N // 512))
         return

@@ -55,12 +55,18 @@ class FlatAdam:
             p.data = view
             p.grad = self.flat_g[o:o + p.numel()].view_as(p)
         self.t = 0
+        self._dirty = False      # flat_g holds a gradient that step() / all_reduce_mean() already consumed (see rebind)
 
     def rebind(self):
         """Make every p.data / p.grad a view of the flat buffers again.  Anything that replaces them behind the
         optimiser's back -- model.zero_grad() (set_to_none=True by default), module.to() / _apply -- would otherwise
         leave flat_g all-zero while autograd fills fresh tensors: the step would run on zeros without an error.
-        A stray gradient / parameter value is copied into its view first, so nothing is lost."""
+        A stray parameter value is copied into its view.  A stray gradient follows torch's semantics for a parameter
+        whose .grad was None: the fresh tensor IS the gradient.  While the flat buffer still holds the gradient the last
+        step() / all_reduce_mean() consumed (`_dirty`: nobody called zero_grad() on THIS object since -- the
+        model.zero_grad()-only training loop), the stray gradient therefore REPLACES its view and a parameter left at
+        .grad = None gets a zeroed view; after a zero_grad() it is added (nothing stale to overwrite, and a caller may
+        have accumulated into the view before detaching it)."""
         bp, bg = self.flat_p.data_ptr(), self.flat_g.data_ptr()
         for p, o in zip(self.params, self.offsets):
             g = p.grad
@@ -72,10 +78,16 @@ class FlatAdam:
                 view.copy_(p.data)
                 p.data = view
             if p.grad is None:
-                p.grad = self.flat_g[o:o + n].view_as(p)
+                view = self.flat_g[o:o + n].view_as(p)
+                if self._dirty:
+                    view.zero_()
+                p.grad = view
             elif p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 view = self.flat_g[o:o + n].view_as(p)
-                view.add_(p.grad.to(view.dtype))
+                if self._dirty:
+                    view.copy_(p.grad.to(view.dtype))
+                else:
+                    view.add_(p.grad.to(view.dtype))
                 p.grad = view
 
     # -- gradient buffer (dist.FlatGrads interface) ------------------------------------------------------------
@@ -84,6 +96,7 @@ class FlatAdam:
         for p in self.params:          # a stray gradient (see rebind) is dropped with the rest
             if p.grad is not None and not (self.flat_g.data_ptr() <= p.grad.data_ptr() < self.flat_g.data_ptr() + 4 * self.numel):
                 p.grad = None
+        self._dirty = False
         self.rebind()
 
     zero = zero_grad
@@ -93,6 +106,7 @@ class FlatAdam:
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
             self.flat_g.div_(dist.get_world_size())
+        self._dirty = True
 
     # -- update ------------------------------------------------------------------------------------------------------
     def step(self):
@@ -101,6 +115,7 @@ class FlatAdam:
         b1, b2 = self.betas
         hip.get_lib().call("fd_adam_step", self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.numel,
                            self.lr, b1, b2, self.eps, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t)
+        self._dirty = True
 
     # -- torch.optim.Adam-compatible checkpoints (data/utils.py:353-362 saves optimizer.state_dict()) ----------------
     def state_dict(self):

@@ -210,3 +210,112 @@ def test_score_network_data_parallel_matches_single_process(emu_lib, mode):
         if err > 2e-5 * float(g.abs().max()) + 1e-7:
             bad.append((n, err, float(g.abs().max())))
     assert not bad, bad[:8]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU tier: the same check with the PRODUCT library on CUDA tensors -- two processes share device 0 (RCCL refuses two ranks
+# on one GPU, so the collective backend is gloo, which stages CUDA tensors through pinned host memory).  This is the only
+# place short of an 8-GPU node where OverlapAllReduce.ready() takes its device branch: async all-reduce of a flat-buffer
+# slice issued from the gradient side stream while the backward pass is still enqueueing kernels (dist.py).
+# ---------------------------------------------------------------------------------------------------------------------
+_GPU_B, _GPU_N, _GPU_BLOCKS = 2, 24, 2
+
+
+def _sn_setup_gpu():
+    from oracle import framediff_oracle as fo
+    from se3_diffusion_amd import train_step as ts
+    from se3_diffusion_amd.model.score_network import ScoreNetwork
+    conf = dict(fo.CONF, num_blocks=_GPU_BLOCKS)
+    model = ScoreNetwork(ts.base_model_conf(_GPU_BLOCKS), diffuser=None)
+    model.load_state_dict(fo.synth_params(seed=3, conf=conf), strict=True)
+    model = model.cuda().train()
+    batch = ts.synthetic_batch(_GPU_B, _GPU_N, "cuda", seed=9)
+    gt37, _ = ts.backbone_atoms(batch["rigids_0"], batch["torsion_angles_sin_cos"][..., 2, :])
+    return model, batch, gt37
+
+
+def _sn_loss_gpu(model, batch, gt37, sl):
+    from se3_diffusion_amd import loss as floss
+    b = {k: v[sl].contiguous() for k, v in batch.items()}
+    return floss.dsm_loss(b, model(b), gt37[sl].contiguous())
+
+
+def _sn_worker_gpu(rank, world, port, q, overlap):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)
+    from se3_diffusion_amd import dist as fdist, ops
+    from se3_diffusion_amd.optim import FlatAdam
+    fdist.init_from_env(backend="gloo")
+    try:
+        probe = torch.ones(4, device="cuda") * (rank + 1)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        assert float(probe[0]) == 3.0
+    except RuntimeError as e:                                   # a torch build whose gloo cannot take device tensors
+        q.put((rank, "unsupported: " + str(e)[:200], None))
+        return
+    model, batch, gt37 = _sn_setup_gpu()
+    opt = FlatAdam(model.parameters(), lr=1e-3, adjacent=model.flat_layout_groups())
+    model.accumulate_into_grad = True
+    hook = None
+    if overlap:
+        hook = fdist.OverlapAllReduce(model, opt)
+        model._fd_grad_ready = hook.ready
+        assert ops.grad_stream(torch.device("cuda", 0)) is not None          # the device branch of ready() is the one taken
+    sl = slice(rank, rank + 1)
+    for it in range(2):                                         # twice: the second pass reuses the bound views / streams
+        opt.zero_grad()
+        _sn_loss_gpu(model, batch, gt37, sl).backward()
+        if hook is not None:
+            assert hook.done == {"embed", "heads"} | set(range(_GPU_BLOCKS)) and len(hook.handles) == len(hook.done)
+            hook.finish()
+        else:
+            opt.all_reduce_mean()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.detach().double().cpu().numpy() for n, p in model.named_parameters()}
+        if it == 0 and hook is not None:
+            # a second backward before finish() must be refused, not silently re-reduced
+            hook.done.add("heads")
+            try:
+                hook.ready("heads")
+                raise AssertionError("ready() accepted a second call for one tag")
+            except RuntimeError:
+                pass
+            hook.done.clear()
+    opt.step()
+    torch.cuda.synchronize()
+    q.put((rank, grads, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).double().cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [True, False])
+def test_score_network_data_parallel_gpu(hip_lib, overlap):
+    """2 ranks x 1 backbone on device 0 == 1 process x 2 backbones: gradients after the (overlapped) all-reduce, replicas
+    bit-identical after FlatAdam.step()."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sn_worker_gpu, args=(r, 2, port, q, overlap)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+    if any(isinstance(g, str) for _, g, _ in got):
+        pytest.skip(f"gloo in this torch build does not take device tensors: {got[0][1]}")
+    assert all(p.exitcode == 0 for p in procs)
+    res = {r: (g, torch.tensor(w)) for r, g, w in got}
+    assert torch.equal(res[0][1], res[1][1])                    # replicas stay bit-identical after the optimiser step
+    model, batch, gt37 = _sn_setup_gpu()
+    loss = 0.5 * (_sn_loss_gpu(model, batch, gt37, slice(0, 1)) + _sn_loss_gpu(model, batch, gt37, slice(1, 2)))
+    loss.backward()
+    bad = []
+    for n, p in model.named_parameters():
+        g = (p.grad if p.grad is not None else torch.zeros_like(p)).double().cpu()
+        err = float((torch.tensor(res[0][0][n]) - g).abs().max())
+        if err > 1e-4 * float(g.abs().max()) + 1e-6:             # fp32 round-off of two summation orders (split-K atomics)
+            bad.append((n, err, float(g.abs().max())))
+    assert not bad, bad[:8]

@@ -29,12 +29,27 @@ def relerr(a, b, floor=1e-12):
     return float((a - b).abs().max() / (b.abs().max() + floor))
 
 
-def grad_mismatch(g, g_ref, tol=2e-3, floor=2e-5, kink_tol=1e-2, kink_elems=2):
+# Parameters whose gradient has entries fed by ONE (row, hidden unit) of a ReLU: the weight / bias of the Linear in front of
+# it (dW[unit, :] = sum_rows [h > 0] dh x, db[unit]).  Only these can show an isolated ReLU-kink outlier; everywhere else a
+# flipped unit is one of >= 10^4 summands and stays inside the ordinary bound.
+_RELU_FED = (r"embedding_layer\.(node|edge)_embedder\.(0|2)\.", r"node_transition_\d+\.linear_(1|2)\.",
+             r"edge_transition_\d+\.trunk\.(0|2)\.", r"seq_tfmr_\d+\.layers\.\d+\.linear1\.", r"torsion_pred\.linear_1\.")
+MAX_KINKS_PER_CASE = 5
+
+
+def relu_fed(name):
+    import re
+    return name is not None and any(re.search(p, name) for p in _RELU_FED)
+
+
+def grad_mismatch(g, g_ref, tol=2e-3, floor=2e-5, kink_tol=1e-2, kink_elems=2, name=None, kinks=None):
     """None if `g` matches `g_ref`, else (max error, scale).  Bound: tol * max|g_ref| + floor per element.  ReLU kinks: a
     hidden unit whose pre-activation lies within fp32 round-off of zero switches on / off between two correct fp32
     implementations (measured: the fused and the unfused edge embedder agree to 6e-7 relative, yet one unit of
     edge_transition_0 flips at N=24), which moves the gradient entries fed by that ONE (row, unit) by its upstream value.
-    Such isolated outliers -- at most `kink_elems` entries per tensor, each within kink_tol * max|g_ref| -- are accepted."""
+    Such isolated outliers -- at most `kink_elems` entries of a tensor, each within kink_tol * max|g_ref|, and only in the
+    parameters of a Linear that feeds a ReLU (`relu_fed(name)`; with name=None nothing is excused) -- are accepted and
+    RECORDED in `kinks` (a list the caller owns) so that a case can bound and print how often the excuse was used."""
     g = g.detach().double().cpu().reshape(-1)
     r = g_ref.detach().double().cpu().reshape(-1)
     scale = float(r.abs().max())
@@ -43,9 +58,18 @@ def grad_mismatch(g, g_ref, tol=2e-3, floor=2e-5, kink_tol=1e-2, kink_elems=2):
     n_over = int(over.sum())
     if n_over == 0:
         return None
-    if n_over <= kink_elems and float(err.max()) <= kink_tol * scale + floor:
+    if relu_fed(name) and n_over <= kink_elems and float(err.max()) <= kink_tol * scale + floor:
+        if kinks is not None:
+            kinks.append((name, n_over, float(err.max()) / (scale + 1e-30)))
         return None
     return float(err.max()), scale
+
+
+def check_kinks(kinks, what=""):
+    """At most MAX_KINKS_PER_CASE excused entries over all 282 tensors of a case; printed (pytest -s / the failure text)."""
+    n = sum(k[1] for k in kinks)
+    print(f"[relu kinks] {what}: {n} excused entries in {len(kinks)} tensors {kinks}")
+    assert n <= MAX_KINKS_PER_CASE, (what, kinks)
 
 
 def quat_align(a, b):
@@ -79,13 +103,14 @@ def run_case(dev, B, N, blocks, seed, n_pad=0, n_fixed=0, check_grad=True, tol_o
     loss.backward()
     G = {k: torch.zeros_like(v) for k, v in Pd.items()}
     trunk.backward(Pd, G, sv, {k: v.to(dev) for k, v in wts.items()})
-    bad = []
+    bad, kinks = [], []
     for k, v in Po.items():
         g_ref = v.grad if v.grad is not None else torch.zeros_like(v)
-        mm = grad_mismatch(G[k], g_ref, tol=tol_grad)
+        mm = grad_mismatch(G[k], g_ref, tol=tol_grad, name=k, kinks=kinks)
         if mm is not None:
             bad.append((k,) + mm)
     assert not bad, bad[:10]
+    check_kinks(kinks, f"B={B} N={N} blocks={blocks} seed={seed}")
     return errs
 
 
@@ -139,10 +164,11 @@ def _golden(dev, name, mode_train=True):
     wts = {k: torch.tensor(g["w_" + k]).to(dev) for k in ["rot_score", "trans_score", "rigids", "atom37", "psi"]}
     G = {k: torch.zeros_like(v) for k, v in P.items()}
     trunk.backward(P, G, sv, wts)
+    kinks = []
     for key in g.files:
         if key.startswith("grad/"):
             n = key[5:]
-            mm = grad_mismatch(G[n], torch.tensor(g[key]))
+            mm = grad_mismatch(G[n], torch.tensor(g[key]), name=n, kinks=kinks)
             assert mm is None, (n, mm)
         elif key.startswith("gsig/"):
             n = key[5:]
@@ -150,6 +176,7 @@ def _golden(dev, name, mode_train=True):
             gg = G[n].cpu().double()
             assert abs(float(gg.norm()) - l2) < 2e-3 * l2 + 1e-6, (n, float(gg.norm()), l2)
             assert abs(float(gg.sum()) - s) < 2e-3 * a + 1e-6, n
+    check_kinks(kinks, name)
 
 
 @pytest.mark.gpu

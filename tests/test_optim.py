@@ -88,3 +88,45 @@ def test_flat_adam_survives_zero_grad_emu(use_emu):
         assert float(fopt.flat_g.abs().max()) == 0.0
     for a, b in zip(ref, mine):
         assert (a.detach() - b.detach()).abs().max() < 2e-6 * (1 + a.detach().abs().max())
+
+
+def test_flat_adam_model_zero_grad_only_emu(use_emu):
+    """The training loop that zeroes ONLY through nn.Module.zero_grad() (never FlatAdam.zero_grad()): the flat buffer still
+    holds the previous step's gradient when autograd hands over fresh tensors -- they must replace it, not be added to it
+    (step() used to run on grad_prev + grad_new without an error)."""
+    ref = _params("cpu", 5)
+    mine = _params("cpu", 5)
+    topt = torch.optim.Adam(ref, lr=1e-2)
+    fopt = FlatAdam(mine, lr=1e-2)
+    g = torch.Generator().manual_seed(6)
+    for it in range(4):
+        grads = [torch.randn(*a.shape, generator=g) for a in ref]
+        for b in mine:
+            b.grad = None                          # model.zero_grad(set_to_none=True)
+        for a, b, gr in zip(ref, mine, grads):
+            a.grad = gr.clone()
+            b.grad = gr.clone()                    # autograd: a fresh tensor
+        if it == 2:
+            fopt.all_reduce_mean()                 # (single process: only the rebind) -- then step() must not fold twice
+        topt.step()
+        fopt.step()
+        for b, o, gr in zip(mine, fopt.offsets, grads):
+            assert b.grad.data_ptr() == fopt.flat_g.data_ptr() + 4 * o
+            assert torch.equal(b.grad, gr)         # this step's gradient alone
+    for a, b in zip(ref, mine):
+        assert (a.detach() - b.detach()).abs().max() < 2e-6 * (1 + a.detach().abs().max())
+
+
+def test_flat_grads_model_zero_grad_only():
+    from se3_diffusion_amd.dist import FlatGrads
+    ps = _params("cpu", 7)
+    fg = FlatGrads(ps)
+    g = torch.Generator().manual_seed(8)
+    for it in range(3):
+        grads = [torch.randn(*a.shape, generator=g) for a in ps]
+        for i, (p, gr) in enumerate(zip(ps, grads)):
+            p.grad = None if (it == 1 and i == 0) else gr.clone()     # one parameter without a gradient in step 1
+        fg.all_reduce_mean()
+        for i, (p, gr) in enumerate(zip(ps, grads)):
+            want = torch.zeros_like(gr) if (it == 1 and i == 0) else gr
+            assert torch.equal(p.grad, want), (it, i)
