@@ -118,11 +118,6 @@ class FdPairDwDesc(Structure):
     _fields_ = [("item", FdPairDwItem * PAIR_DW_MAX_ITEMS), ("nitems", c_int), ("rows", c_long), ("blocks", c_int)]
 
 
-class FdPairDwDiagDesc(Structure):
-    _fields_ = [("A", c_void_p * 3), ("lda", c_long * 3), ("B", c_void_p * 3), ("ldb", c_long * 3), ("C", c_void_p * 3),
-                ("ldc", c_long * 3), ("a_colsum", c_void_p * 3), ("b_cols", c_int * 3), ("rows", c_long), ("blocks", c_int)]
-
-
 def _ptr(t, off=0):
     """Raw address of a tensor (plus an element offset)."""
     if t is None:
@@ -144,7 +139,6 @@ _SIGS = {
     "fd_edge_embed_pack": "pppps",
     "fd_edge_embed": "Ss",
     "fd_pair_dw": "Ss",
-    "fd_pair_dw_diag": "Ss",
     "fd_layernorm_fwd": "plpppplpplifs",
     "fd_layernorm_bwd": "plplpppppl" + "ipplis",
     "fd_colsum_acc": "pllips",
@@ -163,9 +157,6 @@ _SIGS = {
     "fd_ipa_softmax_bwd": "ppppppppppiis",
     "fd_ipa_kpts_bwd": "pppppiis",
     "fd_ipa_dz_acc": "ppplis",
-    "fd_ipa_zb": "ppppls",
-    "fd_ipa_pair_fwd": "pppppppppiis",
-    "fd_ipa_pair_bwd": "pppppppppp" + "i" + "pppppp" + "iis",
     "fd_ipa_opt_fwd": "ppppls",
     "fd_ipa_opt_bwd": "pppppls",
     "fd_ipa_opair_fwd": "pppiis",

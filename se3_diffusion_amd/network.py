@@ -18,12 +18,12 @@ Stage list per trunk block b (A3 of SURVEY.md):
 from __future__ import annotations
 
 import math
-import os
 
 import torch
 
 from . import hip, ops
 from .ops import empty, zeros, mv, lib
+from .options import opts
 
 H, C, PQ, PV, CZ4 = 8, 256, 8, 12, 32
 CS, CZ = 256, 128
@@ -51,31 +51,10 @@ def check_conf(conf):
 
 
 # --------------------------------------------------------------------------- param grads
-# opt-in: the 128-wide pair-row weight gradients of the edge embedder on fd_pair_dw's 128 x 128 tile.  Measured SLOWER than
-# the 64 x 64 fp32 tiles of fd_gemm inside the step (26.5 / 26.6 / 27.5 ms with 128 / 64 / 32 blocks vs 25.9 ms): a wave has
-# 12 MFMAs per 16-row stage between barriers, and every block flushes a full 128 x 128 tile of atomics
-# FD_EMBED_DW=diag: all three layers in ONE pass over the pair rows by the block-diagonal form of the kernel (fd_pair_dw_diag:
-# the 384 x 128 tile's MFMA density).  Correct on gfx950, but the step is 26.1 ms with it against 25.3 without (26.3 / 26.6 on
-# 128 / 64 blocks): six operand streams per stage put the VALU split, the LDS pipe and the MFMAs all at about the same time.
-_EMBED_DW_MODE = os.environ.get("FD_EMBED_DW", "0")
-_EMBED_DW_GROUPED = _EMBED_DW_MODE not in ("0", "diag")
-_EMBED_DW_DIAG = _EMBED_DW_MODE == "diag"
-_EMBED_DW_BLOCKS = int(os.environ.get("FD_EMBED_DW_BLOCKS", "0" if _EMBED_DW_DIAG else "128"))
-_EMBED_DW_MIN_ROWS = 65536
-
-
 def _lin_grads(G, wname, bname, dy, x, M, N, K, w_off=0, w_ld=None):
     if G is None:
         return
     db = G[bname] if (bname is not None and bname in G) else None
-    if (_EMBED_DW_GROUPED and M >= _EMBED_DW_MIN_ROWS and N == 128 and K <= 128 and K % 4 == 0 and w_off == 0 and w_ld is None
-            and wname in G and not lib().exact_f32):
-        # a 128-wide pair-row layer (the edge embedder's, score_network.py:67-86): the grouped split-bf16 kernel on a
-        # 128 x 128 tile instead of the 64 x 64 fp32 tiles of fd_gemm
-        W = G[wname]
-        item = dict(A=dy, B=x, C=(W, 0, K), colsum=db, a_bands=1, b_cols=0 if K == 128 else K)
-        ops.side(lambda: ops.pair_dw([item], M, blocks=_EMBED_DW_BLOCKS), (dy[0], x[0]), M)
-        return
     # node-level calls run on the gradient side stream (ops.side): dy / x must not be written again by the caller
     if wname in G:
         W = G[wname]
@@ -104,19 +83,6 @@ def mlp3_ln_bwd(P, G, pre, sv, dy):
     dh3 = empty((M, Cc), dev)
     ops.layernorm_bwd(mv(dy), mv(sv["h3"]), P[f"{pre}.5.weight"], sv["mean"], sv["rstd"], mv(dh3), M, Cc,
                       rowscale=sv["rowscale"], dgamma=G[f"{pre}.5.weight"], dbeta=G[f"{pre}.5.bias"])
-    if (_EMBED_DW_DIAG and G is not None and M >= _EMBED_DW_MIN_ROWS and Cc == 128 and K0 <= 128 and K0 % 4 == 0 and not lib().exact_f32
-            and all(f"{pre}.{l}.{t}" in G for l in (0, 2, 4) for t in ("weight", "bias"))):
-        # the dX chain first, then the three weight + bias gradients in one launch over the pair rows
-        dh2 = empty((M, Cc), dev)
-        ops.linear_dx(mv(dh3), mv(P[f"{pre}.4.weight"]), mv(dh2), M, Cc, Cc, gate=mv(sv["h2"]))
-        dh1 = empty((M, Cc), dev)
-        ops.linear_dx(mv(dh2), mv(P[f"{pre}.2.weight"]), mv(dh1), M, Cc, Cc, gate=mv(sv["h1"]))
-        x = sv["x"]
-        bands = [dict(A=mv(dh3), B=mv(sv["h2"]), C=(G[f"{pre}.4.weight"], 0, Cc), colsum=G[f"{pre}.4.bias"]),
-                 dict(A=mv(dh2), B=mv(sv["h1"]), C=(G[f"{pre}.2.weight"], 0, Cc), colsum=G[f"{pre}.2.bias"]),
-                 dict(A=mv(dh1), B=x, C=(G[f"{pre}.0.weight"], 0, K0), colsum=G[f"{pre}.0.bias"], b_cols=0 if K0 == 128 else K0)]
-        ops.side(lambda: ops.pair_dw_diag(bands, M, blocks=_EMBED_DW_BLOCKS), (dh3, dh2, dh1, sv["h2"], sv["h1"], x[0]), M)
-        return
     _lin_grads(G, f"{pre}.4.weight", f"{pre}.4.bias", mv(dh3), mv(sv["h2"]), M, Cc, Cc)
     dh2 = empty((M, Cc), dev)
     ops.linear_dx(mv(dh3), mv(P[f"{pre}.4.weight"]), mv(dh2), M, Cc, Cc, gate=mv(sv["h2"]))
@@ -126,24 +92,9 @@ def mlp3_ln_bwd(P, G, pre, sv, dy):
     _lin_grads(G, f"{pre}.0.weight", f"{pre}.0.bias", mv(dh1), sv["x"], M, Cc, K0)
 
 
-_FUSED_EMBED = os.environ.get("FD_EMBED_FUSED", "1") != "0"
-# the fused IPA pair pass (fd_ipa_pair.hip: z read once, zb / dzb only in LDS) is correct and tested but measured SLOWER
-# than the launch sequence it replaces at the training size (B=30 x N=128: forward 325 vs 260 us, backward 758 vs 450 us
-# per block -- one (b, i) row per block serialises its phases at 2 blocks per CU), so it is opt-in
-FUSED_IPA_PAIR = os.environ.get("FD_IPA_PAIR_FUSED", "0") != "0"
-FUSED_IPA_ATTN = os.environ.get("FD_IPA_ATTN_FUSED", "1") != "0"   # softmax + o_pair per query row in one launch
-DZ_STREAM = os.environ.get("FD_IPA_DZ_STREAM", "1") != "0"   # dz += dzb W40 by the streaming kernel instead of fd_gemm
-ZB_STREAM = os.environ.get("FD_IPA_ZB_STREAM", "0") != "0"   # zb = z W40^T by its streaming sibling (slower: MFMA-bound)
-_ZB_DW_SIDE = os.environ.get("FD_IPA_ZB_DW_SIDE", "1") != "0"
-SEQ_ATTN_MIN_ROWS = int(os.environ.get("FD_SEQ_ATTN_MIN_ROWS", "1024"))
-KP_SOA = os.environ.get("FD_IPA_KP_SOA", "1") != "0"   # the attention kernels read the key points from a [B,8,24,N] copy
-FUSED_SEQ_ATTN = os.environ.get("FD_SEQ_ATTN_FUSED", "1") != "0"   # sequence-transformer attention in one launch (with the
-# merged projections below: 26.12 vs 26.58 ms per training step; neutral in sampling)
-
-
 def fused_embed():
     """The fused edge-embedder kernel computes in split-bf16 (fp32-accurate): off in exact-fp32 mode."""
-    return _FUSED_EMBED and not lib().exact_f32
+    return opts.fused_embed and not lib().exact_f32
 
 
 def embed_fwd(P, feats, B, N, cache=None, save=True):
@@ -197,16 +148,12 @@ def embed_fwd(P, feats, B, N, cache=None, save=True):
     return node, edge, dict(node=sv_n, edge=sv_e, emask=emask)
 
 
-_EMBED_REGEN_EARLY = os.environ.get("FD_EMBED_REGEN_EARLY", "1") != "0"
-
-
 def embed_regen_early(sv, G):
     """The [P,120] pair features the first-layer weight gradient of the fused edge embedder needs are a function of the
     inputs alone: regenerate them at the START of the backward pass on the gradient side stream (idle then) instead of on
     the main stream at its end, where nothing is left to hide the 146 us behind."""
     se = sv["edge"]
-    if (not _EMBED_REGEN_EARLY or G is None or se is None or se.get("x") is not None or "regen" not in se
-            or _EMBED_DW_GROUPED):
+    if G is None or se is None or se.get("x") is not None or "regen" not in se:
         return
     seq, tscaled, fixed, sc, B, N = se["regen"]
     Pn = B * N * N
@@ -260,12 +207,11 @@ def _adjacent_view(a, b, shape, *more):
 
 
 _PROJ = ("linear_q", "linear_kv", "linear_q_points", "linear_kv_points")
-_PROJ_MERGE = os.environ.get("FD_PROJ_MERGE", "1") != "0"   # (needs the back-to-back layout of optim.FlatAdam(adjacent=...))
 
 
 def _proj_views(P, pre):
     """([6816, 256] weight, [6816] bias) over IPA's four projections of s when they lie back to back, else None."""
-    if not _PROJ_MERGE:
+    if not opts.proj_merge:          # (needs the back-to-back layout of optim.FlatAdam(adjacent=...))
         return None
     try:
         W = _adjacent_view(*(P[f"{pre}.{n}.weight"] for n in _PROJ[:2]), (LDP, CS), *(P[f"{pre}.{n}.weight"] for n in _PROJ[2:]))
@@ -305,7 +251,7 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
         ops.linear(s, mv(P[f"{pre}.linear_kv_points.weight"]), P[f"{pre}.linear_kv_points.bias"], (proj, 6336, LDP), R, 480, CS)
     qp = empty((R, H, PQ * 3), dev); kp = empty((R, H, PQ * 3), dev); vp = empty((R, H, PV * 3), dev)
     # (the copy serves fd_ipa_attn_fwd/bwd only: the unfused softmax kernels and the fused pair pass read kp)
-    kpT = empty((B, H, PQ * 3, N), dev) if KP_SOA and FUSED_IPA_ATTN and not (FUSED_IPA_PAIR and N <= 512) else None
+    kpT = empty((B, H, PQ * 3, N), dev) if opts.fused_ipa_attn else None
     lib().call("fd_ipa_points_fwd", proj, quat, trans, qp, kp, vp, kpT, N, R, H, C, PQ, PV)
     if cache is not None and ("W40", pre) in cache:
         W40, b40 = cache[("W40", pre)]
@@ -316,46 +262,38 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
         b40 = _joined(P[f"{pre}.linear_b.bias"], P[f"{pre}.down_z.bias"], (ZB,))
         if cache is not None:
             cache[("W40", pre)] = (W40, b40)
-    fused = FUSED_IPA_PAIR and N <= 512
     A = empty((B, H, N, N), dev)
     L = lib()
     L.gemm(proj, proj, A, N, N, C, (LDP, 1), (1, LDP), N, b_off=2048, batch=B * H, bdiv=H,
            a_bs=(N * LDP, C), b_bs=(N * LDP, 2 * C), c_bs=(H * N * N, N * N), alpha=math.sqrt(1.0 / (3 * C)))
     feats = empty((R, LDF), dev)
-    zb = None
-    if fused:
-        # the pair pass in one launch: zb = W40 z + b40 stays in LDS; logits + softmax (A in place) + o_pair
-        L.call("fd_ipa_pair_fwd", A, z, W40, b40, qp, kp, P[f"{pre}.head_weights"], mask, feats, B, N)
+    zb = empty((Pn, ZB), dev)
+    ops.linear(mv(z), mv(W40), b40, mv(zb), Pn, ZB, CZ)
+    fused_attn = opts.fused_ipa_attn
+    if fused_attn:
+        # logits + softmax (A in place) + o_pair (the pair part of feats) of every query row in one launch
+        L.call("fd_ipa_attn_fwd", A, zb, qp, kp, kpT, P[f"{pre}.head_weights"], mask, feats, B, N)
     else:
-        zb = empty((Pn, ZB), dev)
-        if ZB_STREAM and W40.is_contiguous():
-            L.call("fd_ipa_zb", z, W40, b40, zb, Pn)          # (opt-in: 130 vs 119 us for the 128x32-tile GEMM at B=30 x N=128)
-        else:
-            ops.linear(mv(z), mv(W40), b40, mv(zb), Pn, ZB, CZ)
-        if FUSED_IPA_ATTN:
-            # logits + softmax (A in place) + o_pair (the pair part of feats) of every query row in one launch
-            L.call("fd_ipa_attn_fwd", A, zb, qp, kp, kpT, P[f"{pre}.head_weights"], mask, feats, B, N)
-        else:
-            L.call("fd_ipa_softmax_fwd", A, zb, qp, kp, P[f"{pre}.head_weights"], mask, B, N)
+        L.call("fd_ipa_softmax_fwd", A, zb, qp, kp, P[f"{pre}.head_weights"], mask, B, N)
     L.gemm(A, proj, feats, N, C, N, (N, 1), (LDP, 1), LDF, b_off=2048 + C, batch=B * H, bdiv=H,
            a_bs=(H * N * N, N * N), b_bs=(N * LDP, 2 * C), c_bs=(N * LDF, C))
     optg = empty((R, H, PV * 3), dev)
     L.gemm(A, vp, optg, N, PV * 3, N, (N, 1), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
            a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
     L.call("fd_ipa_opt_fwd", optg, quat, trans, feats, R)
-    if not fused and not FUSED_IPA_ATTN:
+    if not fused_attn:
         L.call("fd_ipa_opair_fwd", A, zb, feats, B, N)
     x1 = empty((R, CS), dev)
     ops.linear(mv(feats), mv(P[f"{pre}.linear_out.weight"]), P[f"{pre}.linear_out.bias"], mv(x1), R, CS, LDF,
                rowscale=mask, resid=s)
     sv = dict(s=s, z=z, quat=quat, trans=trans, mask=mask, proj=proj, qp=qp, kp=kp, kpT=kpT, vp=vp, W40=W40, b40=b40, zb=zb, A=A,
-              feats=feats, B=B, N=N)
+              feats=feats, B=B, N=N, fused_attn=fused_attn)
     return x1, sv
 
 
 def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True):
-    """dx1 [R,256] -> accumulates ds (view, +=), dz [P,128] (+= ; = when dz_accumulate is False and the fused pair pass
-    runs), dframe [R,12] (+=); param grads into G."""
+    """dx1 [R,256] -> accumulates ds (view, +=), dz [P,128] (+= ; = when dz_accumulate is False), dframe [R,12] (+=);
+    param grads into G."""
     B, N = sv["B"], sv["N"]
     R, Pn = B * N, B * N * N
     dev = dx1
@@ -388,21 +326,14 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True):
     dqp = empty((R, H, PQ * 3), dev); dkp = empty((R, H, PQ * 3), dev)
     dhw = G[f"{pre}.head_weights"] if G is not None else zeros((H,), dev)
     hw_part = empty((R, H), dev)
-    fused = zb is None
-    if fused:
-        # o_pair backward, softmax backward, dz (+)= dzb W40, dW40 / db40: one launch, dzb only in LDS
-        dW40 = zeros((ZB, CZ), dev); db40 = zeros((ZB,), dev)
-        L.call("fd_ipa_pair_bwd", A, dA, z, sv["W40"], sv["b40"], dfeats, qp, kp, P[f"{pre}.head_weights"], dz,
-               int(bool(dz_accumulate)), dqp, dkp, dhw, hw_part, dW40, db40, B, N)
+    # o_pair backward + softmax backward (dA becomes dLogits) + point / bias / head-weight grads
+    dzb = empty((Pn, ZB), dev)
+    if sv["fused_attn"]:
+        L.call("fd_ipa_attn_bwd", A, dA, zb, dfeats, qp, kp, sv["kpT"], P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw,
+               hw_part, B, N)
     else:
-        # o_pair backward + softmax backward (dA becomes dLogits) + point / bias / head-weight grads
-        dzb = empty((Pn, ZB), dev)
-        if FUSED_IPA_ATTN:
-            L.call("fd_ipa_attn_bwd", A, dA, zb, dfeats, qp, kp, sv["kpT"], P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw,
-                   hw_part, B, N)
-        else:
-            L.call("fd_ipa_opair_bwd", A, zb, dfeats, dA, dzb, B, N)
-            L.call("fd_ipa_softmax_bwd", A, dA, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, hw_part, B, N)
+        L.call("fd_ipa_opair_bwd", A, zb, dfeats, dA, dzb, B, N)
+        L.call("fd_ipa_softmax_bwd", A, dA, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, hw_part, B, N)
     sc = math.sqrt(1.0 / (3 * C))
     # dQ = sc * dL K ; dK = sc * dL^T Q
     L.gemm(dA, proj, dproj, N, C, N, (N, 1), (LDP, 1), LDP, b_off=2048, batch=B * H, bdiv=H,
@@ -410,30 +341,25 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True):
     L.gemm(dA, proj, dproj, N, C, N, (1, N), (LDP, 1), LDP, c_off=2048, batch=B * H, bdiv=H,
            a_bs=(H * N * N, N * N), b_bs=(N * LDP, C), c_bs=(N * LDP, 2 * C), alpha=sc)
     L.call("fd_ipa_points_bwd", proj, quat, dqp, dkp, dvp, dproj, dframe, R, H, C, PQ, PV)
-    # z path: dz += dzb W40 ; dW40 += dzb^T z
-    if not fused:
-        if DZ_STREAM and sv["W40"].is_contiguous():
-            L.call("fd_ipa_dz_acc", dzb, sv["W40"], dz, Pn, int(bool(dz_accumulate)))
-        else:
-            ops.linear_dx(mv(dzb), mv(sv["W40"]), mv(dz), Pn, ZB, CZ, beta=bool(dz_accumulate))
+    # z path: dz += dzb W40 (streaming kernel, W40 resident in registers) ; dW40 += dzb^T z
+    if sv["W40"].is_contiguous():
+        L.call("fd_ipa_dz_acc", dzb, sv["W40"], dz, Pn, int(bool(dz_accumulate)))
+    else:
+        ops.linear_dx(mv(dzb), mv(sv["W40"]), mv(dz), Pn, ZB, CZ, beta=bool(dz_accumulate))
     if G is not None:
         gW = _adjacent_view(G[f"{pre}.linear_b.weight"], G[f"{pre}.down_z.weight"], (ZB, CZ))
         gb = _adjacent_view(G[f"{pre}.linear_b.bias"], G[f"{pre}.down_z.bias"], (ZB,))
-        if not fused and gW is not None and gb is not None:
+        if gW is not None and gb is not None:
             # the two gradients lie back to back in the flat gradient buffer: accumulate into them as one [40, 128] matrix
             # (on the gradient side stream: 135 us per block that nothing on the dX chain waits for)
             def _grads_zb():
                 ops.linear_dw(mv(dzb), mv(z), mv(gW), Pn, ZB, CZ)
                 ops.bias_grad(mv(dzb), gb, Pn, ZB)
-            if _ZB_DW_SIDE:
-                ops.side(_grads_zb, (dzb, z), Pn)
-            else:
-                _grads_zb()
+            ops.side(_grads_zb, (dzb, z), Pn)
         else:
-            if not fused:
-                dW40 = zeros((ZB, CZ), dev); db40 = zeros((ZB,), dev)
-                ops.linear_dw(mv(dzb), mv(z), mv(dW40), Pn, ZB, CZ)
-                ops.bias_grad(mv(dzb), db40, Pn, ZB)
+            dW40 = zeros((ZB, CZ), dev); db40 = zeros((ZB,), dev)
+            ops.linear_dw(mv(dzb), mv(z), mv(dW40), Pn, ZB, CZ)
+            ops.bias_grad(mv(dzb), db40, Pn, ZB)
             G[f"{pre}.linear_b.weight"] += dW40[:H]; G[f"{pre}.down_z.weight"] += dW40[H:]
             G[f"{pre}.linear_b.bias"] += db40[:H]; G[f"{pre}.down_z.bias"] += db40[H:]
     # projections: ds += dproj_slice W ; dW += dproj_slice^T s
@@ -479,7 +405,7 @@ def tfmr_layer_fwd(P, pre, x, key_add, B, N, save=True):
     qkv = empty((R, 3 * TD), dev)
     ops.linear(mv(x), mv(P[f"{pre}.self_attn.in_proj_weight"]), P[f"{pre}.self_attn.in_proj_bias"], mv(qkv), R, 3 * TD, TD)
     o = empty((R, TD), dev)
-    if FUSED_SEQ_ATTN and R >= SEQ_ATTN_MIN_ROWS:
+    if opts.fused_seq_attn and R >= opts.seq_attn_min_rows:
         # scores + key mask + softmax + value product of every (batch, head) in one launch; the probabilities reach HBM
         # only when a backward pass will need them.  (Below ~1,000 residue rows its B x 4 x N/32 blocks are too few: a
         # lone N = 256 backbone samples 2-5 % slower with it; B = 32 x N = 128 is 2 % faster, the training step 1 %.)

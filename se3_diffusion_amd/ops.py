@@ -6,11 +6,11 @@ torch is used for memory (torch.empty / views) and nothing else.
 from __future__ import annotations
 
 import math
-import os
 
 import torch
 
 from . import hip
+from .options import opts
 
 F32 = torch.float32
 
@@ -80,9 +80,6 @@ def linear(x, W, b, out, M, N, K, *, relu=False, resid=None, rowscale=None, pair
                relu=relu, rowscale=rowscale, pair=pair, beta=beta, alpha=alpha, tile=tile, **kw)
 
 
-_DX_SPLITK = os.environ.get("FD_DX_SPLITK", "1") != "0"
-
-
 def linear_dx(dy, W, dx, M, N, K, *, beta=False, gate=None, rowscale=None, alpha=1.0, resid=None):
     """dx[M,K] (+)= dy[M,N] @ W[N,K]; optional relu gate (zero where gate<=0) on the result; resid adds a
     second matrix view (dx = resid + dy W: a residual branch without accumulating in place)."""
@@ -94,7 +91,7 @@ def linear_dx(dy, W, dx, M, N, K, *, beta=False, gate=None, rowscale=None, alpha
         kw.update(gate=(gate[0], gate[1]), ld_gate=gate[2])
     if resid is not None:
         kw.update(resid=(resid[0], resid[1]), ld_resid=resid[2])
-    if beta and not kw and rowscale is None and N >= 1024 and _DX_SPLITK and not lib().exact_f32:
+    if beta and not kw and rowscale is None and N >= 1024 and opts.dx_splitk and not lib().exact_f32:
         # an accumulating dX with a long reduction and few output tiles (IPA projections: 3840 x 256 over N = 2048 / 4096
         # is 240 tiles of 64 x 64 walking 64..128 stages each): split the reduction, the partial tiles add atomically
         # into the accumulator that is already there (order-nondeterministic: off in exact-fp32 mode, whose contract is a
@@ -110,18 +107,17 @@ def linear_dx(dy, W, dx, M, N, K, *, beta=False, gate=None, rowscale=None, alpha
 # weight-gradient side stream.  Weight gradients (dW = dY^T X) do not feed anything until the optimiser, so they
 # run on a second HIP stream beside the dX chain: the ~80 node-level ones per step (15-40 us, at most ~1 block per CU
 # each) fill idle CUs, the pair-level ones (MFMA-bound) overlap the HBM-bound LayerNorm / reduction kernels of the
-# main stream (40.5 -> 39.6 ms/step; 41.8 without the side stream).  FD_GRAD_STREAM=0 disables it,
-# FD_GRAD_STREAM_ROWS caps the row count of the launches that may move.  Contract with the callers: the operands handed to side() are never
+# main stream (40.5 -> 39.6 ms/step; 41.8 without the side stream).  options.opts.grad_stream = False disables it,
+# opts.grad_stream_max_rows caps the row count of the launches that may move.  Contract with the callers: the operands handed to side() are never
 # written again on the main stream (no in-place reuse), and they are kept alive until join_grad_stream().
 # ---------------------------------------------------------------------------
-_SIDE = {"on": os.environ.get("FD_GRAD_STREAM", "1") != "0", "streams": {}, "pending": [], "used": False}
-SIDE_MAX_ROWS = int(os.environ.get("FD_GRAD_STREAM_ROWS", str(1 << 40)))
+_SIDE = {"streams": {}, "pending": [], "used": False}
 
 
 def side(fn, tensors, rows):
     """Run fn() (weight-gradient launches reading `tensors`) on the gradient side stream."""
     t = tensors[0]
-    if not (_SIDE["on"] and t.is_cuda and rows <= SIDE_MAX_ROWS):
+    if not (opts.grad_stream and t.is_cuda and rows <= opts.grad_stream_max_rows):
         fn()
         return
     key = t.device.index
@@ -137,13 +133,13 @@ def side(fn, tensors, rows):
 
 def side_active(t, rows):
     """Would side(fn, (t, ...), rows) move fn to the gradient side stream?"""
-    return bool(_SIDE["on"] and t.is_cuda and rows <= SIDE_MAX_ROWS)
+    return bool(opts.grad_stream and t.is_cuda and rows <= opts.grad_stream_max_rows)
 
 
 def grad_stream(device):
     """The gradient side stream of `device` (None when disabled or not a GPU): work queued on it after side_sync()
     runs behind every gradient launch issued so far on either stream."""
-    if not (_SIDE["on"] and device.type == "cuda"):
+    if not (opts.grad_stream and device.type == "cuda"):
         return None
     st = _SIDE["streams"].get(device.index)
     if st is None:
@@ -155,8 +151,8 @@ def grad_stream(device):
 
 def set_grad_stream(on):
     """Enable / disable the gradient side stream; returns the previous setting."""
-    was = _SIDE["on"]
-    _SIDE["on"] = bool(on)
+    was = opts.grad_stream
+    opts.grad_stream = bool(on)
     return was
 
 
@@ -171,8 +167,8 @@ def join_grad_stream():
 
 
 # smallest K_in that sends an N_out = 128 pair-row weight gradient to the 128-row split-bf16 tile (256: the edge
-# transition's; 96 would add the edge embedder's 128 x 128 / 128 x 120 layers)
-_DW_T6_MIN_K = int(os.environ.get("FD_DW_T6_MIN_K", "256"))
+# transition's; 96 would add the edge embedder's 128 x 128 / 128 x 120 layers, measured slower)
+_DW_T6_MIN_K = 256
 
 
 def linear_dw(dy, x, dW, M, N, K, db=None):
@@ -255,9 +251,6 @@ def feature_tables(device, index_embed_size=32, num_bins=22, min_bin=1e-5, max_b
 # ---------------------------------------------------------------------------
 # fused edge transition (csrc/fd_edge_mlp.hip)
 # ---------------------------------------------------------------------------
-_EDGE_BLOCKS = int(os.environ.get("FD_EDGE_BLOCKS", "0"))   # persistent blocks of the fused edge kernels (0 = 512)
-
-
 def edge_mlp_pack(W1, W2, Wf, backward=False, out=None):
     """Pack the edge-transition weights (trunk.0 [384,384], trunk.2 [384,384], final_layer [128,384]) into the bf16-plane
     image fd_edge_mlp streams.  backward=True packs the transposes (dX chain)."""
@@ -283,7 +276,7 @@ def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, 
         setattr(d, name, None if t is None else t.data_ptr())
         if t is not None:
             tens.append(t)
-    d.rows, d.nres, d.backward, d.eps, d.blocks = int(rows), int(nres), int(bool(backward)), 1e-5, int(blocks or _EDGE_BLOCKS)
+    d.rows, d.nres, d.backward, d.eps, d.blocks = int(rows), int(nres), int(bool(backward)), 1e-5, int(blocks or opts.edge_blocks)
     d.ld_pq, d.ld_pqf = int(ld_pq), int(ld_pqf)
     L = lib()
     stream = L._stream(tens)
@@ -339,27 +332,6 @@ def edge_embed(seq_idx, sc_ca, idenom, dg_lower, dg_upper, img, p, q, bias2, bia
 # ---------------------------------------------------------------------------
 # grouped pair-row weight gradients (csrc/fd_pair_dw.hip)
 # ---------------------------------------------------------------------------
-def pair_dw_diag(bands, rows, blocks=0):
-    """Three independent products over the same pair rows in one launch:  C_i[m, n] += sum_p A_i[p, m] B_i[p, n]
-    (m < 128, n < b_cols_i).  bands: three dicts with A=(tensor, offset, ld) [rows,128], B=(tensor, offset, ld)
-    [rows,b_cols], C=(tensor, offset, ld) [128,b_cols], optionally colsum=tensor [128] (all or none), b_cols=k (k % 4 == 0)."""
-    assert len(bands) == 3
-    d = hip.FdPairDwDiagDesc()
-    tens = []
-    for i, it in enumerate(bands):
-        for name, ld in (("A", "lda"), ("B", "ldb"), ("C", "ldc")):
-            ten, off, stride = it[name]
-            getattr(d, name)[i] = hip._ptr(ten, off)
-            getattr(d, ld)[i] = int(stride)
-            tens.append(ten)
-        cs = it.get("colsum")
-        d.a_colsum[i] = None if cs is None else hip._ptr(cs)
-        d.b_cols[i] = int(it.get("b_cols", 0))
-    d.rows, d.blocks = int(rows), int(blocks)
-    L = lib()
-    L._check(L.cdll.fd_pair_dw_diag(hip.ctypes.byref(d), L._stream(tens)), "fd_pair_dw_diag")
-
-
 def pair_dw(items, rows, blocks=0):
     """One launch for up to 8 tiles  C[m, n] += sum_p (A[p, m] + [m < 128] A_add[p, m]) B[p, n]  (m < 384, n < 128).
 

@@ -1,0 +1,88 @@
+"""Launch-selection options of the hot path: ONE object, read at call time.
+
+Every alternative launch sequence the path can take (a fused kernel against the launches it replaces, the gradient side
+stream, the flat-layout fast paths) is selected by a field of ``opts``.  The fields are initialised once from ``FD_*``
+environment variables (so ``tools/ablation.sh`` keeps working) and can be flipped afterwards -- by tests, without
+re-importing anything:
+
+    from se3_diffusion_amd import options
+    with options.override(fused_edge=False, grad_stream=False):
+        ...
+
+Both settings of every field are covered by a parity test (tests/test_switches.py, tests/test_parity_full.py's exact-fp32
+mode, tests/test_seq_attn.py).  ``FD_GEMM_EXACT_F32`` is not here: it is state of the loaded library
+(``hip.FdLib.set_exact_f32``), because the C side consults it too.
+"""
+from __future__ import annotations
+
+import contextlib
+import dataclasses
+import os
+
+
+def _flag(name, default):
+    return os.environ.get(name, "1" if default else "0") not in ("", "0")
+
+
+def _int(name, default):
+    return int(os.environ.get(name, str(default)))
+
+
+@dataclasses.dataclass
+class Options:
+    # -- streams
+    grad_stream: bool = True          # FD_GRAD_STREAM: weight gradients on a second HIP stream beside the dX chain (ops.side)
+    grad_stream_max_rows: int = 1 << 40   # FD_GRAD_STREAM_ROWS: row count above which a launch stays on the main stream
+    # -- pair level
+    fused_edge: bool = True           # FD_EDGE_FUSED: fd_edge_mlp (whole edge-transition chain per pair row) vs the GEMM sequence
+    fused_embed: bool = True          # FD_EMBED_FUSED: fd_edge_embed (features generated in registers) vs fd_edge_feats + GEMMs
+    fused_embed_bwd: bool = True      # FD_EMBED_BWD_FUSED: the edge embedder's dX chain in one launch (fd_edge_embed_bwd)
+    grouped_pair_dw: bool = True      # FD_PAIR_DW: the edge transition's pair-row weight gradients in one grouped launch
+    pair_dw_blocks: int = 160         # FD_PAIR_DW_BLOCKS: blocks of fd_pair_dw when it runs beside the main stream (0 = 256)
+    edge_blocks: int = 0              # FD_EDGE_BLOCKS: persistent blocks of the fused edge kernels (0 = 512)
+    fold_node_terms: bool = True      # FD_FOLD_NODE_TERMS: sampling -- per-residue terms of an edge transition as one GEMM
+    # -- IPA
+    fused_ipa_attn: bool = True       # FD_IPA_ATTN_FUSED: logits + softmax + o_pair of a query row in one launch
+    flash_ipa: bool = True            # FD_IPA_FLASH: q k^T, softmax, a v, o_pt, o_pair in one kernel (A never in HBM)
+    proj_merge: bool = True           # FD_PROJ_MERGE: IPA's four projections of s as one GEMM over back-to-back weights
+    # -- node level
+    fused_seq_attn: bool = True       # FD_SEQ_ATTN_FUSED: sequence-transformer attention in one launch ...
+    seq_attn_min_rows: int = 1024     # FD_SEQ_ATTN_MIN_ROWS: ... from this many residue rows up
+    grouped_node_dw: bool = True      # FD_NODE_DW: the node-level weight gradients of a trunk block in one grouped launch
+    node_chain: bool = True           # FD_NODE_CHAIN: sampling (M = B*N <= 1024 rows) -- the node-level chain of a block fused
+    # -- backward bookkeeping
+    zero_arena: bool = True           # FD_ZERO_ARENA: one memset for every zero-initialised accumulator of a backward pass
+    dx_splitk: bool = True            # FD_DX_SPLITK: accumulating dX GEMMs with a long reduction split over K (atomics)
+
+    @classmethod
+    def from_env(cls):
+        return cls(
+            grad_stream=_flag("FD_GRAD_STREAM", True), grad_stream_max_rows=_int("FD_GRAD_STREAM_ROWS", 1 << 40),
+            fused_edge=_flag("FD_EDGE_FUSED", True), fused_embed=_flag("FD_EMBED_FUSED", True),
+            fused_embed_bwd=_flag("FD_EMBED_BWD_FUSED", True),
+            grouped_pair_dw=_flag("FD_PAIR_DW", True), pair_dw_blocks=_int("FD_PAIR_DW_BLOCKS", 160),
+            edge_blocks=_int("FD_EDGE_BLOCKS", 0), fold_node_terms=_flag("FD_FOLD_NODE_TERMS", True),
+            fused_ipa_attn=_flag("FD_IPA_ATTN_FUSED", True), flash_ipa=_flag("FD_IPA_FLASH", True),
+            proj_merge=_flag("FD_PROJ_MERGE", True),
+            fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),
+            grouped_node_dw=_flag("FD_NODE_DW", True), node_chain=_flag("FD_NODE_CHAIN", True),
+            zero_arena=_flag("FD_ZERO_ARENA", True), dx_splitk=_flag("FD_DX_SPLITK", True))
+
+
+opts = Options.from_env()
+
+
+@contextlib.contextmanager
+def override(**kw):
+    """Temporarily set fields of ``opts`` (unknown names raise)."""
+    was = {}
+    for k, v in kw.items():
+        if not hasattr(opts, k):
+            raise AttributeError(f"unknown option {k!r}")
+        was[k] = getattr(opts, k)
+        setattr(opts, k, v)
+    try:
+        yield opts
+    finally:
+        for k, v in was.items():
+            setattr(opts, k, v)

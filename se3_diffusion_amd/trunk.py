@@ -3,7 +3,6 @@ whole-network forward / backward drivers.  See network.py for conventions."""
 from __future__ import annotations
 
 import math
-import os
 
 import numpy as np
 import torch
@@ -13,6 +12,7 @@ from .trace import rng
 from . import network as nw
 from .network import CS, CZ, TD, H, _lin_grads
 from .ops import empty, zeros, mv, lib
+from .options import opts
 
 EH = 384  # edge-transition hidden = c_z + 2 * (c_s // 2)
 CE = 128  # edge-transition node embedding (c_s // 2)
@@ -59,18 +59,9 @@ def _edge_mlp_image(P, pre, cache, backward=False):
     return img
 
 
-_FUSED_EDGE = os.environ.get("FD_EDGE_FUSED", "1") != "0"
-
-
-_FOLD_NODE_TERMS = os.environ.get("FD_FOLD_NODE_TERMS", "1") != "0"   # sampling: per-residue terms of the edge transition in 1 GEMM
-_ZERO_ARENA = os.environ.get("FD_ZERO_ARENA", "1") != "0"   # one memset for the backward pass's zero-initialised sums
-_PAIR_DW_BLOCKS = int(os.environ.get("FD_PAIR_DW_BLOCKS", "160"))   # blocks of fd_pair_dw beside the main stream (0 = 256)
-_GROUPED_DW = os.environ.get("FD_PAIR_DW", "1") != "0"   # grouped weight-gradient kernel (fd_pair_dw) behind the fused chain
-
-
 def fused_edge():
     """The fused edge-transition kernel computes in split-bf16 (fp32-accurate): off in exact-fp32 mode."""
-    return _FUSED_EDGE and not lib().exact_f32
+    return opts.fused_edge and not lib().exact_f32
 
 
 def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None):
@@ -83,7 +74,7 @@ def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None):
     R, Pn = B * N, B * N * N
     W1, Wf = P[f"{pre}.trunk.0.weight"], P[f"{pre}.final_layer.weight"]
     kw = {}
-    if cache is not None and not save and _FOLD_NODE_TERMS:
+    if cache is not None and not save and opts.fold_node_terms:
         # static weights (sampling): the per-residue terms P1 | Q1 | Pf | Qf = [W1_i; W1_j; Wf_i; Wf_j] (W_init n3 + b_init)
         # (+ b1, b_f) are ONE GEMM of n3 against a matrix folded once per trajectory (5 launches -> 1); the fused kernel
         # reads the four column blocks of its [R, 1024] output through their row stride
@@ -170,7 +161,7 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
     # y = Wf h2 + Wf[:, :128] z + Pf_i + Qf_j (+bf inside Qf)
     gWf = G[f"{pre}.final_layer.weight"]
     fused = fused_edge()
-    grouped_dw = fused and _GROUPED_DW
+    grouped_dw = fused and opts.grouped_pair_dw
     if not grouped_dw:
         def _grads_y():
             ops.linear_dw(mv(dy), mv(h2), mv(gWf), Pn, CZ, EH)
@@ -204,7 +195,7 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
             # On the side stream the grouped kernel takes 160 of the 256 CUs (32 row ranges x 5 tiles): it then runs 1.6x longer
             # but BESIDE the ~100 latency-bound node-level / IPA launches the main stream issues next, instead of holding
             # every CU while they queue behind it (27.1 -> 26.5 ms per step; 128 / 192 / 256 blocks: 26.6 / 26.6 / 27.1)
-            nblk = _PAIR_DW_BLOCKS if ops.side_active(dh2, Pn) else 0
+            nblk = opts.pair_dw_blocks if ops.side_active(dh2, Pn) else 0
             ops.side(lambda: ops.pair_dw(items, Pn, blocks=nblk), (dh2, dh1, h1, h2, z, dy), Pn)
         else:
             _lin_grads(G, f"{pre}.trunk.2.weight", f"{pre}.trunk.2.bias", mv(dh2), mv(h1), Pn, EH, EH)
@@ -456,7 +447,7 @@ def backward(P, G, sv, d_out, on_done=None):
         raise NotImplementedError("backward is defined for the training-mode (additive) transformer mask")
     # every zero-initialised accumulator of the pass from one memset (per block: dproj [R,6816], the node-term sums of the
     # edge transition [R,2*(128+384)], du0, ds, dframe, ...: ~R * 8,700 floats)
-    with ops.zero_arena(R * (nb * 8800 + 1024) + 65536 if _ZERO_ARENA else 0, dev):
+    with ops.zero_arena(R * (nb * 8800 + 1024) + 65536 if opts.zero_arena else 0, dev):
         _backward(P, G, sv, d_out, notify)
 
 

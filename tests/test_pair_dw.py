@@ -69,46 +69,6 @@ def _run_narrow(dev, rows, seed=0, blocks=0):
         assert err < 5e-6, (name, err, rows, blocks)
 
 
-def _run_diag(dev, rows, seed=0, blocks=0, bias=True):
-    """fd_pair_dw_diag: the three weight (and bias) gradients of the edge embedder's layers in one pass over the pair rows."""
-    g = torch.Generator().manual_seed(seed)
-    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
-    dh = [rn(rows, 128) for _ in range(3)]
-    xs = [rn(rows, 128), rn(rows, 128), rn(rows, 120)]
-    gW = [rn(128, 128), rn(128, 128), rn(128, 120)]
-    gb = [rn(128) for _ in range(3)]
-    ref_W = [t.double().cpu().clone() for t in gW]
-    ref_b = [t.double().cpu().clone() for t in gb]
-    bands = [dict(A=(dh[i], 0, 128), B=(xs[i], 0, xs[i].shape[1]), C=(gW[i], 0, xs[i].shape[1]),
-                  colsum=gb[i] if bias else None, b_cols=0 if xs[i].shape[1] == 128 else xs[i].shape[1]) for i in range(3)]
-    ops.pair_dw_diag(bands, rows, blocks=blocks)
-    d = lambda t: t.double().cpu()
-    for i in range(3):
-        want = ref_W[i] + d(dh[i]).T @ d(xs[i])
-        err = float((d(gW[i]) - want).abs().max() / want.abs().max())
-        assert err < 5e-6, ("W", i, err, rows, blocks)
-        wb = ref_b[i] + (d(dh[i]).sum(0) if bias else 0)
-        errb = float((d(gb[i]) - wb).abs().max() / wb.abs().max())
-        assert errb < 5e-6, ("b", i, errb, rows, blocks)
-
-
-def test_pair_dw_diag_emu(use_emu):
-    _run_diag("cpu", rows=150, blocks=4)                    # 2-3 stages per block, ragged last stage
-    _run_diag("cpu", rows=77, seed=1, blocks=2, bias=False)
-    _run_diag("cpu", rows=16, seed=2, blocks=8)             # fewer stages than blocks
-
-
-# (fd_pair_dw_diag is an opt-in path -- slower than fd_gemm inside the step, DESIGN.md section 7 -- and its GPU test is opt-in with
-# it: passed on gfx950 at the end of round 2 with FD_TEST_PAIR_DW_DIAG=1)
-@pytest.mark.gpu
-@pytest.mark.skipif(not os.environ.get("FD_TEST_PAIR_DW_DIAG"), reason="opt-in path: FD_TEST_PAIR_DW_DIAG=1")
-def test_pair_dw_diag_gpu(hip_lib):
-    _run_diag("cuda", rows=150, blocks=4)
-    _run_diag("cuda", rows=101 * 101, seed=1)
-    _run_diag("cuda", rows=30 * 128 * 128, seed=2)
-    _run_diag("cuda", rows=30 * 128 * 128, seed=3, blocks=160, bias=False)
-
-
 def test_pair_dw_emu(use_emu):
     _run_narrow("cpu", rows=150, blocks=8)
     _run_narrow("cpu", rows=77, seed=1, blocks=16)

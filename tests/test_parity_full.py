@@ -246,11 +246,12 @@ def _trajectory(fixture, use_graph, tol_rot=1e-3, tol_trans=1e-2, tol_psi=2e-3):
     m = m.cuda().eval()
     B, N = int(T["B"]), int(T["N"])
     feats = sampler.init_feats(diff, B, N, "cuda", noise=(T["init_randn"], T["init_rand"], T["init_normal"]))
-    assert np.abs(feats["rigids_t"].cpu().numpy() - T["rig_init"]).max() < 1e-4        # same starting frames
     zr, zt = T["z_rot"], T["z_trans"]
     out = sampler.sample(m, diff, feats, num_t=int(T["num_t"]), min_t=float(T["min_t"]), noise_scale=float(T["noise_scale"]),
                          noise_fn=lambda i, shp: (zr[i], zt[i]), return_traj=True, use_graph=use_graph)
     rm = lambda q: du.quat_wxyz_to_matrix(np.asarray(q)[..., :4].astype(np.float64))
+    r0 = feats["rigids_t"].cpu().numpy()                    # same starting frames (quaternions up to sign)
+    assert np.abs(rm(r0) - rm(T["rig_init"])).max() < 1e-5 and np.abs(r0[..., 4:] - T["rig_init"][..., 4:]).max() < 1e-4
     for i, (got, ref) in enumerate(zip(out["rigid_traj"], T["step_rigids"])):
         got = got.cpu().numpy()
         assert np.abs(rm(got) - rm(ref)).max() < tol_rot, i

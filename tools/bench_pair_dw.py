@@ -49,7 +49,7 @@ def main():
                          ("fd_gemm x 4 (dW2, dW1z, dWf, dWfz)", unfused, flops_all)):
         ms = timeit(fn)
         print(f"{name:40s} rows={rows}  {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
-    # the edge embedder's three 128-wide layers: block-diagonal kernel / 128 x 128 items / fd_gemm (64 x 64 fp32 tiles)
+    # the edge embedder's three 128-wide layers: 128 x 128 items / fd_gemm (64 x 64 fp32 tiles)
     dh = [rn(rows, 128) for _ in range(3)]
     xs = [rn(rows, 128), rn(rows, 128), rn(rows, 120)]
     eW = [torch.zeros(128, x.shape[1], device=dev) for x in xs]
@@ -58,8 +58,7 @@ def main():
                   b_cols=0 if xs[i].shape[1] == 128 else xs[i].shape[1]) for i in range(3)]
     narrow = [dict(b, a_bands=1) for b in bands]
     fl_e = 2.0 * rows * 128 * (128 + 128 + 120)
-    for name, fn in (("fd_pair_dw_diag (embedder, 3 layers)", lambda: ops.pair_dw_diag(bands, rows, blocks=blocks)),
-                     ("fd_pair_dw, 3 items of 128 x 128", lambda: ops.pair_dw(narrow, rows, blocks=blocks)),
+    for name, fn in (("fd_pair_dw, 3 items of 128 x 128", lambda: ops.pair_dw(narrow, rows, blocks=blocks)),
                      ("fd_gemm x 3 (embedder)", lambda: [ops.linear_dw(mv(dh[i]), mv(xs[i]), mv(eW[i]), rows, 128, xs[i].shape[1], db=eb[i]) for i in range(3)])):
         ms = timeit(fn)
         print(f"{name:40s} rows={rows}  {ms:7.3f} ms  {fl_e / ms / 1e9:7.1f} TFLOP/s", flush=True)

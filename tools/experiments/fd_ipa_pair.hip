@@ -1,3 +1,5 @@
+// EXPERIMENT (not part of libfd_hip.so): the IPA pair pass in one kernel per direction.  Parity-tested at N <= 512 and SLOWER
+// than the launch sequence it replaces (forward 325 vs 260 us, backward 758 vs 450 us per block at B=30 x N=128, round 2).
 // Invariant Point Attention, the pair pass (model/ipa_pytorch.py:380-422 logits + softmax, :455-457 o_pair, and their
 // autograd): everything that touches the pair tensor z of one query row (b, i) in ONE kernel per direction, so z is
 // read once for BOTH linear_b (128 -> 8 bias) and down_z (128 -> 32 values) and the [P, 40] projections `zb` / `dzb`
@@ -13,7 +15,7 @@
 //            flushed with one atomic pass per block; db40 likewise.
 // W40 = [linear_b.weight (8) ; down_z.weight (32)] x 128, b40 likewise.  N <= 512.
 #include "fd_common.h"
-#include "../../include/fd_hip.h"
+#include "fd_experiments.h"
 
 namespace {
 
