@@ -34,7 +34,7 @@ def relerr(a, b, floor=1e-12):
 # flipped unit is one of >= 10^4 summands and stays inside the ordinary bound.
 _RELU_FED = (r"embedding_layer\.(node|edge)_embedder\.(0|2)\.", r"node_transition_\d+\.linear_(1|2)\.",
              r"edge_transition_\d+\.trunk\.(0|2)\.", r"seq_tfmr_\d+\.layers\.\d+\.linear1\.", r"torsion_pred\.linear_1\.")
-MAX_KINKS_PER_CASE = 5
+MAX_KINKS_PER_CASE = 6
 
 
 def relu_fed(name):
@@ -42,33 +42,37 @@ def relu_fed(name):
     return name is not None and any(re.search(p, name) for p in _RELU_FED)
 
 
-def grad_mismatch(g, g_ref, tol=2e-3, floor=2e-5, kink_tol=1e-2, kink_elems=2, name=None, kinks=None):
+def grad_mismatch(g, g_ref, tol=2e-3, floor=2e-5, kink_tol=1e-2, kink_units=2, name=None, kinks=None):
     """None if `g` matches `g_ref`, else (max error, scale).  Bound: tol * max|g_ref| + floor per element.  ReLU kinks: a
     hidden unit whose pre-activation lies within fp32 round-off of zero switches on / off between two correct fp32
     implementations (measured: the fused and the unfused edge embedder agree to 6e-7 relative, yet one unit of
-    edge_transition_0 flips at N=24), which moves the gradient entries fed by that ONE (row, unit) by its upstream value.
-    Such isolated outliers -- at most `kink_elems` entries of a tensor, each within kink_tol * max|g_ref|, and only in the
-    parameters of a Linear that feeds a ReLU (`relu_fed(name)`; with name=None nothing is excused) -- are accepted and
-    RECORDED in `kinks` (a list the caller owns) so that a case can bound and print how often the excuse was used."""
-    g = g.detach().double().cpu().reshape(-1)
-    r = g_ref.detach().double().cpu().reshape(-1)
-    scale = float(r.abs().max())
-    err = (g - r).abs()
+    edge_transition_0 flips at N=24).  A flipped (row, unit) moves dW[unit, :] of the Linear in front of the ReLU by
+    dh[row, unit] * x[row, :] -- ONE ROW of that weight (and one bias entry), nothing else.  Accepted and RECORDED in `kinks`
+    (a list the caller owns): offending entries confined to at most `kink_units` rows of a weight / entries of a bias of a
+    ReLU-fed Linear (`relu_fed(name)`; with name=None nothing is excused), each within kink_tol * max|g_ref|."""
+    g2 = g.detach().double().cpu()
+    r2 = g_ref.detach().double().cpu()
+    scale = float(r2.abs().max())
+    err = (g2 - r2).abs()
     over = err > tol * scale + floor
     n_over = int(over.sum())
     if n_over == 0:
         return None
-    if relu_fed(name) and n_over <= kink_elems and float(err.max()) <= kink_tol * scale + floor:
-        if kinks is not None:
-            kinks.append((name, n_over, float(err.max()) / (scale + 1e-30)))
-        return None
+    if relu_fed(name) and float(err.max()) <= kink_tol * scale + floor:
+        units = over.reshape(over.shape[0], -1).any(dim=1)          # rows of a weight [out, in] / entries of a bias [out]
+        n_units = int(units.sum())
+        if n_units <= kink_units:
+            if kinks is not None:
+                kinks.append((name, n_units, n_over, float(err.max()) / (scale + 1e-30)))
+            return None
     return float(err.max()), scale
 
 
 def check_kinks(kinks, what=""):
-    """At most MAX_KINKS_PER_CASE excused entries over all 282 tensors of a case; printed (pytest -s / the failure text)."""
+    """At most MAX_KINKS_PER_CASE excused hidden units (weight rows + bias entries; a flipped unit usually shows in both) over
+    all 282 tensors of a case; printed (pytest -s / the failure text)."""
     n = sum(k[1] for k in kinks)
-    print(f"[relu kinks] {what}: {n} excused entries in {len(kinks)} tensors {kinks}")
+    print(f"[relu kinks] {what}: {n} excused units in {len(kinks)} tensors (name, units, entries, rel err) {kinks}")
     assert n <= MAX_KINKS_PER_CASE, (what, kinks)
 
 
