@@ -209,6 +209,32 @@ typedef struct FdPairDwDesc {
 } FdPairDwDesc;
 int fd_pair_dw(const FdPairDwDesc* desc, void* stream);
 
+/* ---- grouped node-level weight gradients (se3_diffusion_amd/csrc/fd_group_dw.hip): autograd of the per-residue nn.Linear
+ * layers of a trunk block w.r.t. their weights and biases -- IPA's projections and linear_out (model/ipa_pytorch.py:236-301,
+ * 455-460), skip_embed / the sequence transformer / post_tfmr (:584-595,632-638), StructureModuleTransition (:169-191),
+ * the per-residue halves of EdgeTransition (:194-233), the torsion head (:560-582) and the node embedder
+ * (model/score_network.py:57-66) -- as ONE launch instead of one split-K GEMM each:
+ *   C_t[m * ldc_t + n] += sum_r A_t[r, m] * B_t[r, n]   (m < n_out_t, n < k_in_t, r < rows)      dW = dY^T X
+ *   a_colsum_t[m]      += sum_r A_t[r, m]                (optional)                                db = sum_r dY
+ * A_t = dY_t [rows, n_out_t] (row stride lda_t), B_t = X_t [rows, k_in_t] (row stride ldb_t); 16-byte aligned, strides,
+ * n_out, k_in multiples of 4.  fp32 in / out, products as 3-term bf16 splits (fp32-accurate, as fd_gemm tile 4). */
+#define FD_GROUP_DW_MAX_ITEMS 32
+typedef struct FdGroupDwItem {
+  const float* A;
+  const float* B;
+  float* C;
+  float* a_colsum;
+  int lda, ldb, ldc;
+  int n_out, k_in;
+} FdGroupDwItem;
+typedef struct FdGroupDwDesc {
+  FdGroupDwItem item[FD_GROUP_DW_MAX_ITEMS];
+  int nitems;
+  long rows;            /* B * nres */
+  int blocks;           /* 0 = two persistent blocks per CU (512) */
+} FdGroupDwDesc;
+int fd_group_dw(const FdGroupDwDesc* desc, void* stream);
+
 /* ---- sequence-transformer self-attention, fused (torch.nn.TransformerEncoderLayer.self_attn inside IpaScore,
  * model/ipa_pytorch.py:584-593; nhead 4, d_model 320): out = softmax(scale * q k^T + key_add) v per (batch, head) in one
  * launch (se3_diffusion_amd/csrc/fd_seq_attn.hip).  qkv [B*N, 960] = in_proj output [q | k | v]; key_add [B, N] additive

@@ -1,0 +1,248 @@
+// fd_group_dw: every independent weight gradient  dW_t = dY_t^T X_t  (+ bias gradient) of a trunk block's node-level
+// Linear layers in ONE launch on MI355X (gfx950) -- autograd of the nn.Linear layers of model/ipa_pytorch.py:169-191
+// (StructureModuleTransition), :236-301,455-460 (IPA projections / linear_out), :584-595,632-644 (sequence transformer,
+// skip embedding, post_tfmr), :194-233 (the per-residue halves of EdgeTransition) and the torsion / embedder heads.
+//
+//   C_t[m, n] += sum_r A_t[r, m] * B_t[r, n]        t = 0 .. nitems-1,  r over the B*N residue rows,
+//   colsum_t[m] += sum_r A_t[r, m]                   (A_t = dY_t [rows, n_out], B_t = X_t [rows, k_in])
+//
+// These are ~25 GEMMs per trunk block with tiny outputs (64 x 256 .. 6816 x 256) and a short reduction (rows = 3,840 in
+// training): as separate split-K launches of fd_gemm's 64 x 64 fp32 tile they cost 17-59 us each, ~100 launches per
+// step, and re-read their operands once per split.  Here one persistent grid walks a list of work units
+//   unit = (item, 128 x 128 output tile, row range)
+// Both operands are row-major [rows, features] fp32 activations, i.e. the reduction index is the strided one of both:
+// the staging of fd_pair_dw (float4 loads along the feature axis, fp32 -> 3 bf16 planes in registers, [panel][k][32] LDS
+// images, ds_read_b64_tr_b16 operand reads, 6 x v_mfma_f32_32x32x16_bf16 per fp32-accurate 16-row step) on a 4-wave
+// block: wave (wm, wn) owns a 64 x 64 quarter of the tile = 24 MFMAs per stage, two blocks per CU.
+// Column tails (n_out, k_in not multiples of 128) are staged as zeros and never stored.
+#include "fd_common.h"
+#include "fd_pair_dw_common.h"
+#include "../../include/fd_hip.h"
+
+namespace {
+
+constexpr int GD_THREADS = 256;
+constexpr int GD_PANELS = 8;                        // 4 of A (128 columns of dY) + 4 of B (128 columns of X)
+constexpr int GD_PLANE = GD_PANELS * DW_PSTRIDE;
+constexpr int GD_STAGE = 3 * GD_PLANE;              // 26,112 B
+constexpr int GD_RING = 2;
+static_assert(2 * GD_RING * GD_STAGE <= 160 * 1024, "LDS: two blocks per CU");
+
+struct GdUnit {
+  const float* A;
+  const float* B;
+  float* C;
+  float* colsum;     // non-null only for the n-tile 0 of an item with a bias gradient
+  long lda, ldb, ldc;
+  int ma, nb;        // valid A / B columns of this tile (1..128, multiples of 4)
+  long row0, row1;
+};
+
+__device__ __forceinline__ void gd_unit(const GdUnit& u, char* lds) {
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // staging: thread -> rows kk, kk + 8 of the 16-row stage, float4 column c4 of A and of B
+  const int kk = tid >> 5, c4 = tid & 31;
+  const int wA = (c4 >> 3) * DW_PSTRIDE + kk * 64 + (c4 & 7) * 8;
+  const int wB = (4 + (c4 >> 3)) * DW_PSTRIDE + kk * 64 + (c4 & 7) * 8;
+  const bool aok = 4 * c4 < u.ma, bok = 4 * c4 < u.nb;
+  const int ca = aok ? 4 * c4 : 0, cb = bok ? 4 * c4 : 0;
+  const float* __restrict__ A = dw_global(u.A) + u.row0 * u.lda;
+  const float* __restrict__ B = dw_global(u.B) + u.row0 * u.ldb;
+  const long nrows = u.row1 - u.row0, last = nrows - 1;
+  const int nst = (int)((nrows + DW_KS - 1) / DW_KS);
+
+  float4 rg[2][4];           // [register set][A row kk, A row kk+8, B row kk, B row kk+8]
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  auto sel = [](const float4 v, bool ok) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
+  // rows past the end of the range are read from its last row (a valid address) and replaced by zeros
+  auto load = [&](float4 (&r)[4], int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long k = (long)st * DW_KS + kk + 8 * h;
+      const bool ok = k <= last;
+      const long kc = ok ? k : last;
+      r[h] = sel(*reinterpret_cast<const float4*>(A + kc * u.lda + ca), ok && aok);
+      r[2 + h] = sel(*reinterpret_cast<const float4*>(B + kc * u.ldb + cb), ok && bok);
+    }
+  };
+  auto put = [&](float4 (&r)[4], char* dst) __attribute__((always_inline)) {
+    csum[0] += r[0].x + r[1].x; csum[1] += r[0].y + r[1].y; csum[2] += r[0].z + r[1].z; csum[3] += r[0].w + r[1].w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint2 s0, s1, s2;
+      dw_split4(r[i], s0, s1, s2);
+      const int o = ((i & 2) ? wB : wA) + (i & 1) * 8 * 64;
+      *reinterpret_cast<uint2*>(dst + o) = s0;
+      *reinterpret_cast<uint2*>(dst + GD_PLANE + o) = s1;
+      *reinterpret_cast<uint2*>(dst + 2 * GD_PLANE + o) = s2;
+    }
+  };
+
+  // MFMA side: wave (wm, wn) owns A panels 2wm, 2wm+1 and B panels 2wn, 2wn+1
+  const int i16 = lane & 15, half = (lane >> 4) & 1, kg = lane >> 5;
+  const int lofs = (8 * kg + (i16 >> 2)) * 64 + half * 32 + (i16 & 3) * 8;
+  const int a_rd = (2 * wm) * DW_PSTRIDE + lofs, b_rd = (4 + 2 * wn) * DW_PSTRIDE + lofs;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto mma = [&](const char* st) __attribute__((always_inline)) {
+    uint4 fb[2][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j][s] = dw_read8(st + b_rd + j * DW_PSTRIDE + s * GD_PLANE);
+#pragma unroll
+    for (int sa = 2; sa >= 0; --sa) {   // the small terms first
+      uint4 fa[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = dw_read8(st + a_rd + i * DW_PSTRIDE + sa * GD_PLANE);
+#pragma unroll
+      for (int sb = 2 - sa; sb >= 0; --sb)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = fd::mfma_32x32x16_bf16(fa[i], fb[j][sb], acc[i][j]);
+    }
+  };
+
+  // full stages through running pointers (no clamp / select of the row index)
+  const float* pa = A + ((long)3 * DW_KS + kk) * u.lda + ca;
+  const float* pb = B + ((long)3 * DW_KS + kk) * u.ldb + cb;
+  const long sa = (long)DW_KS * u.lda, sb = (long)DW_KS * u.ldb, ha = 8 * u.lda, hb = 8 * u.ldb;
+  auto load_fast = [&](float4 (&r)[4]) __attribute__((always_inline)) {
+    r[0] = sel(*reinterpret_cast<const float4*>(pa), aok);
+    r[1] = sel(*reinterpret_cast<const float4*>(pa + ha), aok);
+    r[2] = sel(*reinterpret_cast<const float4*>(pb), bok);
+    r[3] = sel(*reinterpret_cast<const float4*>(pb + hb), bok);
+    pa += sa;
+    pb += sb;
+  };
+
+  // pipeline: stage s lives in register set s & 1 (loaded two stages ahead) and ring slot s & 1
+  load(rg[0], 0);
+  load(rg[1], 1);
+  put(rg[0], lds);
+  load(rg[0], 2);
+  __syncthreads();
+  auto step_fast = [&](int s, float4 (&r)[4]) __attribute__((always_inline)) {
+    mma(lds + (s & 1) * GD_STAGE);
+    put(r, lds + ((s + 1) & 1) * GD_STAGE);
+    load_fast(r);
+    __syncthreads();
+  };
+  auto step = [&](int s, float4 (&r)[4]) __attribute__((always_inline)) {
+    mma(lds + (s & 1) * GD_STAGE);
+    put(r, lds + ((s + 1) & 1) * GD_STAGE);
+    load(r, s + 3);
+    __syncthreads();
+  };
+  const int nfull = (int)(nrows / DW_KS);
+  int s = 0;
+  for (; s + 5 <= nfull; s += 2) {
+    step_fast(s, rg[1]);
+    step_fast(s + 1, rg[0]);
+  }
+  for (; s < nst; s += 2) {
+    step(s, rg[1]);
+    step(s + 1, rg[0]);          // nst odd: one stage of zeros
+  }
+
+  // flush: C += acc, atomically (every row range of the tile adds its part); lanes run along n (one line per 32 lanes)
+  const int h = lane >> 5, l31 = lane & 31;
+  float* __restrict__ C = dw_global(u.C);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = (2 * wn + j) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (2 * wm + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < u.ma && n < u.nb) atomicAdd(C + (long)m * u.ldc + n, acc[i][j][r]);
+      }
+    }
+  if (u.colsum != nullptr && aok) {
+    // the put() calls of the pipeline staged every row of the range exactly once (zeros beyond it); the eight threads
+    // (kk = 0..7) that share the float4 column c4 add their parts atomically
+    float* __restrict__ cs = dw_global(u.colsum);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(cs + 4 * c4 + e, csum[e]);
+  }
+}
+
+__global__ __launch_bounds__(GD_THREADS, 2) void group_dw_kernel(FdGroupDwDesc d, int nunits, int nsplit) {
+  __shared__ __attribute__((aligned(16))) char lds[GD_RING * GD_STAGE];
+  const long nst_all = (d.rows + DW_KS - 1) / DW_KS;
+  for (int un = (int)blockIdx.x; un < nunits; un += (int)gridDim.x) {
+    // unit -> (tile, row range): consecutive units are the row ranges of one tile
+    const int tile = un / nsplit, sp = un - tile * nsplit;
+    // tile -> item (a select chain over the by-value descriptor array: a dynamic index would spill it to scratch)
+    FdGroupDwItem it = d.item[0];
+    int first = 0, acc_tiles = 0;
+#pragma unroll
+    for (int t = 0; t < FD_GROUP_DW_MAX_ITEMS; ++t) {
+      if (t < d.nitems) {
+        const int nt = ((d.item[t].n_out + 127) >> 7) * ((d.item[t].k_in + 127) >> 7);
+        if (tile >= acc_tiles) { it = d.item[t]; first = acc_tiles; }
+        acc_tiles += nt;
+      }
+    }
+    const int tn = (it.k_in + 127) >> 7;
+    const int loc = tile - first, ti = loc / tn, tj = loc - ti * tn;
+    GdUnit u;
+    u.A = it.A + 128 * ti;
+    u.B = it.B + 128 * tj;
+    u.C = it.C + (long)(128 * ti) * it.ldc + 128 * tj;
+    u.colsum = (it.a_colsum != nullptr && tj == 0) ? it.a_colsum + 128 * ti : nullptr;
+    u.lda = it.lda; u.ldb = it.ldb; u.ldc = it.ldc;
+    u.ma = it.n_out - 128 * ti < 128 ? it.n_out - 128 * ti : 128;
+    u.nb = it.k_in - 128 * tj < 128 ? it.k_in - 128 * tj : 128;
+    const long s0 = nst_all * sp / nsplit, s1 = nst_all * (sp + 1) / nsplit;
+    u.row0 = s0 * DW_KS;
+    u.row1 = (s1 * DW_KS < d.rows) ? s1 * DW_KS : d.rows;
+    if (u.row0 < u.row1) gd_unit(u, lds);
+    __syncthreads();             // the ring is reused by the next unit
+  }
+}
+
+}  // namespace
+
+extern "C" int fd_group_dw(const FdGroupDwDesc* desc, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  FD_CHECK_ARG(desc != nullptr, "fd_group_dw: null descriptor");
+  const FdGroupDwDesc& d = *desc;
+  FD_CHECK_ARG(d.nitems >= 1 && d.nitems <= FD_GROUP_DW_MAX_ITEMS, "fd_group_dw: 1..%d items", FD_GROUP_DW_MAX_ITEMS);
+  FD_CHECK_ARG(d.rows >= 0, "fd_group_dw: negative row count");
+  if (d.rows == 0) return FD_OK;
+  long tiles = 0;
+  for (int t = 0; t < d.nitems; ++t) {
+    const FdGroupDwItem& it = d.item[t];
+    FD_CHECK_ARG(it.A && it.B && it.C, "fd_group_dw: item %d: null operand", t);
+    FD_CHECK_ARG(it.n_out >= 4 && it.k_in >= 4 && (it.n_out & 3) == 0 && (it.k_in & 3) == 0,
+                 "fd_group_dw: item %d: n_out / k_in must be positive multiples of 4 (got %d, %d)", t, it.n_out, it.k_in);
+    FD_CHECK_ARG(fd_aligned16(it.A) && fd_aligned16(it.B) && (it.lda & 3) == 0 && (it.ldb & 3) == 0 && it.lda >= it.n_out &&
+                     it.ldb >= it.k_in,
+                 "fd_group_dw: item %d: A [rows,n_out] / B [rows,k_in] must be 16-byte aligned with row strides %% 4 == 0", t);
+    FD_CHECK_ARG(it.ldc >= it.k_in, "fd_group_dw: item %d: ldc too small", t);
+    tiles += (long)((it.n_out + 127) / 128) * ((it.k_in + 127) / 128);
+  }
+  int blocks = d.blocks > 0 ? d.blocks : 512;          // two blocks per CU on the 256 CUs of an MI355X
+  // row ranges per tile: enough units for ~4 per block (load balance of a persistent grid), at least 8 stages per range
+  const long nst = (d.rows + DW_KS - 1) / DW_KS;
+  long nsplit = (4L * blocks + tiles - 1) / tiles;
+  if (nsplit > nst / 8) nsplit = nst / 8;
+  if (nsplit < 1) nsplit = 1;
+  const long nunits = tiles * nsplit;
+  FD_CHECK_ARG(nunits < (1L << 30), "fd_group_dw: too many work units");
+  if (blocks > nunits) blocks = (int)nunits;
+  hipLaunchKernelGGL(group_dw_kernel, dim3(blocks), dim3(GD_THREADS), 0, stream, d, (int)nunits, (int)nsplit);
+  FD_CHECK_LAUNCH("fd_group_dw");
+  return FD_OK;
+}

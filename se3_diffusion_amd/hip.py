@@ -118,6 +118,18 @@ class FdPairDwDesc(Structure):
     _fields_ = [("item", FdPairDwItem * PAIR_DW_MAX_ITEMS), ("nitems", c_int), ("rows", c_long), ("blocks", c_int)]
 
 
+GROUP_DW_MAX_ITEMS = 32
+
+
+class FdGroupDwItem(Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("a_colsum", c_void_p),
+                ("lda", c_int), ("ldb", c_int), ("ldc", c_int), ("n_out", c_int), ("k_in", c_int)]
+
+
+class FdGroupDwDesc(Structure):
+    _fields_ = [("item", FdGroupDwItem * GROUP_DW_MAX_ITEMS), ("nitems", c_int), ("rows", c_long), ("blocks", c_int)]
+
+
 def _ptr(t, off=0):
     """Raw address of a tensor (plus an element offset)."""
     if t is None:
@@ -139,6 +151,7 @@ _SIGS = {
     "fd_edge_embed_pack": "pppps",
     "fd_edge_embed": "Ss",
     "fd_pair_dw": "Ss",
+    "fd_group_dw": "Ss",
     "fd_layernorm_fwd": "plpppplpplifs",
     "fd_layernorm_bwd": "plplpppppl" + "ipplis",
     "fd_colsum_acc": "pllips",

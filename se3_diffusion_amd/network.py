@@ -58,6 +58,8 @@ def _lin_grads(G, wname, bname, dy, x, M, N, K, w_off=0, w_ld=None):
     # node-level calls run on the gradient side stream (ops.side): dy / x must not be written again by the caller
     if wname in G:
         W = G[wname]
+        if ops.queue_dw(dy, x, (W, w_off, w_ld if w_ld is not None else W.shape[1]), M, N, K, db=db):
+            return          # part of the block's grouped launch (ops.flush_dw in trunk.backward)
         ops.side(lambda: ops.linear_dw(dy, x, (W, w_off, w_ld if w_ld is not None else W.shape[1]), M, N, K, db=db),
                  (dy[0], x[0]), M)
     elif db is not None:
@@ -368,7 +370,8 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True):
     if pv is not None and gv is not None:
         # one [6816, 256] weight, one gradient: a single dX GEMM over the 6816 columns and a single dW GEMM
         ops.linear_dx(mv(dproj), mv(pv[0]), ds, R, LDP, CS, beta=True)
-        ops.side(lambda: ops.linear_dw(mv(dproj), s, mv(gv[0]), R, LDP, CS, db=gv[1]), (dproj, s[0]), R)
+        if not ops.queue_dw(mv(dproj), s, mv(gv[0]), R, LDP, CS, db=gv[1]):
+            ops.side(lambda: ops.linear_dw(mv(dproj), s, mv(gv[0]), R, LDP, CS, db=gv[1]), (dproj, s[0]), R)
         return
     for name, off, n in (("linear_q", 0, 2048), ("linear_kv", 2048, 4096), ("linear_q_points", 6144, 192),
                          ("linear_kv_points", 6336, 480)):

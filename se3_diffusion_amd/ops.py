@@ -158,6 +158,7 @@ def set_grad_stream(on):
 
 def join_grad_stream():
     """Main stream waits for every side-stream gradient launch; releases the operand references."""
+    flush_dw()
     if _SIDE["used"]:
         cur = torch.cuda.current_stream()
         for st in _SIDE["streams"].values():
@@ -196,6 +197,71 @@ def linear_dw(dy, x, dW, M, N, K, db=None):
     ks = max(1, min((768 if tile in (4, 6) else 2304) // max(1, blocks), M // 256))
     lib().gemm(dt, xt, wt, N, K, M, (1, dl), (xl, 1), wl, a_off=do, b_off=xo, c_off=wo,
                beta=(ks == 1), ksplit=ks, tile=tile, a_rowsum=db)
+
+
+# ---------------------------------------------------------------------------
+# grouped node-level weight gradients (csrc/fd_group_dw.hip).  The backward pass QUEUES every per-residue dW = dY^T X
+# (+ bias gradient) it meets; flush_dw() executes the queue as one launch on the gradient side stream -- once per trunk
+# block instead of ~25 split-K GEMM launches.  Same contract as side(): queued operands are never written again and stay
+# referenced until join_grad_stream().
+# ---------------------------------------------------------------------------
+_DWQ = {"items": [], "tensors": [], "rows": None}
+GROUP_DW_MAX_ROWS = 16384          # residue rows (B*N <= 5e5 / N); pair-row gradients have their own kernels
+
+
+def queue_dw(dy, x, dW, M, N, K, db=None):
+    """Queue dW[N,K] += dy[M,N]^T @ x[M,K] (db[N] += column sums of dy) for the next flush_dw().  Returns False when the
+    product does not qualify (option off, exact-fp32 mode, operands not float4-addressable): the caller launches it itself."""
+    if not opts.grouped_node_dw or M > GROUP_DW_MAX_ROWS or M < 1 or lib().exact_f32:
+        return False
+    dt, do, dl = dy
+    xt, xo, xl = x
+    wt, wo, wl = dW
+    if (N % 4) or (K % 4) or (dl % 4) or (xl % 4) or (dt.data_ptr() + 4 * do) % 16 or (xt.data_ptr() + 4 * xo) % 16:
+        return False
+    if wl < K or dl < N or xl < K:
+        return False
+    q = _DWQ
+    if q["rows"] is not None and q["rows"] != M:
+        flush_dw()
+    q["rows"] = M
+    q["items"].append((hip._ptr(dt, do), hip._ptr(xt, xo), hip._ptr(wt, wo), None if db is None else hip._ptr(db),
+                       int(dl), int(xl), int(wl), int(N), int(K)))
+    q["tensors"].extend(t for t in (dt, xt, wt, db) if t is not None)
+    if len(q["items"]) == hip.GROUP_DW_MAX_ITEMS:
+        flush_dw()
+    return True
+
+
+def flush_dw(blocks=0):
+    """Launch the queued weight gradients (one fd_group_dw per <= 32 items) on the gradient side stream."""
+    q = _DWQ
+    if not q["items"]:
+        return
+    items, tens, rows = q["items"], q["tensors"], q["rows"]
+    q["items"], q["tensors"], q["rows"] = [], [], None
+    d = hip.FdGroupDwDesc()
+    for t, (a, b, c, cs, lda, ldb, ldc, n, k) in enumerate(items):
+        e = d.item[t]
+        e.A, e.B, e.C, e.a_colsum, e.lda, e.ldb, e.ldc, e.n_out, e.k_in = a, b, c, cs, lda, ldb, ldc, n, k
+    d.nitems, d.rows, d.blocks = len(items), int(rows), int(blocks)
+    L = lib()
+
+    def launch():
+        stream = L._stream(tens)
+        prof = L.gemm_profile
+        if prof is not None and L.is_device:
+            # profile record (tile code 11): 2 * rows * n_out * k_in flops per item
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+            L._check(L.cdll.fd_group_dw(hip.ctypes.byref(d), stream), "fd_group_dw")
+            e1.record(torch.cuda.current_stream())
+            prof.append((11, False, False, sum(2.0 * rows * it[7] * it[8] for it in items), e0, e1,
+                         (len(items), 128, int(rows), 1, 0, 0, 0, 1)))
+            return
+        L._check(L.cdll.fd_group_dw(hip.ctypes.byref(d), stream), "fd_group_dw")
+    side(launch, tens, rows)
 
 
 def add_view(dst, src, rows, cols, alpha=1.0):

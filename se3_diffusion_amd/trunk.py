@@ -173,7 +173,9 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
         ops.linear_dw(mv(dPf), mv(e), (gWf, CZ, EH), R, CZ, CE)
         ops.linear_dw(mv(dQf), mv(e), (gWf, CZ + CE, EH), R, CZ, CE)
         ops.bias_grad(mv(dQf), G[f"{pre}.final_layer.bias"], R, CZ)
-    ops.side(_grads_f, (dPf, dQf, e), R)
+    if not (ops.queue_dw(mv(dPf), mv(e), (gWf, CZ, EH), R, CZ, CE)
+            and ops.queue_dw(mv(dQf), mv(e), (gWf, CZ + CE, EH), R, CZ, CE, db=G[f"{pre}.final_layer.bias"])):
+        ops.side(_grads_f, (dPf, dQf, e), R)
     de = empty((R, CE), dev)
     ops.linear_dx(mv(dPf), (Wf, CZ, EH), mv(de), R, CZ, CE)
     ops.linear_dx(mv(dQf), (Wf, CZ + CE, EH), mv(de), R, CZ, CE, beta=True)
@@ -216,7 +218,9 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
         ops.linear_dw(mv(dP1), mv(e), (gW1, CZ, EH), R, EH, CE)
         ops.linear_dw(mv(dQ1), mv(e), (gW1, CZ + CE, EH), R, EH, CE)
         ops.bias_grad(mv(dQ1), G[f"{pre}.trunk.0.bias"], R, EH)
-    ops.side(_grads_1, (dP1, dQ1, e), R)
+    if not (ops.queue_dw(mv(dP1), mv(e), (gW1, CZ, EH), R, EH, CE)
+            and ops.queue_dw(mv(dQ1), mv(e), (gW1, CZ + CE, EH), R, EH, CE, db=G[f"{pre}.trunk.0.bias"])):
+        ops.side(_grads_1, (dP1, dQ1, e), R)
     ops.linear_dx(mv(dP1), (W1, CZ, EH), mv(de), R, EH, CE, beta=True)
     ops.linear_dx(mv(dQ1), (W1, CZ + CE, EH), mv(de), R, EH, CE, beta=True)
     if not fused:
@@ -460,6 +464,7 @@ def _backward(P, G, sv, d_out, notify):
     nw.embed_regen_early(sv["embed"], G)
     with rng("heads.bwd"):
         dq, dt = heads_bwd(P, G, sv["heads"], f, d_out, dnode)
+    ops.flush_dw()
     notify("heads")
     dinit = zeros((R, CS), dev)
     dz = None
@@ -495,11 +500,13 @@ def _backward(P, G, sv, d_out, notify):
         # fold the IPA frame gradients (dL/dR, dL/dt of the block's input frame) into (dq, dt)
         _frame_grad_fold(st["bb"]["quat"], dframe, dq_in, dt_in, R)
         dq, dt, dnode, dz = dq_in, dt_in, ds, dz_in
+        ops.flush_dw()           # every node-level weight gradient of the block in one launch on the side stream
         notify(b)
     # node = init_node at block 0 input; both carry gradient into the node embedder
     ops.add_view(mv(dnode), mv(dinit), R, CS)
     with rng("embed.bwd"):
         nw.embed_bwd(P, G, sv["embed"], dnode, dz)
+    ops.flush_dw()
     notify("embed")
     ops.join_grad_stream()   # the node-level weight gradients ran beside the dX chain (ops.side)
 

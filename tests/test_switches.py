@@ -2,7 +2,8 @@
 between a fused kernel and the launches it replaces is flipped here (read at call time: no re-import): IPA's four
 projections of s as ONE GEMM over back-to-back weights (proj_merge; optim.FlatAdam lays them out so), the sequence-
 transformer attention in one launch (fused_seq_attn), the per-row IPA attention kernel (fused_ipa_attn), the fused edge
-transition + grouped weight gradients (fused_edge, grouped_pair_dw), the fused edge embedder (fused_embed), the zero arena,
+transition + grouped weight gradients (fused_edge, grouped_pair_dw), the grouped node-level weight gradients
+(grouped_node_dw), the fused edge embedder (fused_embed), the zero arena,
 split-K dX, and the gradient side stream -- model/ipa_pytorch.py:340-374,584-593.
 
 Tolerance: 5e-5 of (each gradient's maximum + 1e-3) -- the merged GEMM has other tile shapes, the fused attention another
@@ -49,6 +50,7 @@ GROUPS = [
     (dict(fused_ipa_attn=False), 5e-5),
     (dict(zero_arena=False, dx_splitk=False, grad_stream=False), 5e-5),
     (dict(grouped_pair_dw=False), 5e-5),
+    (dict(grouped_node_dw=False), 5e-5),
     (dict(fused_edge=False, fused_embed=False), 2e-4),
 ]
 
@@ -84,4 +86,4 @@ def test_options_override_restores():
 @pytest.mark.gpu
 def test_switches_gpu(hip_lib):
     _compare("cuda", B=2, N=24, blocks=2)
-    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:3])
+    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:3] + GROUPS[4:5])
