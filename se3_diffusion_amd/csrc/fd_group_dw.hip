@@ -8,8 +8,9 @@
 //
 // These are ~25 GEMMs per trunk block with tiny outputs (64 x 256 .. 6816 x 256) and a short reduction (rows = 3,840 in
 // training): as separate split-K launches of fd_gemm's 64 x 64 fp32 tile they cost 17-59 us each, ~100 launches per
-// step, and re-read their operands once per split.  Here one persistent grid walks a list of work units
-//   unit = (item, 128 x 128 output tile, row range)
+// step, and re-read their operands once per split.  Here one persistent grid shares the sequence of
+//   (item, 128 x 128 output tile, 16-row stage)
+// in equal pieces (a block's piece spans one or two tiles: one prologue and one atomic flush each)
 // Both operands are row-major [rows, features] fp32 activations, i.e. the reduction index is the strided one of both:
 // the staging of fd_pair_dw (float4 loads along the feature axis, fp32 -> 3 bf16 planes in registers, [panel][k][32] LDS
 // images, ds_read_b64_tr_b16 operand reads, 6 x v_mfma_f32_32x32x16_bf16 per fp32-accurate 16-row step) on a 4-wave
@@ -38,7 +39,7 @@ struct GdUnit {
   long row0, row1;
 };
 
-__device__ __forceinline__ void gd_unit(const GdUnit& u, char* lds) {
+__device__ __forceinline__ void gd_unit(const GdUnit& u, char* lds, const int dbg) {
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // staging: thread -> rows kk, kk + 8 of the 16-row stage, float4 column c4 of A and of B
@@ -131,15 +132,16 @@ __device__ __forceinline__ void gd_unit(const GdUnit& u, char* lds) {
   put(rg[0], lds);
   load(rg[0], 2);
   __syncthreads();
+  // dbg (FD_GROUP_DW_DEBUG, measurements only): 1 = no flush, 2 = no MFMA phase, 4 = no split / LDS writes
   auto step_fast = [&](int s, float4 (&r)[4]) __attribute__((always_inline)) {
-    mma(lds + (s & 1) * GD_STAGE);
-    put(r, lds + ((s + 1) & 1) * GD_STAGE);
+    if (!(dbg & 2)) mma(lds + (s & 1) * GD_STAGE);
+    if (!(dbg & 4)) put(r, lds + ((s + 1) & 1) * GD_STAGE);
     load_fast(r);
     __syncthreads();
   };
   auto step = [&](int s, float4 (&r)[4]) __attribute__((always_inline)) {
-    mma(lds + (s & 1) * GD_STAGE);
-    put(r, lds + ((s + 1) & 1) * GD_STAGE);
+    if (!(dbg & 2)) mma(lds + (s & 1) * GD_STAGE);
+    if (!(dbg & 4)) put(r, lds + ((s + 1) & 1) * GD_STAGE);
     load(r, s + 3);
     __syncthreads();
   };
@@ -155,6 +157,18 @@ __device__ __forceinline__ void gd_unit(const GdUnit& u, char* lds) {
   }
 
   // flush: C += acc, atomically (every row range of the tile adds its part); lanes run along n (one line per 32 lanes)
+  if (dbg & 1) {
+    // keep the results alive without the atomics
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 1.2345e-30f) dw_global(u.C)[0] = t + rg[0][0].x + rg[1][1].y + csum[0];
+    return;
+  }
   const int h = lane >> 5, l31 = lane & 31;
   float* __restrict__ C = dw_global(u.C);
 #pragma unroll
@@ -177,12 +191,24 @@ __device__ __forceinline__ void gd_unit(const GdUnit& u, char* lds) {
   }
 }
 
-__global__ __launch_bounds__(GD_THREADS, 2) void group_dw_kernel(FdGroupDwDesc d, int nunits, int nsplit) {
+__global__ __launch_bounds__(GD_THREADS, 2) void group_dw_kernel(FdGroupDwDesc d, int ntiles, int dbg) {
   __shared__ __attribute__((aligned(16))) char lds[GD_RING * GD_STAGE];
-  const long nst_all = (d.rows + DW_KS - 1) / DW_KS;
-  for (int un = (int)blockIdx.x; un < nunits; un += (int)gridDim.x) {
-    // unit -> (tile, row range): consecutive units are the row ranges of one tile
-    const int tile = un / nsplit, sp = un - tile * nsplit;
+  // The work is the (tile, 16-row stage) sequence, tile-major; block b takes the b-th of gridDim.x equal pieces of it and
+  // walks it tile by tile: every block multiplies the same number of stages (+-1) whatever the mix of item sizes, and
+  // flushes at most (piece length / stages per tile) + 2 partial tiles.
+  const long nst = (d.rows + DW_KS - 1) / DW_KS;
+  const long total = (long)ntiles * nst;
+  // logical piece order XCD-major (block b runs on XCD b % 8): neighbouring pieces -- the n-tiles of one dY panel, the
+  // m-tiles that share an X panel -- run on ONE XCD at about the same time, so a panel is fetched from HBM once and
+  // served to its other tiles by that XCD's L2 (measured: the launch moves 1.1 GB through the CUs for ~0.2 GB of operands)
+  const long piece = fd_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+  long lo = total * piece / gridDim.x;
+  const long hi = total * (piece + 1) / gridDim.x;
+  while (lo < hi) {
+    const int tile = (int)(lo / nst);
+    const long s0 = lo - (long)tile * nst;
+    const long s1 = (hi - lo < nst - s0) ? s0 + (hi - lo) : nst;
+    lo += s1 - s0;
     // tile -> item (a select chain over the by-value descriptor array: a dynamic index would spill it to scratch)
     FdGroupDwItem it = d.item[0];
     int first = 0, acc_tiles = 0;
@@ -204,11 +230,10 @@ __global__ __launch_bounds__(GD_THREADS, 2) void group_dw_kernel(FdGroupDwDesc d
     u.lda = it.lda; u.ldb = it.ldb; u.ldc = it.ldc;
     u.ma = it.n_out - 128 * ti < 128 ? it.n_out - 128 * ti : 128;
     u.nb = it.k_in - 128 * tj < 128 ? it.k_in - 128 * tj : 128;
-    const long s0 = nst_all * sp / nsplit, s1 = nst_all * (sp + 1) / nsplit;
     u.row0 = s0 * DW_KS;
     u.row1 = (s1 * DW_KS < d.rows) ? s1 * DW_KS : d.rows;
-    if (u.row0 < u.row1) gd_unit(u, lds);
-    __syncthreads();             // the ring is reused by the next unit
+    gd_unit(u, lds, dbg);
+    __syncthreads();             // the ring is reused by the next piece
   }
 }
 
@@ -234,15 +259,14 @@ extern "C" int fd_group_dw(const FdGroupDwDesc* desc, void* stream_) {
     tiles += (long)((it.n_out + 127) / 128) * ((it.k_in + 127) / 128);
   }
   int blocks = d.blocks > 0 ? d.blocks : 512;          // two blocks per CU on the 256 CUs of an MI355X
-  // row ranges per tile: enough units for ~4 per block (load balance of a persistent grid), at least 8 stages per range
+  // at least 8 stages per block: below that the prologue and the flush of a piece cost more than its stages
   const long nst = (d.rows + DW_KS - 1) / DW_KS;
-  long nsplit = (4L * blocks + tiles - 1) / tiles;
-  if (nsplit > nst / 8) nsplit = nst / 8;
-  if (nsplit < 1) nsplit = 1;
-  const long nunits = tiles * nsplit;
-  FD_CHECK_ARG(nunits < (1L << 30), "fd_group_dw: too many work units");
-  if (blocks > nunits) blocks = (int)nunits;
-  hipLaunchKernelGGL(group_dw_kernel, dim3(blocks), dim3(GD_THREADS), 0, stream, d, (int)nunits, (int)nsplit);
+  const long total = tiles * nst;
+  FD_CHECK_ARG(tiles < (1L << 24), "fd_group_dw: too many tiles");
+  if ((long)blocks > (total + 7) / 8) blocks = (int)((total + 7) / 8);
+  if (blocks < 1) blocks = 1;
+  static const int dbg = getenv("FD_GROUP_DW_DEBUG") ? atoi(getenv("FD_GROUP_DW_DEBUG")) : 0;
+  hipLaunchKernelGGL(group_dw_kernel, dim3(blocks), dim3(GD_THREADS), 0, stream, d, (int)tiles, dbg);
   FD_CHECK_LAUNCH("fd_group_dw");
   return FD_OK;
 }

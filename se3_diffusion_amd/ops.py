@@ -244,7 +244,7 @@ def flush_dw(blocks=0):
     for t, (a, b, c, cs, lda, ldb, ldc, n, k) in enumerate(items):
         e = d.item[t]
         e.A, e.B, e.C, e.a_colsum, e.lda, e.ldb, e.ldc, e.n_out, e.k_in = a, b, c, cs, lda, ldb, ldc, n, k
-    d.nitems, d.rows, d.blocks = len(items), int(rows), int(blocks)
+    d.nitems, d.rows, d.blocks = len(items), int(rows), int(blocks or opts.node_dw_blocks)
     L = lib()
 
     def launch():

@@ -49,6 +49,7 @@ class Options:
     fused_seq_attn: bool = True       # FD_SEQ_ATTN_FUSED: sequence-transformer attention in one launch ...
     seq_attn_min_rows: int = 1024     # FD_SEQ_ATTN_MIN_ROWS: ... from this many residue rows up
     grouped_node_dw: bool = True      # FD_NODE_DW: the node-level weight gradients of a trunk block in one grouped launch
+    node_dw_blocks: int = 0           # FD_NODE_DW_BLOCKS: its persistent blocks (0 = 512: two per CU)
     node_chain: bool = True           # FD_NODE_CHAIN: sampling (M = B*N <= 1024 rows) -- the node-level chain of a block fused
     # -- backward bookkeeping
     zero_arena: bool = True           # FD_ZERO_ARENA: one memset for every zero-initialised accumulator of a backward pass
@@ -65,7 +66,8 @@ class Options:
             fused_ipa_attn=_flag("FD_IPA_ATTN_FUSED", True), flash_ipa=_flag("FD_IPA_FLASH", True),
             proj_merge=_flag("FD_PROJ_MERGE", True),
             fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),
-            grouped_node_dw=_flag("FD_NODE_DW", True), node_chain=_flag("FD_NODE_CHAIN", True),
+            grouped_node_dw=_flag("FD_NODE_DW", True), node_dw_blocks=_int("FD_NODE_DW_BLOCKS", 0),
+            node_chain=_flag("FD_NODE_CHAIN", True),
             zero_arena=_flag("FD_ZERO_ARENA", True), dx_splitk=_flag("FD_DX_SPLITK", True))
 
 
