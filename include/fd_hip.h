@@ -181,6 +181,32 @@ typedef struct FdEdgeEmbedDesc {
 } FdEdgeEmbedDesc;
 int fd_edge_embed(const FdEdgeEmbedDesc* desc, void* stream);
 
+/* Backward dX chain of the same MLP (autograd of model/score_network.py:67-86,194-195 w.r.t. its hidden activations) in one
+ * launch (se3_diffusion_amd/csrc/fd_edge_embed_bwd.hip): LayerNorm backward (dgamma / dbeta accumulated), dh2 = [h2 > 0]
+ * (dh3 W4), dh1 = [h1 > 0] (dh2 W2).  h1, h2, h3, mean, rstd are fd_edge_embed's saves; dh3 / dh2 / dh1 [rows,128] are the
+ * operands of the weight gradients (fd_group_dw).  Image: fd_edge_embed_bwd_pack(W2 = edge_embedder.2.weight, W4 = .4.weight). */
+#define FD_EDGE_EMBED_BWD_IMAGE_BYTES (16 * 12288)
+int fd_edge_embed_bwd_pack(const float* W2, const float* W4, void* image, void* stream);
+typedef struct FdEdgeEmbedBwdDesc {
+  const float* dy;        /* [rows,128] gradient of the embedder output */
+  const float* h3;        /* [rows,128] pre-LayerNorm save */
+  const float* mean;      /* [rows] */
+  const float* rstd;      /* [rows] */
+  const float* gamma;     /* LayerNorm weight [128] */
+  const float* rowscale;  /* optional [rows] pair mask */
+  const float* h2;        /* [rows,128] post-ReLU layer 2 */
+  const float* h1;        /* [rows,128] post-ReLU layer 1 */
+  const void* img;
+  float* dh3;             /* [rows,128] out */
+  float* dh2;
+  float* dh1;
+  float* dgamma;          /* optional [128], accumulated */
+  float* dbeta;           /* optional [128], accumulated */
+  long rows;
+  int blocks;             /* 0 = two persistent blocks per CU (512) */
+} FdEdgeEmbedBwdDesc;
+int fd_edge_embed_bwd(const FdEdgeEmbedBwdDesc* desc, void* stream);
+
 /* ---- weight gradients of the pair-row MLPs, grouped (autograd of the Linear layers of EdgeTransition,
  * model/ipa_pytorch.py:194-233: dW = dY^T X with the B*N*N pair rows as the reduction index) ----
  * One launch for up to FD_PAIR_DW_MAX_ITEMS output tiles of 384 x 128 that share the row count

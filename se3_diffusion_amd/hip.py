@@ -104,6 +104,17 @@ class FdEdgeEmbedDesc(Structure):
 
 EDGE_EMBED_IMAGE_BYTES = 20 * 12288
 
+
+class FdEdgeEmbedBwdDesc(Structure):
+    _fields_ = [
+        ("dy", c_void_p), ("h3", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("gamma", c_void_p), ("rowscale", c_void_p),
+        ("h2", c_void_p), ("h1", c_void_p), ("img", c_void_p), ("dh3", c_void_p), ("dh2", c_void_p), ("dh1", c_void_p),
+        ("dgamma", c_void_p), ("dbeta", c_void_p), ("rows", c_long), ("blocks", c_int),
+    ]
+
+
+EDGE_EMBED_BWD_IMAGE_BYTES = 16 * 12288
+
 PAIR_DW_MAX_ITEMS = 8
 
 
@@ -150,6 +161,8 @@ _SIGS = {
     "fd_edge_mlp": "Ss",
     "fd_edge_embed_pack": "pppps",
     "fd_edge_embed": "Ss",
+    "fd_edge_embed_bwd_pack": "ppps",
+    "fd_edge_embed_bwd": "Ss",
     "fd_pair_dw": "Ss",
     "fd_group_dw": "Ss",
     "fd_layernorm_fwd": "plpppplpplifs",

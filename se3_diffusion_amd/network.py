@@ -178,7 +178,23 @@ def embed_bwd(P, G, sv, dnode, dedge):
         ef = empty((B * N * N, 120), dedge)
         lib().call("fd_edge_feats", seq, tscaled, fixed, sc, tfreq, idenom, lower, upper, ef, B, N)
         se = dict(se, x=mv(ef))
-    mlp3_ln_bwd(P, G, "embedding_layer.edge_embedder", se, dedge)
+    pre = "embedding_layer.edge_embedder"
+    if (opts.fused_embed_bwd and fused_embed() and G is not None and se.get("regen") is not None
+            and all(f"{pre}.{l}.{t}" in G for l in (0, 2, 4) for t in ("weight", "bias"))):
+        # the fused forward's saves: LayerNorm backward + both gated dX products in one launch, then the three weight (and
+        # bias) gradients over the pair rows in one grouped launch on the side stream
+        M = se["M"]
+        dh3 = empty((M, CZ), dedge); dh2 = empty((M, CZ), dedge); dh1 = empty((M, CZ), dedge)
+        img = ops.edge_embed_bwd_pack(P[f"{pre}.2.weight"], P[f"{pre}.4.weight"])
+        ops.edge_embed_bwd(dedge, se["h3"], se["mean"], se["rstd"], P[f"{pre}.5.weight"], se["rowscale"], se["h2"], se["h1"], img,
+                           dh3, dh2, dh1, G[f"{pre}.5.weight"], G[f"{pre}.5.bias"], M)
+        x = se["x"]
+        items = [(mv(dh3), mv(se["h2"]), mv(G[f"{pre}.4.weight"]), G[f"{pre}.4.bias"], CZ, CZ),
+                 (mv(dh2), mv(se["h1"]), mv(G[f"{pre}.2.weight"]), G[f"{pre}.2.bias"], CZ, CZ),
+                 (mv(dh1), x, mv(G[f"{pre}.0.weight"]), G[f"{pre}.0.bias"], CZ, se["K0"])]
+        ops.side(lambda: ops.group_dw(items, M), (dh3, dh2, dh1, se["h2"], se["h1"], x[0]), M)
+        return
+    mlp3_ln_bwd(P, G, pre, se, dedge)
 
 
 def pair_mask(mask, B, N):

@@ -225,12 +225,40 @@ def queue_dw(dy, x, dW, M, N, K, db=None):
     if q["rows"] is not None and q["rows"] != M:
         flush_dw()
     q["rows"] = M
-    q["items"].append((hip._ptr(dt, do), hip._ptr(xt, xo), hip._ptr(wt, wo), None if db is None else hip._ptr(db),
-                       int(dl), int(xl), int(wl), int(N), int(K)))
+    q["items"].append((dy, x, dW, db, int(N), int(K)))
     q["tensors"].extend(t for t in (dt, xt, wt, db) if t is not None)
     if len(q["items"]) == hip.GROUP_DW_MAX_ITEMS:
         flush_dw()
     return True
+
+
+def group_dw(items, rows, blocks=0):
+    """One fd_group_dw launch on the CURRENT stream.  items: (dy view, x view, dW view, db tensor | None, n_out, k_in) with views
+    = (tensor, element offset, row stride):  dW[n_out, k_in] += dy^T x,  db += column sums of dy."""
+    assert 1 <= len(items) <= hip.GROUP_DW_MAX_ITEMS
+    d = hip.FdGroupDwDesc()
+    tens = []
+    for t, (dy, x, dW, db, n, k) in enumerate(items):
+        e = d.item[t]
+        e.A, e.B, e.C = hip._ptr(dy[0], dy[1]), hip._ptr(x[0], x[1]), hip._ptr(dW[0], dW[1])
+        e.a_colsum = None if db is None else hip._ptr(db)
+        e.lda, e.ldb, e.ldc, e.n_out, e.k_in = int(dy[2]), int(x[2]), int(dW[2]), int(n), int(k)
+        tens.extend(t_ for t_ in (dy[0], x[0], dW[0], db) if t_ is not None)
+    d.nitems, d.rows, d.blocks = len(items), int(rows), int(blocks or opts.node_dw_blocks)
+    L = lib()
+    stream = L._stream(tens)
+    prof = L.gemm_profile
+    if prof is not None and L.is_device:
+        # profile record (tile code 11): 2 * rows * n_out * k_in flops per item
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream())
+        L._check(L.cdll.fd_group_dw(hip.ctypes.byref(d), stream), "fd_group_dw")
+        e1.record(torch.cuda.current_stream())
+        prof.append((11, False, False, sum(2.0 * rows * it[4] * it[5] for it in items), e0, e1,
+                     (len(items), 128, int(rows), 1, 0, 0, 0, 1)))
+        return
+    L._check(L.cdll.fd_group_dw(hip.ctypes.byref(d), stream), "fd_group_dw")
 
 
 def flush_dw(blocks=0):
@@ -240,28 +268,7 @@ def flush_dw(blocks=0):
         return
     items, tens, rows = q["items"], q["tensors"], q["rows"]
     q["items"], q["tensors"], q["rows"] = [], [], None
-    d = hip.FdGroupDwDesc()
-    for t, (a, b, c, cs, lda, ldb, ldc, n, k) in enumerate(items):
-        e = d.item[t]
-        e.A, e.B, e.C, e.a_colsum, e.lda, e.ldb, e.ldc, e.n_out, e.k_in = a, b, c, cs, lda, ldb, ldc, n, k
-    d.nitems, d.rows, d.blocks = len(items), int(rows), int(blocks or opts.node_dw_blocks)
-    L = lib()
-
-    def launch():
-        stream = L._stream(tens)
-        prof = L.gemm_profile
-        if prof is not None and L.is_device:
-            # profile record (tile code 11): 2 * rows * n_out * k_in flops per item
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(torch.cuda.current_stream())
-            L._check(L.cdll.fd_group_dw(hip.ctypes.byref(d), stream), "fd_group_dw")
-            e1.record(torch.cuda.current_stream())
-            prof.append((11, False, False, sum(2.0 * rows * it[7] * it[8] for it in items), e0, e1,
-                         (len(items), 128, int(rows), 1, 0, 0, 0, 1)))
-            return
-        L._check(L.cdll.fd_group_dw(hip.ctypes.byref(d), stream), "fd_group_dw")
-    side(launch, tens, rows)
+    side(lambda: group_dw(items, rows, blocks), tens, rows)
 
 
 def add_view(dst, src, rows, cols, alpha=1.0):
@@ -393,6 +400,26 @@ def edge_embed(seq_idx, sc_ca, idenom, dg_lower, dg_upper, img, p, q, bias2, bia
         prof.append((8, True, True, 2.0 * int(rows) * 310 * 128, e0, e1, (int(rows), 128, 128, 1, 0, 0, 0, 1)))
         return
     L._check(L.cdll.fd_edge_embed(hip.ctypes.byref(d), stream), "fd_edge_embed")
+
+
+def edge_embed_bwd_pack(W2, W4, out=None):
+    img = out if out is not None else torch.empty(hip.EDGE_EMBED_BWD_IMAGE_BYTES, dtype=torch.uint8, device=W2.device)
+    lib().call("fd_edge_embed_bwd_pack", W2, W4, img)
+    return img
+
+
+def edge_embed_bwd(dy, h3, mean, rstd, gamma, rowscale, h2, h1, img, dh3, dh2, dh1, dgamma, dbeta, rows, blocks=0):
+    """The edge embedder's LayerNorm backward + dX chain in one launch (csrc/fd_edge_embed_bwd.hip)."""
+    d = hip.FdEdgeEmbedBwdDesc()
+    tens = []
+    for name, t in (("dy", dy), ("h3", h3), ("mean", mean), ("rstd", rstd), ("gamma", gamma), ("rowscale", rowscale), ("h2", h2),
+                    ("h1", h1), ("img", img), ("dh3", dh3), ("dh2", dh2), ("dh1", dh1), ("dgamma", dgamma), ("dbeta", dbeta)):
+        setattr(d, name, None if t is None else t.data_ptr())
+        if t is not None:
+            tens.append(t)
+    d.rows, d.blocks = int(rows), int(blocks)
+    L = lib()
+    L._check(L.cdll.fd_edge_embed_bwd(hip.ctypes.byref(d), L._stream(tens)), "fd_edge_embed_bwd")
 
 
 # ---------------------------------------------------------------------------
