@@ -59,8 +59,17 @@ def per_step(rows):
 
 
 def short(name):
-    name = name.replace("void ", "")
-    return name[:name.index("(")] if "(" in name else name[:80]
+    """kernel name without return type, anonymous namespace and argument list (template arguments kept)"""
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    depth = 0
+    for i, ch in enumerate(name):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i]
+    return name[:80]
 
 
 def main():
