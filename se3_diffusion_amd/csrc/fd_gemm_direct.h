@@ -9,6 +9,7 @@
 // flight.  The four partial tiles meet in LDS and every thread finishes one float4 of the tile with the full fused
 // epilogue.  fp32 MFMA: exact fp32 products and sums (the k order differs from the 64x64 kernel's).
 constexpr int DG = 8;   // k per group
+constexpr int DPF = 8;  // groups in flight per wave
 
 template <bool KC>
 __device__ __forceinline__ void direct_load(float (&v)[4], const float* __restrict__ p, long kstride) {
@@ -47,27 +48,41 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(GemmArgs g) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int ngroups = d.K / DG;   // K % 8 == 0 (checked by the host)
-  float a0[4], b0[4], a1[4], b1[4];
-  int gi = wave;
-  if (gi < ngroups) {
-    direct_load<A_KC>(a0, pa + gi * ag, d.a_cs);
-    direct_load<B_KC>(b0, pb + gi * bg, d.b_rs);
-  }
-  for (; gi < ngroups; gi += 8) {
-    const bool more1 = gi + 4 < ngroups;
-    if (more1) {
-      direct_load<A_KC>(a1, pa + (gi + 4) * ag, d.a_cs);
-      direct_load<B_KC>(b1, pb + (gi + 4) * bg, d.b_rs);
-    }
+  // This wave's groups are g = wave, wave + 4, ...: nmine of them.  DPF groups (one float4 of A and of B each) are kept in
+  // flight in a register ring: a launch of this kernel is a chain of dependent latencies (operand fetch -> MFMA chain ->
+  // reduction -> store), and with two groups in flight a K = 320 product paid five memory round trips per wave (8.5 us per
+  // launch, 45 % of a sampling forward at N = 128); with eight its ten groups are one round trip and a quarter.
+  const int nmine = (ngroups - wave + 3) >> 2;
+  if (nmine > 0) {
+    // (loads are unconditional with the group index clamped to the wave's last group -- a few redundant L1 hits at the end
+    // instead of branches around loads: the count of loads in flight is then static and every wait is an exact vmcnt(n))
+    const int lastg = nmine - 1;
+    float av[DPF][4], bv[DPF][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc = fd::mfma_32x32x2(a0[t], b0[t], acc);
-    if (!more1) break;
-    if (gi + 8 < ngroups) {
-      direct_load<A_KC>(a0, pa + (gi + 8) * ag, d.a_cs);
-      direct_load<B_KC>(b0, pb + (gi + 8) * bg, d.b_rs);
+    for (int u = 0; u < DPF; ++u) {
+      const int gq = wave + 4 * (u < lastg ? u : lastg);
+      direct_load<A_KC>(av[u], pa + (long)gq * ag, d.a_cs);
+      direct_load<B_KC>(bv[u], pb + (long)gq * bg, d.b_rs);
     }
+    int t0 = 0;
+    for (; t0 + DPF <= nmine; t0 += DPF) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc = fd::mfma_32x32x2(a1[t], b1[t], acc);
+      for (int u = 0; u < DPF; ++u) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fd::mfma_32x32x2(av[u][e], bv[u][e], acc);
+        const int tn = t0 + u + DPF;
+        const int gq = wave + 4 * (tn < lastg ? tn : lastg);
+        direct_load<A_KC>(av[u], pa + (long)gq * ag, d.a_cs);
+        direct_load<B_KC>(bv[u], pb + (long)gq * bg, d.b_rs);
+      }
+    }
+    const int rem = nmine - t0;     // < DPF groups left, already in the ring
+#pragma unroll
+    for (int u = 0; u < DPF - 1; ++u)
+      if (u < rem) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fd::mfma_32x32x2(av[u][e], bv[u][e], acc);
+      }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
