@@ -321,6 +321,11 @@ int fd_ipa_kpts_bwd(const float* dL, const float* qp, const float* kp, const flo
 int fd_row_softmax_fwd(float* S, const float* key_add, long rows, int N, int rows_per_batch, void* stream);
 int fd_row_softmax_bwd(const float* A, float* dA, long rows, int N, void* stream);
 
+/* ---- input frames: rigids_t [R,7] -> quat [R,4], trans [R,3] * scale (scale_rigids, model/score_network.py:190-193) and,
+ * optionally, tscaled[b] = t[b] * tscale for the B examples (the embedder's timestep argument, score_network.py:38,43) ---- */
+int fd_split_rigids(const float* rig7, float scale, const float* t, float tscale, float* quat, float* trans, float* tscaled,
+                    long R, int B, void* stream);
+
 /* ---- backbone update: ipa_pytorch.py:530-557,641-644; rigid_utils.py:266-275,587-616,1039-1063 ---- */
 int fd_bb_update_fwd(const float* node, long ldn, int cs, const float* dmask, const float* W6, const float* b6,
                      const float* quat, const float* trans, float* upd, float* quat_out, float* trans_out,

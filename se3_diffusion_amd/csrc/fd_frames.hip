@@ -510,11 +510,40 @@ __global__ __launch_bounds__(128) void heads_bwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------- input frames
+// rigids_t [R,7] (quaternion | translation in Angstrom) -> quat [R,4], trans [R,3] * coordinate_scaling (score_network.py:
+// 190-193 scale_rigids) and the embedder's timestep argument t * 10000 per example (score_network.py:38,43): one launch
+// instead of three element-wise torch kernels at the head of every forward pass
+__global__ __launch_bounds__(256) void split_rigids_kernel(const float* __restrict__ rig, float scale,
+                                                           const float* __restrict__ t, float tscale,
+                                                           float* __restrict__ quat, float* __restrict__ trans,
+                                                           float* __restrict__ tscaled, long R_, int B) {
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < R_; r += (long)gridDim.x * 256) {
+    const float* s = rig + r * 7;
+    quat[r * 4 + 0] = s[0]; quat[r * 4 + 1] = s[1]; quat[r * 4 + 2] = s[2]; quat[r * 4 + 3] = s[3];
+    trans[r * 3 + 0] = s[4] * scale; trans[r * 3 + 1] = s[5] * scale; trans[r * 3 + 2] = s[6] * scale;
+    if (r < B && tscaled != nullptr) tscaled[r] = t[r] * tscale;
+  }
+}
+
 }  // namespace
 
 static unsigned rows4_grid(long rows, long cap) {
   long g = (rows + 3) / 4;
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+extern "C" int fd_split_rigids(const float* rig7, float scale, const float* t, float tscale, float* quat, float* trans,
+                               float* tscaled, long R_, int B, void* stream) {
+  FD_CHECK_ARG(rig7 && quat && trans, "fd_split_rigids: null operand");
+  FD_CHECK_ARG(tscaled == nullptr || (t != nullptr && B <= R_), "fd_split_rigids: t missing or B > rows");
+  if (R_ == 0) return FD_OK;
+  long g = (R_ + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(split_rigids_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, rig7, scale, t, tscale, quat, trans,
+                     tscaled, R_, B);
+  FD_CHECK_LAUNCH("fd_split_rigids");
+  return FD_OK;
 }
 
 extern "C" int fd_row_softmax_fwd(float* S, const float* key_add, long rows, int N, int rows_per_batch,

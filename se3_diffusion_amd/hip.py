@@ -189,6 +189,7 @@ _SIGS = {
     "fd_ipa_opair_bwd": "pppppiis",
     "fd_row_softmax_fwd": "pplii" + "s",
     "fd_row_softmax_bwd": "pplis",
+    "fd_split_rigids": "pfpfppplis",
     "fd_bb_update_fwd": "plipppppppp" + "ls",
     "fd_bb_update_bwd": "pppppppppp" + "ls",
     "fd_heads_fwd": "pppp" + "pl" + "ppp" + "pi" + "S" + "pppppp" + "iis",

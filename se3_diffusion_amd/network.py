@@ -34,6 +34,11 @@ TD, TH, THD = 320, 4, 80  # transformer width, heads, head dim
 
 
 def check_conf(conf):
+    """Which model_conf keys are free and which are frozen (INTEGRATION.md "model_conf").  Free: ipa.num_blocks,
+    ipa.seq_tfmr_num_layers (host loops), ipa.coordinate_scaling, dropout (unused by the reference's forward too).  Frozen at
+    config/base.yaml's values, because the kernels bake them into register / LDS layouts: node_embed_size = ipa.c_s = 256,
+    edge_embed_size = ipa.c_z = 128, ipa.c_hidden = 256, ipa.c_skip = 64, ipa.no_heads = 8, no_qk_points = 8, no_v_points = 12,
+    seq_tfmr_num_heads = 4, embed.index_embed_size = 32, embed.num_bins = 22, embed.embed_self_conditioning = True."""
     ipa = conf.ipa
     want = dict(c_s=256, c_z=128, c_hidden=256, c_skip=64, no_heads=8, no_qk_points=8, no_v_points=12,
                 seq_tfmr_num_heads=4)
@@ -43,8 +48,8 @@ def check_conf(conf):
                 f"the gfx950 kernels are built for config/base.yaml dimensions; model.ipa.{k}={getattr(ipa, k)} != {v}")
     if conf.node_embed_size != 256 or conf.edge_embed_size != 128:
         raise NotImplementedError("node_embed_size/edge_embed_size must be 256/128")
-    if getattr(ipa, "seq_tfmr_num_layers", 2) != 2:
-        raise NotImplementedError(f"the trunk runs 2 transformer layers per block; model.ipa.seq_tfmr_num_layers={ipa.seq_tfmr_num_layers}")
+    if int(getattr(ipa, "seq_tfmr_num_layers", 2)) < 1:
+        raise NotImplementedError(f"model.ipa.seq_tfmr_num_layers={ipa.seq_tfmr_num_layers}: at least one transformer layer per block")
     e = conf.embed
     if e.index_embed_size != 32 or e.num_bins != 22 or not e.embed_self_conditioning:
         raise NotImplementedError("embed config must match config/base.yaml (index 32, 22 bins, self-conditioning)")
@@ -103,7 +108,7 @@ def embed_fwd(P, feats, B, N, cache=None, save=True):
     dev = feats["res_mask"]
     mask = feats["res_mask"]
     tfreq, idenom, lower, upper = ops.feature_tables(dev.device)
-    tscaled = (feats["t"] * 10000).float().contiguous()          # score_network.py:38,43
+    tscaled = feats["tscaled"] if "tscaled" in feats else (feats["t"] * 10000).float().contiguous()   # score_network.py:38,43
     fixed = feats["fixed_mask"]
     seq = feats["seq_idx"]
     R, Pn = B * N, B * N * N
@@ -417,7 +422,7 @@ def ln_skip_bwd(P, G, b, sv, du0, dx1, dinit):
 
 
 # --------------------------------------------------------------------------- transformer layer
-def tfmr_layer_fwd(P, pre, x, key_add, B, N, save=True):
+def tfmr_layer_fwd(P, pre, x, key_add, B, N, save=True, out_rowscale=None):
     dev = x
     R = B * N
     L = lib()
@@ -446,7 +451,7 @@ def tfmr_layer_fwd(P, pre, x, key_add, B, N, save=True):
     t2 = empty((R, TD), dev)
     ops.linear(mv(f), mv(P[f"{pre}.linear2.weight"]), P[f"{pre}.linear2.bias"], mv(t2), R, TD, TD, resid=mv(y1))
     y2 = empty((R, TD), dev); m2 = empty((R,), dev); r2 = empty((R,), dev)
-    ops.layernorm(mv(t2), P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"], mv(y2), R, TD, save=(m2, r2))
+    ops.layernorm(mv(t2), P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"], mv(y2), R, TD, rowscale=out_rowscale, save=(m2, r2))
     return y2, dict(x=x, qkv=qkv, A=A, o=o, t1=t1, m1=m1, r1=r1, y1=y1, f=f, t2=t2, m2=m2, r2=r2, B=B, N=N)
 
 

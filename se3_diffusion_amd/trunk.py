@@ -367,6 +367,14 @@ def _cached(cache, key, fn):
     return cache[key]
 
 
+def _tfmr_layers(P, b):
+    """model.ipa.seq_tfmr_num_layers, read off the state_dict (ipa_pytorch.py:584-593: nn.TransformerEncoder(layer, num_layers))"""
+    n = 0
+    while f"score_model.trunk.seq_tfmr_{b}.layers.{n}.linear1.weight" in P:
+        n += 1
+    return n
+
+
 def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_bool_mask=False, save=True, cache=None):
     """ScoreNetwork.forward.  Returns (outputs, saved-for-backward or None).  `cache`: see _cached (no-grad only)."""
     if save:
@@ -383,6 +391,13 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
         if cache.get("_sig") != sig:
             cache.clear()
             cache["_sig"] = sig
+    # frames and the embedder's timestep argument in one launch (instead of a slice copy, a scaled slice copy and t * 1e4)
+    rig = f["rigids_t"]
+    quat = empty((R, 4), dev); trans = empty((R, 3), dev)                      # trans: scale_rigids (A -> nm)
+    t32 = f["t"].dtype == torch.float32
+    tsc = empty((B,), dev) if t32 else None
+    L.call("fd_split_rigids", rig, float(dconf[0]), f["t"] if t32 else None, 10000.0, quat, trans, tsc, R, B)
+    f["tscaled"] = tsc if t32 else (f["t"] * 10000).float().contiguous()     # score_network.py:38,43
     with rng("embed.fwd"):
         node0, z, sv_embed = nw.embed_fwd(P, f, B, N, cache, save=save)
     emask = sv_embed["emask"]
@@ -392,9 +407,6 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
         L.call("fd_rowscale", (1 - f["fixed_mask"]).contiguous(), 1, mask.reshape(-1), dm, 1, R, 1)
         return dm
     dmask = _cached(cache, "dmask", _dmask)
-    rig = f["rigids_t"]
-    quat = rig[..., :4].contiguous().view(R, 4)
-    trans = (rig[..., 4:] * dconf[0]).contiguous().view(R, 3)                  # scale_rigids (A -> nm)
     init_node = node0                                                          # already masked (LN rowscale)
     node = node0
     if tfmr_bool_mask:
@@ -411,13 +423,13 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
             u, sv_ln = nw.ln_skip_fwd(P, b, x1, init_node, R)
             u0 = u
             sv_t = []
-            for l in range(2):
-                u, s_ = nw.tfmr_layer_fwd(P, f"score_model.trunk.seq_tfmr_{b}.layers.{l}", u, key_add, B, N, save=save)
+            nl = _tfmr_layers(P, b)
+            for l in range(nl):
+                # eval + no_grad fast path of nn.TransformerEncoder: padded rows of its output are zeroed (nested-tensor
+                # round trip) -- the row mask rides on the last layer's LayerNorm instead of a launch of its own
+                u, s_ = nw.tfmr_layer_fwd(P, f"score_model.trunk.seq_tfmr_{b}.layers.{l}", u, key_add, B, N, save=save,
+                                          out_rowscale=mask.view(-1) if (tfmr_bool_mask and l == nl - 1) else None)
                 sv_t.append(s_)
-            if tfmr_bool_mask:
-                u2 = empty((R, TD), dev)
-                L.call("fd_rowscale", u, TD, mask.view(-1), u2, TD, R, TD)
-                u = u2
         with rng(f"node_transition_{b}.fwd"):
             n3, sv_pn = nw.post_node_fwd(P, b, u, u0, mask.view(-1), R)
             q2, t2, sv_bb = bb_update_fwd(P, b, n3, dmask.view(-1), quat, trans, R)
@@ -485,7 +497,7 @@ def _backward(P, G, sv, d_out, notify):
             du2 = nw.post_node_bwd(P, G, b, st["pn"], dn3, du0)
         with rng(f"seq_tfmr_{b}.bwd"):
             du = du2
-            for l in reversed(range(2)):
+            for l in reversed(range(len(st["tfmr"]))):
                 du = nw.tfmr_layer_bwd(P, G, f"score_model.trunk.seq_tfmr_{b}.layers.{l}", st["tfmr"][l], du)
             ops.add_view(mv(du0), mv(du), R, TD)
             dx1 = empty((R, CS), dev)

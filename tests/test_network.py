@@ -81,8 +81,9 @@ def quat_align(a, b):
     return torch.cat([a[..., :4] * s, a[..., 4:]], -1)
 
 
-def run_case(dev, B, N, blocks, seed, n_pad=0, n_fixed=0, check_grad=True, tol_out=2e-4, tol_grad=2e-3, rot_floor=1e-12):
-    conf = dict(fo.CONF, num_blocks=blocks)
+def run_case(dev, B, N, blocks, seed, n_pad=0, n_fixed=0, check_grad=True, tol_out=2e-4, tol_grad=2e-3, rot_floor=1e-12,
+             tfmr_layers=2):
+    conf = dict(fo.CONF, num_blocks=blocks, tfmr_layers=tfmr_layers)
     P = fo.synth_params(seed=seed, conf=conf)
     feats = fo.synth_feats(B, N, seed=seed, n_pad=n_pad, n_fixed=n_fixed)
     Pd = {k: v.to(dev) for k, v in P.items()}
@@ -132,6 +133,13 @@ def test_degenerate_sizes_emu(use_emu):
     # all fixed: the frames do not move, the reference's relative rotation is exactly the identity and its rot_score exactly 0;
     # here it is the fp32 round-off of R0^T R0 (|rot_score| ~ 1e-8): compared on an absolute scale
     run_case("cpu", B=1, N=4, blocks=1, seed=5, n_fixed=4, rot_floor=1e-3)
+
+
+def test_other_transformer_depths_emu(use_emu):
+    """model.ipa.seq_tfmr_num_layers other than config/base.yaml's 2 (ipa_pytorch.py:584-593): the layer count is read off the
+    state_dict, forward and every gradient against the oracle"""
+    run_case("cpu", B=1, N=6, blocks=1, seed=9, tfmr_layers=1)
+    run_case("cpu", B=2, N=5, blocks=2, seed=10, n_pad=1, tfmr_layers=3)
 
 
 @pytest.mark.slow
