@@ -113,8 +113,13 @@ int fd_rowscale(const float* x, long ldx, const float* rs, float* y, long ldy, l
  *   backward: x = dy; d2 = [gate1 > 0] (A1 x); d1 = [gate2 > 0] (A2 d2); out = A3 x + A4 d1, with the image packed
  *             from the TRANSPOSED weights (A1 = Wf^T, A2 = W2^T, A3 = Wfz^T, A4 = W1z^T; gate1 = h2, gate2 = h1);
  *             save1 = d2, save2 = d1 (operands of the weight-gradient GEMMs).
- * A1 [384,128], A2 [384,384], A3 [128,128], A4 [128,384] are given as (pointer, row stride, column stride). */
-#define FD_EDGE_MLP_IMAGE_BYTES (128 * 12288)
+ * A1 [384,128], A2 [384,384], A3 [128,128], A4 [128,384] are given as (pointer, row stride, column stride).
+ * Optional fourth forward layer (zb_out != NULL): zb_out[rows,40] = W40 out + zb_bias, W40 = [linear_b.weight ; down_z.weight]
+ * of the NEXT trunk block's IPA (ipa_pytorch.py:380-386,455) -- the pair bias and the down-projected pair features of its
+ * attention, taken from the output while it is in registers; the image then carries four more units
+ * (fd_edge_mlp_pack_zb, after fd_edge_mlp_pack). */
+#define FD_EDGE_MLP_IMAGE_BYTES (132 * 12288)
+int fd_edge_mlp_pack_zb(const float* W40, void* image, void* stream);
 int fd_edge_mlp_pack(const float* A1, long rs1, long cs1, const float* A2, long rs2, long cs2, const float* A3,
                      long rs3, long cs3, const float* A4, long rs4, long cs4, void* image, void* stream);
 typedef struct FdEdgeMlpDesc {
@@ -143,6 +148,8 @@ typedef struct FdEdgeMlpDesc {
   int blocks;            /* 0 = one persistent block per CU (256) */
   long ld_pq;            /* row stride of p1 / q1 (0 = 384) */
   long ld_pqf;           /* row stride of pf / qf (0 = 128) */
+  float* zb_out;         /* forward, optional: [rows,40] (see above) */
+  const float* zb_bias;  /* forward, optional: [40] */
 } FdEdgeMlpDesc;
 int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream);
 
@@ -152,7 +159,10 @@ int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream);
  * layer that depends on one residue only arrives as p[b,i] = W0[:, 0:33] pt_i + b0 and q[b,j] = W0[:, 33:66] pt_j
  * (pt = [t-emb(32) | fixed]); the kernel adds W0[:, 66:120] [relpos sincos(32) | distogram(22)].  The image packs
  * W0[:, 66:120], W2, W4 ([128,120], [128,128], [128,128] row-major) as bf16 planes (FD_EDGE_EMBED_IMAGE_BYTES). */
-#define FD_EDGE_EMBED_IMAGE_BYTES (20 * 12288)
+#define FD_EDGE_EMBED_IMAGE_BYTES (24 * 12288)
+/* optional fourth layer, as fd_edge_mlp's: zb_out[rows,40] = W40 out + zb_bias for the FIRST trunk block's IPA; the image then
+ * carries four more units (fd_edge_embed_pack_zb after fd_edge_embed_pack) */
+int fd_edge_embed_pack_zb(const float* W40, void* image, void* stream);
 int fd_edge_embed_pack(const float* W0, const float* W2, const float* W4, void* image, void* stream);
 typedef struct FdEdgeEmbedDesc {
   const long* seq_idx;    /* [B*nres] */
@@ -178,6 +188,8 @@ typedef struct FdEdgeEmbedDesc {
   int nres;
   float eps;
   int blocks;             /* 0 = one persistent block per CU (256) */
+  float* zb_out;          /* optional [rows,40] */
+  const float* zb_bias;   /* optional [40] */
 } FdEdgeEmbedDesc;
 int fd_edge_embed(const FdEdgeEmbedDesc* desc, void* stream);
 

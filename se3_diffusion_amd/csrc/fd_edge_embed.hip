@@ -17,7 +17,8 @@ namespace {
 #include "fd_chain.h"
 
 constexpr int EE_UNITS = 20;               // layer 1: 2 k-steps x 2 n-groups; layers 2, 3: 4 x 2 each
-constexpr int EE_NSTAGE = EE_UNITS / EM_UPS;
+constexpr int EE_ZB_UNITS = 4;             // + the first IPA block's [linear_b ; down_z] (40 <- 128: 4 k-steps x one n-group)
+constexpr int EE_ZB = 40;
 constexpr int EE_C = 128;
 constexpr float kPi = 3.14159265358979323846f;
 
@@ -51,7 +52,32 @@ __global__ __launch_bounds__(256) void edge_embed_pack_kernel(const float* __res
   *reinterpret_cast<uint4*>(dst + 2 * EM_PIECE) = s2;
 }
 
+// units 20..23 of the image: W40 = [linear_b.weight ; down_z.weight] [40,128] of the first trunk block's IPA
+// (ipa_pytorch.py:380-386,455), rows 40..63 zero, chained k order
+__global__ __launch_bounds__(256) void edge_embed_pack_zb_kernel(const float* __restrict__ W40, char* __restrict__ img) {
+  const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x);   // (k-step, n-block, lane)
+  if (gid >= EE_ZB_UNITS * 4 * 64) return;
+  const int lane = gid & 63, i = (gid >> 6) & 3, ks = gid >> 8;
+  const int m = lane & 15, g = lane >> 4;
+  const int n = 16 * i + m;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 32 * ks + 16 * (e >> 2) + 4 * g + (e & 3);
+    x[e] = n < EE_ZB ? W40[n * EE_C + k] : 0.f;
+  }
+  uint4 s0, s1, s2;
+  em_split8(x, s0, s1, s2);
+  char* dst = img + (long)(EE_UNITS + ks) * EM_UNIT + (i * 3) * EM_PIECE + lane * 16;
+  *reinterpret_cast<uint4*>(dst) = s0;
+  *reinterpret_cast<uint4*>(dst + EM_PIECE) = s1;
+  *reinterpret_cast<uint4*>(dst + 2 * EM_PIECE) = s2;
+}
+
+// ZB: a fourth chained layer on the kernel's own output -- zb = [linear_b ; down_z] z + b40 of the first trunk block's IPA
+template <bool ZB>
 __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_kernel(FdEdgeEmbedDesc d) {
+  constexpr int EE_NSTAGE = (EE_UNITS + (ZB ? EE_ZB_UNITS : 0)) / EM_UPS;
   __shared__ __attribute__((aligned(16))) char lds[2 * EM_STAGE];
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -242,6 +268,38 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_kernel(FdEdgeEmbe
       o.z = (acc3[nb][2] * rstd * gm.z + bt.z) * rs;
       o.w = (acc3[nb][3] * rstd * gm.w + bt.w) * rs;
       if (rok) *reinterpret_cast<float4*>(d.out + row * EE_C + col) = o;
+      if (ZB) { acc3[nb][0] = o.x; acc3[nb][1] = o.y; acc3[nb][2] = o.z; acc3[nb][3] = o.w; }
+    }
+    if (ZB) {
+      // ---- layer 4: zb[0:40] = W40 z + b40 (n-blocks 0..2 of one n-group; columns >= 40 are zero weights) ----
+      f32x4 acc4[4];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const int col = 16 * nb + 4 * g;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < EE_ZB && d.zb_bias != nullptr) a = *reinterpret_cast<const float4*>(d.zb_bias + col);
+        acc4[nb][0] = a.x; acc4[nb][1] = a.y; acc4[nb][2] = a.z; acc4[nb][3] = a.w;
+      }
+#pragma clang loop unroll(full)
+      for (int sg = 0; sg < EE_ZB_UNITS / EM_UPS; ++sg) {
+        const char* st = stage_begin();
+        em16_read_half(H[0], st);
+#pragma clang loop unroll(full)
+        for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
+          const int ks = EM_UPS * sg + (hh >> 1), a = 2 * (hh & 1);
+          if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
+          fd::sched_pin();
+          if ((hh & 1) == 0) em16_split2(acc3[2 * ks], acc3[2 * ks + 1], b[0], b[1], b[2]);
+          em16_mma_half(acc4[a], acc4[a + 1], H[hh & 1], b);
+          if (hh == 1) stage_prefetch();
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < 3; ++nb) {
+        const int col = 16 * nb + 4 * g;
+        if (rok && col < EE_ZB)
+          *reinterpret_cast<float4*>(d.zb_out + row * EE_ZB + col) = make_float4(acc4[nb][0], acc4[nb][1], acc4[nb][2], acc4[nb][3]);
+      }
     }
   }
 }
@@ -257,6 +315,15 @@ extern "C" int fd_edge_embed_pack(const float* W0, const float* W2, const float*
   return FD_OK;
 }
 
+extern "C" int fd_edge_embed_pack_zb(const float* W40, void* img, void* stream) {
+  FD_CHECK_ARG(W40 && img, "fd_edge_embed_pack_zb: null operand");
+  FD_CHECK_ARG(fd_aligned16(img), "fd_edge_embed_pack_zb: image must be 16-byte aligned");
+  hipLaunchKernelGGL(edge_embed_pack_zb_kernel, dim3(EE_ZB_UNITS * 4 * 64 / 256), dim3(256), 0, (hipStream_t)stream, W40,
+                     static_cast<char*>(img));
+  FD_CHECK_LAUNCH("fd_edge_embed_pack_zb");
+  return FD_OK;
+}
+
 extern "C" int fd_edge_embed(const FdEdgeEmbedDesc* desc, void* stream) {
   FD_CHECK_ARG(desc != nullptr, "fd_edge_embed: null descriptor");
   const FdEdgeEmbedDesc& d = *desc;
@@ -269,8 +336,14 @@ extern "C" int fd_edge_embed(const FdEdgeEmbedDesc* desc, void* stream) {
   if (d.rows == 0) return FD_OK;
   const long ntiles = (d.rows + EM_ROWS - 1) / EM_ROWS;
   const int blocks = d.blocks > 0 ? d.blocks : 256 * EM_BLOCKS_PER_CU;   // MI355X: persistent blocks fill the 256 CUs
-  hipLaunchKernelGGL(edge_embed_kernel, dim3((unsigned)(ntiles < blocks ? ntiles : blocks)), dim3(64 * EM_WAVES), 0,
-                     (hipStream_t)stream, d);
+  FD_CHECK_ARG(d.zb_out == nullptr || (fd_aligned16(d.zb_out) && fd_aligned16(d.zb_bias)),
+               "fd_edge_embed: zb_out / zb_bias must be 16-byte aligned (and the image carry the fd_edge_embed_pack_zb units)");
+  if (d.zb_out != nullptr)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_embed_kernel<true>), dim3((unsigned)(ntiles < blocks ? ntiles : blocks)), dim3(64 * EM_WAVES),
+                       0, (hipStream_t)stream, d);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_embed_kernel<false>), dim3((unsigned)(ntiles < blocks ? ntiles : blocks)), dim3(64 * EM_WAVES),
+                       0, (hipStream_t)stream, d);
   FD_CHECK_LAUNCH("fd_edge_embed");
   return FD_OK;
 }

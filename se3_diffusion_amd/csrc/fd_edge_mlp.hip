@@ -41,7 +41,8 @@ namespace {
 #include "fd_chain.h"
 
 constexpr int EM_UNITS = 128;              // units per tile
-constexpr int EM_NSTAGE = EM_UNITS / EM_UPS;
+constexpr int EM_ZB_UNITS = 4;             // + the next IPA block's [linear_b ; down_z] (40 <- 128: 4 k-steps x one n-group)
+constexpr int EM_ZB = 40;
 #ifndef EM_RING
 // LDS stages of the weight stream.  3 (the copy runs two stages ahead behind a counted vmcnt wait) makes the kernel 2-3 %
 // faster on its own (1.47 vs 1.51 ms forward with saves) but costs 144 KB of LDS per CU, and the training step then loses
@@ -97,8 +98,34 @@ __global__ __launch_bounds__(256) void edge_mlp_pack16_kernel(EmMat A1, EmMat A2
   *reinterpret_cast<uint4*>(dst + 2 * EM_PIECE) = s2;
 }
 
-template <bool BWD>
+// units 128..131 of the forward image: W40 = [linear_b.weight ; down_z.weight] [40,128] of the NEXT trunk block's IPA
+// (ipa_pytorch.py:380-386,455), rows 40..63 zero, chained k order (its operand is the LayerNorm output in registers)
+__global__ __launch_bounds__(256) void edge_mlp_pack_zb_kernel(const float* __restrict__ W40, char* __restrict__ img) {
+  const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x);   // (k-step, n-block, lane)
+  if (gid >= EM_ZB_UNITS * 4 * 64) return;
+  const int lane = gid & 63, i = (gid >> 6) & 3, ks = gid >> 8;
+  const int m = lane & 15, g = lane >> 4;
+  const int n = 16 * i + m;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 32 * ks + 16 * (e >> 2) + 4 * g + (e & 3);
+    x[e] = n < EM_ZB ? W40[n * EM_C + k] : 0.f;
+  }
+  uint4 s0, s1, s2;
+  em_split8(x, s0, s1, s2);
+  char* dst = img + (long)(EM_UNITS + ks) * EM_UNIT + (i * 3) * EM_PIECE + lane * 16;
+  *reinterpret_cast<uint4*>(dst) = s0;
+  *reinterpret_cast<uint4*>(dst + EM_PIECE) = s1;
+  *reinterpret_cast<uint4*>(dst + 2 * EM_PIECE) = s2;
+}
+
+// ZB (forward only): a fourth chained layer on the kernel's own output -- zb = [linear_b ; down_z] z' + b40 of the next
+// trunk block's IPA -- so that block needs no pass over z' [P,128] for it (fd_gemm: 119 us per block at B=30 x N=128, 252 MB
+// read); +3 % of the chain's MFMAs, 160 B more written per pair row
+template <bool BWD, bool ZB = false>
 __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpDesc d) {
+  constexpr int EM_NSTAGE = (EM_UNITS + (ZB ? EM_ZB_UNITS : 0)) / EM_UPS;
   __shared__ __attribute__((aligned(16))) char lds[EM_RING * EM_STAGE];
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -341,6 +368,38 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
         o.z = (acc3[nb][2] * rstd * gm.z + bt.z) * rs;
         o.w = (acc3[nb][3] * rstd * gm.w + bt.w) * rs;
         if (rok) *reinterpret_cast<float4*>(d.out + row * EM_C + col) = o;
+        if (ZB) { acc3[nb][0] = o.x; acc3[nb][1] = o.y; acc3[nb][2] = o.z; acc3[nb][3] = o.w; }
+      }
+      if (ZB) {
+        // ---- layer 4: zb[0:40] = W40 z' + b40 (n-blocks 0..2 of one n-group; columns >= 40 are zero weights) ----
+        f32x4 acc4[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const int col = 16 * nb + 4 * g;
+          float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (col < EM_ZB && d.zb_bias != nullptr) a = *reinterpret_cast<const float4*>(d.zb_bias + col);
+          acc4[nb][0] = a.x; acc4[nb][1] = a.y; acc4[nb][2] = a.z; acc4[nb][3] = a.w;
+        }
+#pragma clang loop unroll(full)
+        for (int sg = 0; sg < EM_ZB_UNITS / EM_UPS; ++sg) {
+          const char* st = stage_begin();
+          em16_read_half(H[0], st);
+#pragma clang loop unroll(full)
+          for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
+            const int ks = EM_UPS * sg + (hh >> 1), a = 2 * (hh & 1);
+            if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
+            fd::sched_pin();
+            if ((hh & 1) == 0) em16_split2(acc3[2 * ks], acc3[2 * ks + 1], b[0], b[1], b[2]);
+            em16_mma_half(acc4[a], acc4[a + 1], H[hh & 1], b);
+            if (hh == 1) stage_prefetch();
+          }
+        }
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+          const int col = 16 * nb + 4 * g;
+          if (rok && col < EM_ZB)
+            *reinterpret_cast<float4*>(d.zb_out + row * EM_ZB + col) = make_float4(acc4[nb][0], acc4[nb][1], acc4[nb][2], acc4[nb][3]);
+        }
       }
     } else {
 #pragma unroll
@@ -366,6 +425,15 @@ extern "C" int fd_edge_mlp_pack(const float* A1, long rs1, long cs1, const float
   return FD_OK;
 }
 
+extern "C" int fd_edge_mlp_pack_zb(const float* W40, void* img, void* stream) {
+  FD_CHECK_ARG(W40 && img, "fd_edge_mlp_pack_zb: null operand");
+  FD_CHECK_ARG(fd_aligned16(img), "fd_edge_mlp_pack_zb: image must be 16-byte aligned");
+  hipLaunchKernelGGL(edge_mlp_pack_zb_kernel, dim3(EM_ZB_UNITS * 4 * 64 / 256), dim3(256), 0, (hipStream_t)stream, W40,
+                     static_cast<char*>(img));
+  FD_CHECK_LAUNCH("fd_edge_mlp_pack_zb");
+  return FD_OK;
+}
+
 extern "C" int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream) {
   FD_CHECK_ARG(desc != nullptr, "fd_edge_mlp: null descriptor");
   const FdEdgeMlpDesc& d = *desc;
@@ -384,10 +452,14 @@ extern "C" int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream) {
   const long ntiles = (d.rows + EM_ROWS - 1) / EM_ROWS;
   const int blocks = d.blocks > 0 ? d.blocks : 256 * EM_BLOCKS_PER_CU;   // MI355X: persistent blocks fill the 256 CUs
   const int grid = (int)(ntiles < blocks ? ntiles : blocks);
+  FD_CHECK_ARG(d.zb_out == nullptr || (!d.backward && fd_aligned16(d.zb_out) && fd_aligned16(d.zb_bias)),
+               "fd_edge_mlp: zb_out is a forward output (16-byte aligned; the image must carry the fd_edge_mlp_pack_zb units)");
   if (d.backward)
-    hipLaunchKernelGGL(edge_mlp16_kernel<true>, dim3(grid), dim3(64 * EM_WAVES), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false>), dim3(grid), dim3(64 * EM_WAVES), 0, (hipStream_t)stream, d);
+  else if (d.zb_out != nullptr)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true>), dim3(grid), dim3(64 * EM_WAVES), 0, (hipStream_t)stream, d);
   else
-    hipLaunchKernelGGL(edge_mlp16_kernel<false>, dim3(grid), dim3(64 * EM_WAVES), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, false>), dim3(grid), dim3(64 * EM_WAVES), 0, (hipStream_t)stream, d);
   FD_CHECK_LAUNCH("fd_edge_mlp");
   return FD_OK;
 }

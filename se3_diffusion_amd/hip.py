@@ -85,11 +85,11 @@ class FdEdgeMlpDesc(Structure):
         ("pf", c_void_p), ("qf", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("rowscale", c_void_p),
         ("y", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("out", c_void_p),
         ("rows", c_long), ("nres", c_int), ("backward", c_int), ("eps", c_float), ("blocks", c_int),
-        ("ld_pq", c_long), ("ld_pqf", c_long),
+        ("ld_pq", c_long), ("ld_pqf", c_long), ("zb_out", c_void_p), ("zb_bias", c_void_p),
     ]
 
 
-EDGE_MLP_IMAGE_BYTES = 128 * 12288
+EDGE_MLP_IMAGE_BYTES = 132 * 12288
 
 
 class FdEdgeEmbedDesc(Structure):
@@ -98,11 +98,11 @@ class FdEdgeEmbedDesc(Structure):
         ("img", c_void_p), ("p", c_void_p), ("q", c_void_p), ("bias2", c_void_p), ("bias3", c_void_p),
         ("gamma", c_void_p), ("beta", c_void_p), ("rowscale", c_void_p),
         ("h1", c_void_p), ("h2", c_void_p), ("h3", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("out", c_void_p),
-        ("rows", c_long), ("nres", c_int), ("eps", c_float), ("blocks", c_int),
+        ("rows", c_long), ("nres", c_int), ("eps", c_float), ("blocks", c_int), ("zb_out", c_void_p), ("zb_bias", c_void_p),
     ]
 
 
-EDGE_EMBED_IMAGE_BYTES = 20 * 12288
+EDGE_EMBED_IMAGE_BYTES = 24 * 12288
 
 
 class FdEdgeEmbedBwdDesc(Structure):
@@ -159,8 +159,10 @@ _SIGS = {
     "fd_gemm_set_persistent_blocks": "i",
     "fd_edge_mlp_pack": "pllpllpllpllps",
     "fd_edge_mlp": "Ss",
+    "fd_edge_mlp_pack_zb": "pps",
     "fd_edge_embed_pack": "pppps",
     "fd_edge_embed": "Ss",
+    "fd_edge_embed_pack_zb": "pps",
     "fd_edge_embed_bwd_pack": "ppps",
     "fd_edge_embed_bwd": "Ss",
     "fd_pair_dw": "Ss",

@@ -104,7 +104,9 @@ def fused_embed():
     return opts.fused_embed and not lib().exact_f32
 
 
-def embed_fwd(P, feats, B, N, cache=None, save=True):
+def embed_fwd(P, feats, B, N, cache=None, save=True, zb_next=None):
+    """Returns (node, edge, saved, zb): zb = W40 edge + b40 of the first IPA block (zb_next = its (W40, b40)) when the fused
+    edge embedder forms it from its output in registers, else None."""
     dev = feats["res_mask"]
     mask = feats["res_mask"]
     tfreq, idenom, lower, upper = ops.feature_tables(dev.device)
@@ -123,7 +125,7 @@ def embed_fwd(P, feats, B, N, cache=None, save=True):
         ef = empty((Pn, 120), dev)
         lib().call("fd_edge_feats", seq, tscaled, fixed, feats["sc_ca_t"], tfreq, idenom, lower, upper, ef, B, N)
         edge, sv_e = mlp3_ln_fwd(P, pre, mv(ef), Pn, 120, CZ, emask)
-        return node, edge, dict(node=sv_n, edge=sv_e, emask=emask)
+        return node, edge, dict(node=sv_n, edge=sv_e, emask=emask), None
     # fused: no [P,120] feature tensor, no hidden activations in HBM.  The residue-only part of the first layer
     # (t-embedding + fixed flag of i and of j = the first 33 columns of the node feature) is node-level:
     # p = W0[:, 0:33] pt + b0, q = W0[:, 33:66] pt
@@ -131,19 +133,25 @@ def embed_fwd(P, feats, B, N, cache=None, save=True):
     p_ = empty((R, CZ), dev); q_ = empty((R, CZ), dev)
     ops.linear((nf, 0, 65), (W0, 0, 120), P[f"{pre}.0.bias"], mv(p_), R, CZ, 33)
     ops.linear((nf, 0, 65), (W0, 33, 120), None, mv(q_), R, CZ, 33)
-    key = ("ee_img", pre)
+    use_zb = (opts.zb_from_edge and zb_next is not None and zb_next[0].is_contiguous() and zb_next[0].data_ptr() % 16 == 0
+              and zb_next[1].data_ptr() % 16 == 0)
+    key = ("ee_img", pre, use_zb)
     if cache is not None and key in cache:
         img = cache[key]
     else:
-        img = ops.edge_embed_pack(W0, P[f"{pre}.2.weight"], P[f"{pre}.4.weight"])
+        img = ops.edge_embed_pack(W0, P[f"{pre}.2.weight"], P[f"{pre}.4.weight"], W40=zb_next[0] if use_zb else None)
         if cache is not None:
             cache[key] = img
     edge = empty((Pn, CZ), dev)
     kw = {}
+    zb = None
+    if use_zb:
+        zb = empty((Pn, ZB), dev)
+        kw.update(zb_out=zb, zb_bias=zb_next[1])
     if save:
         h1 = empty((Pn, CZ), dev); h2 = empty((Pn, CZ), dev); h3 = empty((Pn, CZ), dev)
         mean = empty((Pn,), dev); rstd = empty((Pn,), dev)
-        kw = dict(h1=h1, h2=h2, h3=h3, mean=mean, rstd=rstd)
+        kw.update(h1=h1, h2=h2, h3=h3, mean=mean, rstd=rstd)
     ops.edge_embed(seq, feats["sc_ca_t"], idenom, lower, upper, img, p_, q_, P[f"{pre}.2.bias"], P[f"{pre}.4.bias"],
                    P[f"{pre}.5.weight"], P[f"{pre}.5.bias"], edge, Pn, N, rowscale=emask, **kw)
     sv_e = None
@@ -152,7 +160,7 @@ def embed_fwd(P, feats, B, N, cache=None, save=True):
         # which is regenerated there (embed_bwd) instead of being kept alive through the whole step
         sv_e = dict(x=None, h1=h1, h2=h2, h3=h3, mean=mean, rstd=rstd, rowscale=emask, M=Pn, K0=120, C=CZ,
                     regen=(seq, tscaled, fixed, feats["sc_ca_t"], B, N))
-    return node, edge, dict(node=sv_n, edge=sv_e, emask=emask)
+    return node, edge, dict(node=sv_n, edge=sv_e, emask=emask), zb
 
 
 def embed_regen_early(sv, G):
@@ -250,8 +258,21 @@ def _joined(a, b, shape):
 
 
 # --------------------------------------------------------------------------- IPA
-def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
-    """x1 = s + mask * IPA(s, z, T).  s: matrix view [R,256]."""
+def ipa_w40(P, pre, cache=None):
+    """[linear_b ; down_z] of an IPA block as one [40, 128] operand + [40] bias: a view when the two parameters lie back to
+    back (optim.FlatAdam with ScoreNetwork.flat_layout_groups()), a tiny pack otherwise (once per trajectory with a cache)."""
+    if cache is not None and ("W40", pre) in cache:
+        return cache[("W40", pre)]
+    W40 = _joined(P[f"{pre}.linear_b.weight"], P[f"{pre}.down_z.weight"], (ZB, CZ))
+    b40 = _joined(P[f"{pre}.linear_b.bias"], P[f"{pre}.down_z.bias"], (ZB,))
+    if cache is not None:
+        cache[("W40", pre)] = (W40, b40)
+    return W40, b40
+
+
+def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None):
+    """x1 = s + mask * IPA(s, z, T).  s: matrix view [R,256].  zb: [P,40] = W40 z + b40 when the kernel that produced z
+    already formed it (the previous block's fused edge transition)."""
     dev = z
     R, Pn = B * N, B * N * N
     proj = empty((R, LDP), dev)
@@ -276,22 +297,15 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None):
     # (the copy serves fd_ipa_attn_fwd/bwd only: the unfused softmax kernels and the fused pair pass read kp)
     kpT = empty((B, H, PQ * 3, N), dev) if opts.fused_ipa_attn else None
     lib().call("fd_ipa_points_fwd", proj, quat, trans, qp, kp, vp, kpT, N, R, H, C, PQ, PV)
-    if cache is not None and ("W40", pre) in cache:
-        W40, b40 = cache[("W40", pre)]
-    else:
-        # [linear_b ; down_z] as one [40, 128] operand: a view when the two parameters lie back to back (optim.FlatAdam with
-        # ScoreNetwork.flat_layout_groups()), a tiny pack otherwise
-        W40 = _joined(P[f"{pre}.linear_b.weight"], P[f"{pre}.down_z.weight"], (ZB, CZ))
-        b40 = _joined(P[f"{pre}.linear_b.bias"], P[f"{pre}.down_z.bias"], (ZB,))
-        if cache is not None:
-            cache[("W40", pre)] = (W40, b40)
+    W40, b40 = ipa_w40(P, pre, cache)
     A = empty((B, H, N, N), dev)
     L = lib()
     L.gemm(proj, proj, A, N, N, C, (LDP, 1), (1, LDP), N, b_off=2048, batch=B * H, bdiv=H,
            a_bs=(N * LDP, C), b_bs=(N * LDP, 2 * C), c_bs=(H * N * N, N * N), alpha=math.sqrt(1.0 / (3 * C)))
     feats = empty((R, LDF), dev)
-    zb = empty((Pn, ZB), dev)
-    ops.linear(mv(z), mv(W40), b40, mv(zb), Pn, ZB, CZ)
+    if zb is None:
+        zb = empty((Pn, ZB), dev)
+        ops.linear(mv(z), mv(W40), b40, mv(zb), Pn, ZB, CZ)
     fused_attn = opts.fused_ipa_attn
     if fused_attn:
         # logits + softmax (A in place) + o_pair (the pair part of feats) of every query row in one launch

@@ -324,14 +324,18 @@ def feature_tables(device, index_embed_size=32, num_bins=22, min_bin=1e-5, max_b
 # ---------------------------------------------------------------------------
 # fused edge transition (csrc/fd_edge_mlp.hip)
 # ---------------------------------------------------------------------------
-def edge_mlp_pack(W1, W2, Wf, backward=False, out=None):
+def edge_mlp_pack(W1, W2, Wf, backward=False, out=None, W40=None):
     """Pack the edge-transition weights (trunk.0 [384,384], trunk.2 [384,384], final_layer [128,384]) into the bf16-plane
-    image fd_edge_mlp streams.  backward=True packs the transposes (dX chain)."""
+    image fd_edge_mlp streams.  backward=True packs the transposes (dX chain).  W40 [40,128] (forward only): the next IPA
+    block's [linear_b ; down_z] as a fourth layer (edge_mlp(..., zb_out=, zb_bias=))."""
     img = out if out is not None else torch.empty(hip.EDGE_MLP_IMAGE_BYTES, dtype=torch.uint8, device=W1.device)
     ld = 384
     if not backward:
         # A1 = W1[:, :128], A2 = W2, A3 = Wf[:, :128], A4 = Wf
         lib().call("fd_edge_mlp_pack", W1, ld, 1, W2, ld, 1, Wf, ld, 1, Wf, ld, 1, img)
+        if W40 is not None:
+            assert W40.is_contiguous() and tuple(W40.shape) == (40, 128)
+            lib().call("fd_edge_mlp_pack_zb", W40, img)
     else:
         # A1 = Wf^T [384,128], A2 = W2^T, A3 = Wf[:, :128]^T, A4 = W1[:, :128]^T [128,384]
         lib().call("fd_edge_mlp_pack", Wf, 1, ld, W2, 1, ld, Wf, 1, ld, W1, 1, ld, img)
@@ -340,12 +344,13 @@ def edge_mlp_pack(W1, W2, Wf, backward=False, out=None):
 
 def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, qf=None, gamma=None, beta=None,
              rowscale=None, gate1=None, gate2=None, save1=None, save2=None, y=None, mean=None, rstd=None,
-             backward=False, blocks=0, ld_pq=0, ld_pqf=0):
+             backward=False, blocks=0, ld_pq=0, ld_pqf=0, zb_out=None, zb_bias=None):
     d = hip.FdEdgeMlpDesc()
     tens = []
     for name, t in (("x", x), ("img", img), ("p1", p1), ("q1", q1), ("bias2", bias2), ("gate1", gate1), ("gate2", gate2),
                     ("save1", save1), ("save2", save2), ("pf", pf), ("qf", qf), ("gamma", gamma), ("beta", beta),
-                    ("rowscale", rowscale), ("y", y), ("mean", mean), ("rstd", rstd), ("out", out)):
+                    ("rowscale", rowscale), ("y", y), ("mean", mean), ("rstd", rstd), ("out", out), ("zb_out", zb_out),
+                    ("zb_bias", zb_bias)):
         setattr(d, name, None if t is None else t.data_ptr())
         if t is not None:
             tens.append(t)
@@ -362,7 +367,8 @@ def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, 
         e0.record()
         L._check(L.cdll.fd_edge_mlp(hip.ctypes.byref(d), stream), "fd_edge_mlp")
         e1.record()
-        prof.append((7, True, True, 2.0 * int(rows) * 262144, e0, e1, (int(rows), 128, 384, 1, int(bool(backward)), 0, 0, 1)))
+        prof.append((7, True, True, 2.0 * int(rows) * (262144 + (5120 if zb_out is not None else 0)), e0, e1,
+                     (int(rows), 128, 384, 1, int(bool(backward)), 0, 0, 1)))
         return
     L._check(L.cdll.fd_edge_mlp(hip.ctypes.byref(d), stream), "fd_edge_mlp")
 
@@ -370,19 +376,23 @@ def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, 
 # ---------------------------------------------------------------------------
 # fused edge embedder (csrc/fd_edge_embed.hip)
 # ---------------------------------------------------------------------------
-def edge_embed_pack(W0, W2, W4, out=None):
+def edge_embed_pack(W0, W2, W4, out=None, W40=None):
     img = out if out is not None else torch.empty(hip.EDGE_EMBED_IMAGE_BYTES, dtype=torch.uint8, device=W0.device)
     lib().call("fd_edge_embed_pack", W0, W2, W4, img)
+    if W40 is not None:
+        assert W40.is_contiguous() and tuple(W40.shape) == (40, 128)
+        lib().call("fd_edge_embed_pack_zb", W40, img)
     return img
 
 
 def edge_embed(seq_idx, sc_ca, idenom, dg_lower, dg_upper, img, p, q, bias2, bias3, gamma, beta, out, rows, nres, *,
-               rowscale=None, h1=None, h2=None, h3=None, mean=None, rstd=None, blocks=0):
+               rowscale=None, h1=None, h2=None, h3=None, mean=None, rstd=None, blocks=0, zb_out=None, zb_bias=None):
     d = hip.FdEdgeEmbedDesc()
     tens = []
     for name, t in (("seq_idx", seq_idx), ("sc_ca", sc_ca), ("idenom", idenom), ("dg_lower", dg_lower), ("dg_upper", dg_upper),
                     ("img", img), ("p", p), ("q", q), ("bias2", bias2), ("bias3", bias3), ("gamma", gamma), ("beta", beta),
-                    ("rowscale", rowscale), ("h1", h1), ("h2", h2), ("h3", h3), ("mean", mean), ("rstd", rstd), ("out", out)):
+                    ("rowscale", rowscale), ("h1", h1), ("h2", h2), ("h3", h3), ("mean", mean), ("rstd", rstd), ("out", out),
+                    ("zb_out", zb_out), ("zb_bias", zb_bias)):
         setattr(d, name, None if t is None else t.data_ptr())
         if t is not None:
             tens.append(t)

@@ -46,14 +46,14 @@ def bb_update_bwd(P, G, b, sv, dq2, dt2, dframe, dn3):
 
 
 # --------------------------------------------------------------------------- edge transition
-def _edge_mlp_image(P, pre, cache, backward=False):
+def _edge_mlp_image(P, pre, cache, backward=False, W40=None):
     """bf16-plane weight image of the fused kernel: packed once per forward in training (the weights change every
-    step), once per trajectory in sampling (cache)."""
-    key = ("et_img", pre, backward)
+    step), once per trajectory in sampling (cache).  W40: the next IPA block's [linear_b ; down_z] (fourth layer)."""
+    key = ("et_img", pre, backward, W40 is not None)
     if cache is not None and key in cache:
         return cache[key]
     img = ops.edge_mlp_pack(P[f"{pre}.trunk.0.weight"], P[f"{pre}.trunk.2.weight"], P[f"{pre}.final_layer.weight"],
-                            backward=backward)
+                            backward=backward, W40=W40)
     if cache is not None:
         cache[key] = img
     return img
@@ -64,11 +64,13 @@ def fused_edge():
     return opts.fused_edge and not lib().exact_f32
 
 
-def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None):
+def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None, zb_next=None):
     """z' = emask * LN(W_f (relu(W_2 relu(W_1 x)) + x) + b_f), x = [z | e_i | e_j], e = W_init n3 -- the whole pair-level
-    chain in ONE launch (fd_edge_mlp): h1 / h2 never reach HBM unless the backward needs them (save)."""
+    chain in ONE launch (fd_edge_mlp): h1 / h2 never reach HBM unless the backward needs them (save).
+    zb_next = (W40 [40,128], b40 [40]) of the next block's IPA: its pair projection zb = W40 z' + b40 is formed by the same
+    launch from z' in registers.  Returns (z', saved, zb or None)."""
     if not fused_edge():
-        return edge_transition_fwd_unfused(P, b, n3, z, emask, B, N)
+        return edge_transition_fwd_unfused(P, b, n3, z, emask, B, N) + (None,)
     pre = f"score_model.trunk.edge_transition_{b}"
     dev = z
     R, Pn = B * N, B * N * N
@@ -105,17 +107,23 @@ def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None):
         ops.linear(mv(e), (W1, CZ + CE, EH), P[f"{pre}.trunk.0.bias"], mv(Q1), R, EH, CE)
         ops.linear(mv(e), (Wf, CZ, EH), None, mv(Pf), R, CZ, CE)
         ops.linear(mv(e), (Wf, CZ + CE, EH), P[f"{pre}.final_layer.bias"], mv(Qf), R, CZ, CE)
-    img = _edge_mlp_image(P, pre, cache)
+    zb = None
+    use_zb = (opts.zb_from_edge and zb_next is not None and zb_next[0].is_contiguous() and zb_next[0].data_ptr() % 16 == 0
+              and zb_next[1].data_ptr() % 16 == 0)
+    img = _edge_mlp_image(P, pre, cache, W40=zb_next[0] if use_zb else None)
     z2 = empty((Pn, CZ), dev)
     if save:
         h1 = empty((Pn, EH), dev); h2 = empty((Pn, EH), dev); y = empty((Pn, CZ), dev)
         mean = empty((Pn,), dev); rstd = empty((Pn,), dev)
         kw = dict(save1=h1, save2=h2, y=y, mean=mean, rstd=rstd)
+    if use_zb:
+        zb = empty((Pn, nw.ZB), dev)
+        kw.update(zb_out=zb, zb_bias=zb_next[1])
     ops.edge_mlp(z, img, z2, Pn, N, p1=P1, q1=Q1, bias2=P[f"{pre}.trunk.2.bias"], pf=Pf, qf=Qf,
                  gamma=P[f"{pre}.layer_norm.weight"], beta=P[f"{pre}.layer_norm.bias"], rowscale=emask, **kw)
     if not save:
-        return z2, None
-    return z2, dict(n3=n3, z=z, e=e, h1=h1, h2=h2, y=y, mean=mean, rstd=rstd, emask=emask, B=B, N=N)
+        return z2, None, zb
+    return z2, dict(n3=n3, z=z, e=e, h1=h1, h2=h2, y=y, mean=mean, rstd=rstd, emask=emask, B=B, N=N), zb
 
 
 def edge_transition_fwd_unfused(P, b, n3, z, emask, B, N):
@@ -399,7 +407,8 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
     L.call("fd_split_rigids", rig, float(dconf[0]), f["t"] if t32 else None, 10000.0, quat, trans, tsc, R, B)
     f["tscaled"] = tsc if t32 else (f["t"] * 10000).float().contiguous()     # score_network.py:38,43
     with rng("embed.fwd"):
-        node0, z, sv_embed = nw.embed_fwd(P, f, B, N, cache, save=save)
+        node0, z, sv_embed, zb = nw.embed_fwd(P, f, B, N, cache, save=save,
+                                              zb_next=nw.ipa_w40(P, "score_model.trunk.ipa_0", cache) if num_blocks > 0 else None)
     emask = sv_embed["emask"]
 
     def _dmask():
@@ -418,7 +427,7 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
     for b in range(num_blocks):
         pre = f"score_model.trunk.ipa_{b}"
         with rng(f"ipa_{b}.fwd"):
-            x1, sv_ipa = nw.ipa_fwd(P, pre, mv(node), z, quat, trans, mask.view(-1), B, N, cache)
+            x1, sv_ipa = nw.ipa_fwd(P, pre, mv(node), z, quat, trans, mask.view(-1), B, N, cache, zb=zb)
         with rng(f"seq_tfmr_{b}.fwd"):
             u, sv_ln = nw.ln_skip_fwd(P, b, x1, init_node, R)
             u0 = u
@@ -436,7 +445,8 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
         sv_et = None
         if b < num_blocks - 1:
             with rng(f"edge_transition_{b}.fwd"):
-                z, sv_et = edge_transition_fwd(P, b, n3, z, emask, B, N, save=save, cache=cache)
+                z, sv_et, zb = edge_transition_fwd(P, b, n3, z, emask, B, N, save=save, cache=cache,
+                                                   zb_next=nw.ipa_w40(P, f"score_model.trunk.ipa_{b + 1}", cache))
         stages.append(dict(ipa=sv_ipa, ln=sv_ln, tfmr=sv_t, pn=sv_pn, bb=sv_bb, et=sv_et))
         node, quat, trans = n3, q2, t2
         if not save:

@@ -55,6 +55,19 @@ def _run(dev, B, N, seed=0, blocks=0):
     ops.edge_mlp(t["z"], img, out2, P, N, p1=t["P1"], q1=t["Q1"], bias2=t["b2"], pf=t["Pf"], qf=t["Qf"], gamma=t["gamma"],
                  beta=t["beta"], rowscale=t["emask"], blocks=blocks)
     assert torch.equal(out, out2)
+    # with the fourth layer: zb = W40 out + b40 (the next IPA block's linear_b / down_z, ipa_pytorch.py:380-386,455), with
+    # and without the training saves; the other outputs are unchanged
+    gz = torch.Generator().manual_seed(seed + 100)
+    W40, b40 = (torch.randn(40, 128, generator=gz) * 0.1).to(dev), torch.randn(40, generator=gz).to(dev)
+    img4 = ops.edge_mlp_pack(t["W1"], t["W2"], t["Wf"], W40=W40)
+    for saves in (False, True):
+        out3, zb = e(P, 128), torch.full((P, 40), float("nan"), device=dev)
+        kw = dict(save1=e(P, 384), save2=e(P, 384), y=e(P, 128), mean=e(P), rstd=e(P)) if saves else {}
+        ops.edge_mlp(t["z"], img4, out3, P, N, p1=t["P1"], q1=t["Q1"], bias2=t["b2"], pf=t["Pf"], qf=t["Qf"], gamma=t["gamma"],
+                     beta=t["beta"], rowscale=t["emask"], blocks=blocks, zb_out=zb, zb_bias=b40, **kw)
+        assert torch.equal(out, out3)
+        rzb = rout @ W40.double().cpu().T + b40.double().cpu()
+        assert rel(zb, rzb) < 2e-5, rel(zb, rzb)
     # backward chain: d2 = [h2 > 0] dy Wf ; d1 = [h1 > 0] d2 W2 ; dz = dy Wf[:, :128] + d1 W1[:, :128]
     imgT = ops.edge_mlp_pack(t["W1"], t["W2"], t["Wf"], backward=True)
     dz, d2, d1 = e(P, 128), e(P, 384), e(P, 384)
