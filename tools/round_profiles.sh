@@ -3,7 +3,7 @@
 #   whole-step HBM traffic, full 500-step sampling runs.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/${1:-r02}
+O=gpurun_out/${1:-r03}
 rm -rf $O; mkdir -p $O
 timeout 120 python -m pytest tests/test_switches.py -x -q -m gpu > $O/test_switches.log 2>&1
 python bench.py > $O/bench_train.json 2> $O/bench_train.err
@@ -14,6 +14,9 @@ python bench.py --mode sample --n-res 512 --batch 8 --steps 1 --warmup 0 > $O/be
 python bench.py --mode sample --n-res 128 --batch 32 --steps 1 --warmup 0 > $O/bench_sample_n128_b32.json 2>/dev/null
 python tools/bench_edge_mlp.py --shapes 30x128,8x128,1x128,1x256,1x512 > $O/edge_mlp_microbench.log 2>&1
 python tools/bench_pair_dw.py > $O/pair_dw_microbench.log 2>&1
+python tools/bench_group_dw.py > $O/group_dw_microbench.log 2>&1
+python tools/bench_embed_bwd.py > $O/embed_bwd_microbench.log 2>&1
+python tools/bench_ipa_attn.py 30 128 > $O/ipa_attn_microbench.log 2>&1
 python tools/bench_gemm.py --only kk --iters 50 > $O/gemm_s64_microbench.log 2>&1
 # per-kernel time of the training step, launches serialised
 FD_BENCH_PROFILE=1 FD_GRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python bench.py --steps 5 --warmup 2 --no-sampling --no-cpu-baseline > $O/kt.log 2>&1
@@ -22,9 +25,8 @@ python tools/kernel_stats_md.py $O/kt/p_kernel_stats.csv "training step B=30 x N
 rocprofv3 --kernel-trace --stats -d $O/ks -o p --output-format csv -- python bench.py --mode sample --n-res 128 --batch 1 --num-t 100 --steps 1 --warmup 0 --no-graph > $O/ks.log 2>&1
 python tools/kernel_stats_md.py $O/ks/p_kernel_stats.csv "sampling N=128 B=1, 100 steps, eager launches" > $O/sample_n128_b1_kernel_stats.md
 if [ -z "$LITE" ]; then   # (LITE=1: the counter passes are skipped -- kernels unchanged since the last full run)
-bash tools/pmc_edge_mlp.sh > $O/pmc_edge_mlp.txt 2>&1
-bash tools/pmc_step.sh > $O/pmc_step.txt 2>&1
-bash tools/pmc_pair_dw.sh > $O/pmc_pair_dw.txt 2>&1
+bash tools/pmc_roofline.sh ${1:-r03} > $O/pmc_roofline.txt 2>&1      # HBM bytes per kernel of the step, calibrated -> bench.py
+bash tools/pmc_step_sq.sh > $O/pmc_step_sq.txt 2>&1                   # SQ / LDS / clock counters of the big kernels IN the step
 fi
 bash tools/prof_gap.sh > $O/step_gap.txt 2>&1
 find $O -name "*.csv" -size +512k -delete
