@@ -94,6 +94,14 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_bwd_kernel(FdEdge
     const bool rok = row < rows;
     const long rc = rok ? row : rows - 1;         // rows past the end are clamped on load, masked on store / in the sums
 
+    // packed ReLU gates (the forward's mask outputs: bit 4 nb + e of word (row, g) <-> unit 16 nb + 4 g + e), fetched up front
+    const bool packed = d.gmask2 != nullptr;
+    unsigned gm2 = 0u, gm1 = 0u;
+    if (packed) {
+      gm2 = d.gmask2[rc * 4 + g];
+      gm1 = d.gmask1[rc * 4 + g];
+    }
+
     // ---- LayerNorm backward: dh3 in the register layout of a layer output (lane (m, g): columns 16 nb + 4 g + r) ----
     f32x4 d3[8];
     {
@@ -161,11 +169,16 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_bwd_kernel(FdEdge
     }
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) {
-      const float4 h = *reinterpret_cast<const float4*>(d.h2 + rc * EB_C + 16 * nb + 4 * g);
-      a2[nb][0] = h.x > 0.f ? a2[nb][0] : 0.f;
-      a2[nb][1] = h.y > 0.f ? a2[nb][1] : 0.f;
-      a2[nb][2] = h.z > 0.f ? a2[nb][2] : 0.f;
-      a2[nb][3] = h.w > 0.f ? a2[nb][3] : 0.f;
+      if (packed) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a2[nb][e] = ((gm2 >> (4 * nb + e)) & 1u) ? a2[nb][e] : 0.f;
+      } else {
+        const float4 h = *reinterpret_cast<const float4*>(d.h2 + rc * EB_C + 16 * nb + 4 * g);
+        a2[nb][0] = h.x > 0.f ? a2[nb][0] : 0.f;
+        a2[nb][1] = h.y > 0.f ? a2[nb][1] : 0.f;
+        a2[nb][2] = h.z > 0.f ? a2[nb][2] : 0.f;
+        a2[nb][3] = h.w > 0.f ? a2[nb][3] : 0.f;
+      }
       if (rok)
         *reinterpret_cast<float4*>(d.dh2 + row * EB_C + 16 * nb + 4 * g) = make_float4(a2[nb][0], a2[nb][1], a2[nb][2], a2[nb][3]);
     }
@@ -192,11 +205,16 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_bwd_kernel(FdEdge
     }
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) {
-      const float4 h = *reinterpret_cast<const float4*>(d.h1 + rc * EB_C + 16 * nb + 4 * g);
-      if (rok)
-        *reinterpret_cast<float4*>(d.dh1 + row * EB_C + 16 * nb + 4 * g) =
-            make_float4(h.x > 0.f ? a1[nb][0] : 0.f, h.y > 0.f ? a1[nb][1] : 0.f, h.z > 0.f ? a1[nb][2] : 0.f,
+      float4 o;
+      if (packed) {
+        o = make_float4(((gm1 >> (4 * nb)) & 1u) ? a1[nb][0] : 0.f, ((gm1 >> (4 * nb + 1)) & 1u) ? a1[nb][1] : 0.f,
+                        ((gm1 >> (4 * nb + 2)) & 1u) ? a1[nb][2] : 0.f, ((gm1 >> (4 * nb + 3)) & 1u) ? a1[nb][3] : 0.f);
+      } else {
+        const float4 h = *reinterpret_cast<const float4*>(d.h1 + rc * EB_C + 16 * nb + 4 * g);
+        o = make_float4(h.x > 0.f ? a1[nb][0] : 0.f, h.y > 0.f ? a1[nb][1] : 0.f, h.z > 0.f ? a1[nb][2] : 0.f,
                         h.w > 0.f ? a1[nb][3] : 0.f);
+      }
+      if (rok) *reinterpret_cast<float4*>(d.dh1 + row * EB_C + 16 * nb + 4 * g) = o;
     }
   }
 
@@ -251,8 +269,9 @@ extern "C" int fd_edge_embed_bwd_pack(const float* W2, const float* W4, void* im
 extern "C" int fd_edge_embed_bwd(const FdEdgeEmbedBwdDesc* desc, void* stream) {
   FD_CHECK_ARG(desc != nullptr, "fd_edge_embed_bwd: null descriptor");
   const FdEdgeEmbedBwdDesc& d = *desc;
-  FD_CHECK_ARG(d.dy && d.h3 && d.mean && d.rstd && d.gamma && d.h2 && d.h1 && d.img && d.dh3 && d.dh2 && d.dh1,
+  FD_CHECK_ARG(d.dy && d.h3 && d.mean && d.rstd && d.gamma && d.img && d.dh3 && d.dh2 && d.dh1,
                "fd_edge_embed_bwd: a required operand is null");
+  FD_CHECK_ARG((d.h2 && d.h1) || (d.gmask2 && d.gmask1), "fd_edge_embed_bwd: h2 / h1 or their packed sign masks are required");
   FD_CHECK_ARG(d.rows >= 0, "fd_edge_embed_bwd: negative row count");
   const void* ptrs[] = {d.dy, d.h3, d.gamma, d.h2, d.h1, d.img, d.dh3, d.dh2, d.dh1};
   for (const void* p : ptrs) FD_CHECK_ARG(fd_aligned16(p), "fd_edge_embed_bwd: operands must be 16-byte aligned");

@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void edge_mlp_pack_zb_kernel(const float* __re
 // ZB (forward only): a fourth chained layer on the kernel's own output -- zb = [linear_b ; down_z] z' + b40 of the next
 // trunk block's IPA -- so that block needs no pass over z' [P,128] for it (fd_gemm: 119 us per block at B=30 x N=128, 252 MB
 // read); +3 % of the chain's MFMAs, 160 B more written per pair row
-template <bool BWD, bool ZB = false>
+// MASK (forward, training): also write the packed signs of h1 / h2 for the backward's gates
+template <bool BWD, bool ZB = false, bool MASK = false>
 __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpDesc d) {
   constexpr int EM_NSTAGE = (EM_UNITS + (ZB ? EM_ZB_UNITS : 0)) / EM_UPS;
   __shared__ __attribute__((aligned(16))) char lds[EM_RING * EM_STAGE];
@@ -195,6 +196,18 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
       }
     }
 
+    // backward with packed ReLU gates (gmask1 / gmask2: the forward's mask2 / mask1 outputs): bit 4 nb + e of word (row, chunk c,
+    // g) says whether hidden unit 128 c + 16 nb + 4 g + e was positive -- 6 dwords per lane and tile, fetched here, instead of
+    // 3 KB of h2 / h1 per row fetched (and waited for) inside the epilogues
+    unsigned gm1[3] = {0u, 0u, 0u}, gm2[3] = {0u, 0u, 0u};
+    const bool packed_gates = BWD && d.gmask1 != nullptr;
+    if (packed_gates) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gm1[c] = d.gmask1[rc * 12 + 4 * c + g];
+        gm2[c] = d.gmask2[rc * 12 + 4 * c + g];
+      }
+    }
     uint4 b[3];          // activation planes (B operand) of the current k-step
     Em16Half H[2];       // fragments of the current / next half-unit
     f32x4 acc2[24];
@@ -228,6 +241,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
         }
       }
       // epilogue 1: forward  h1 = relu(acc + P1_i + Q1_j);  backward  d2 = acc gated by h2 > 0
+      unsigned bits1 = 0u;
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) {
         const int col = 128 * c + 16 * nb + 4 * g;
@@ -239,7 +253,13 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
           const float4 bq = *reinterpret_cast<const float4*>(d.q1 + qj * ld_pq + col);
           v[0] += a.x + bq.x; v[1] += a.y + bq.y; v[2] += a.z + bq.z; v[3] += a.w + bq.w;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          for (int e = 0; e < 4; ++e) {
+            if (MASK) bits1 |= (v[e] > 0.f ? 1u : 0u) << (4 * nb + e);
+            v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+        } else if (packed_gates) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ((gm1[c] >> (4 * nb + e)) & 1u) ? v[e] : 0.f;
         } else {
           const float4 gt = *reinterpret_cast<const float4*>(d.gate1 + rc * EM_H + col);
           v[0] = gt.x > 0.f ? v[0] : 0.f; v[1] = gt.y > 0.f ? v[1] : 0.f;
@@ -250,6 +270,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
         if (d.save1 != nullptr && rok)
           *reinterpret_cast<float4*>(d.save1 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
       }
+      if (!BWD && MASK && rok) d.mask1[row * 12 + 4 * c + g] = bits1;
       // ---- layer 2, k in chunk c: units (k-step u2 / 6, n-group u2 % 6) ----
 #pragma clang loop unroll(full)
       for (int sg = 0; sg < 24 / EM_UPS; ++sg) {
@@ -268,6 +289,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
     }
 
     // epilogue 2: forward  h2 = relu(acc2);  backward  d1 = acc2 gated by h1 > 0
+    unsigned bits2 = 0u;
 #pragma unroll
     for (int nb = 0; nb < 24; ++nb) {
       const int col = 16 * nb + 4 * g;
@@ -276,7 +298,13 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
       for (int e = 0; e < 4; ++e) v[e] = acc2[nb][e];
       if (!BWD) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          if (MASK) bits2 |= (v[e] > 0.f ? 1u : 0u) << (4 * (nb & 7) + e);
+          v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+      } else if (packed_gates) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((gm2[nb >> 3] >> (4 * (nb & 7) + e)) & 1u) ? v[e] : 0.f;
       } else {
         const float4 gt = *reinterpret_cast<const float4*>(d.gate2 + rc * EM_H + col);
         v[0] = gt.x > 0.f ? v[0] : 0.f; v[1] = gt.y > 0.f ? v[1] : 0.f;
@@ -286,6 +314,10 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
       for (int e = 0; e < 4; ++e) acc2[nb][e] = v[e];
       if (d.save2 != nullptr && rok)
         *reinterpret_cast<float4*>(d.save2 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
+      if (!BWD && MASK && (nb & 7) == 7) {
+        if (rok) d.mask2[row * 12 + 4 * (nb >> 3) + g] = bits2;
+        bits2 = 0u;
+      }
     }
 
     // ---- layer 3: 128 outputs x (K = 128 of x, then K = 384 of the hidden layer) ----
@@ -440,7 +472,8 @@ extern "C" int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream) {
   FD_CHECK_ARG(d.x && d.img && d.out, "fd_edge_mlp: x / img / out are required");
   FD_CHECK_ARG(d.nres > 0 && d.rows >= 0, "fd_edge_mlp: bad extents");
   if (d.backward) {
-    FD_CHECK_ARG(d.gate1 && d.gate2, "fd_edge_mlp(backward): the saved activations h2 (gate1) and h1 (gate2) are required");
+    FD_CHECK_ARG((d.gate1 && d.gate2) || (d.gmask1 && d.gmask2),
+                 "fd_edge_mlp(backward): the saved activations h2 (gate1) and h1 (gate2), or their packed sign masks, are required");
   } else {
     FD_CHECK_ARG(d.p1 && d.q1 && d.bias2 && d.pf && d.qf && d.gamma && d.beta,
                  "fd_edge_mlp(forward): p1 / q1 / bias2 / pf / qf / gamma / beta are required");
@@ -454,12 +487,21 @@ extern "C" int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream) {
   const int grid = (int)(ntiles < blocks ? ntiles : blocks);
   FD_CHECK_ARG(d.zb_out == nullptr || (!d.backward && fd_aligned16(d.zb_out) && fd_aligned16(d.zb_bias)),
                "fd_edge_mlp: zb_out is a forward output (16-byte aligned; the image must carry the fd_edge_mlp_pack_zb units)");
+  FD_CHECK_ARG((d.mask1 == nullptr) == (d.mask2 == nullptr) && (d.gmask1 == nullptr) == (d.gmask2 == nullptr),
+               "fd_edge_mlp: mask1 / mask2 (forward) and gmask1 / gmask2 (backward) come in pairs");
+  const dim3 g3(grid), b3(64 * EM_WAVES);
+  hipStream_t st = (hipStream_t)stream;
+  const bool zbv = d.zb_out != nullptr, mk = d.mask1 != nullptr;
   if (d.backward)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false>), dim3(grid), dim3(64 * EM_WAVES), 0, (hipStream_t)stream, d);
-  else if (d.zb_out != nullptr)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true>), dim3(grid), dim3(64 * EM_WAVES), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false>), g3, b3, 0, st, d);
+  else if (zbv && mk)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true, true>), g3, b3, 0, st, d);
+  else if (zbv)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true, false>), g3, b3, 0, st, d);
+  else if (mk)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, false, true>), g3, b3, 0, st, d);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, false>), dim3(grid), dim3(64 * EM_WAVES), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, false, false>), g3, b3, 0, st, d);
   FD_CHECK_LAUNCH("fd_edge_mlp");
   return FD_OK;
 }

@@ -86,6 +86,7 @@ class FdEdgeMlpDesc(Structure):
         ("y", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("out", c_void_p),
         ("rows", c_long), ("nres", c_int), ("backward", c_int), ("eps", c_float), ("blocks", c_int),
         ("ld_pq", c_long), ("ld_pqf", c_long), ("zb_out", c_void_p), ("zb_bias", c_void_p),
+        ("mask1", c_void_p), ("mask2", c_void_p), ("gmask1", c_void_p), ("gmask2", c_void_p),
     ]
 
 
@@ -99,6 +100,7 @@ class FdEdgeEmbedDesc(Structure):
         ("gamma", c_void_p), ("beta", c_void_p), ("rowscale", c_void_p),
         ("h1", c_void_p), ("h2", c_void_p), ("h3", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("out", c_void_p),
         ("rows", c_long), ("nres", c_int), ("eps", c_float), ("blocks", c_int), ("zb_out", c_void_p), ("zb_bias", c_void_p),
+        ("mask1", c_void_p), ("mask2", c_void_p),
     ]
 
 
@@ -109,7 +111,7 @@ class FdEdgeEmbedBwdDesc(Structure):
     _fields_ = [
         ("dy", c_void_p), ("h3", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("gamma", c_void_p), ("rowscale", c_void_p),
         ("h2", c_void_p), ("h1", c_void_p), ("img", c_void_p), ("dh3", c_void_p), ("dh2", c_void_p), ("dh1", c_void_p),
-        ("dgamma", c_void_p), ("dbeta", c_void_p), ("rows", c_long), ("blocks", c_int),
+        ("dgamma", c_void_p), ("dbeta", c_void_p), ("rows", c_long), ("blocks", c_int), ("gmask2", c_void_p), ("gmask1", c_void_p),
     ]
 
 

@@ -152,6 +152,9 @@ def embed_fwd(P, feats, B, N, cache=None, save=True, zb_next=None):
         h1 = empty((Pn, CZ), dev); h2 = empty((Pn, CZ), dev); h3 = empty((Pn, CZ), dev)
         mean = empty((Pn,), dev); rstd = empty((Pn,), dev)
         kw.update(h1=h1, h2=h2, h3=h3, mean=mean, rstd=rstd)
+        if opts.packed_gates:
+            mh1 = empty((Pn, 4), dev, torch.int32); mh2 = empty((Pn, 4), dev, torch.int32)
+            kw.update(mask1=mh1, mask2=mh2)
     ops.edge_embed(seq, feats["sc_ca_t"], idenom, lower, upper, img, p_, q_, P[f"{pre}.2.bias"], P[f"{pre}.4.bias"],
                    P[f"{pre}.5.weight"], P[f"{pre}.5.bias"], edge, Pn, N, rowscale=emask, **kw)
     sv_e = None
@@ -159,6 +162,7 @@ def embed_fwd(P, feats, B, N, cache=None, save=True, zb_next=None):
         # the backward is the unfused MLP backward; its first-layer weight gradient needs the [P,120] feature tensor,
         # which is regenerated there (embed_bwd) instead of being kept alive through the whole step
         sv_e = dict(x=None, h1=h1, h2=h2, h3=h3, mean=mean, rstd=rstd, rowscale=emask, M=Pn, K0=120, C=CZ,
+                    mh1=kw.get("mask1"), mh2=kw.get("mask2"),
                     regen=(seq, tscaled, fixed, feats["sc_ca_t"], B, N))
     return node, edge, dict(node=sv_n, edge=sv_e, emask=emask), zb
 
@@ -200,7 +204,7 @@ def embed_bwd(P, G, sv, dnode, dedge):
         dh3 = empty((M, CZ), dedge); dh2 = empty((M, CZ), dedge); dh1 = empty((M, CZ), dedge)
         img = ops.edge_embed_bwd_pack(P[f"{pre}.2.weight"], P[f"{pre}.4.weight"])
         ops.edge_embed_bwd(dedge, se["h3"], se["mean"], se["rstd"], P[f"{pre}.5.weight"], se["rowscale"], se["h2"], se["h1"], img,
-                           dh3, dh2, dh1, G[f"{pre}.5.weight"], G[f"{pre}.5.bias"], M)
+                           dh3, dh2, dh1, G[f"{pre}.5.weight"], G[f"{pre}.5.bias"], M, gmask2=se.get("mh2"), gmask1=se.get("mh1"))
         x = se["x"]
         items = [(mv(dh3), mv(se["h2"]), mv(G[f"{pre}.4.weight"]), G[f"{pre}.4.bias"], CZ, CZ),
                  (mv(dh2), mv(se["h1"]), mv(G[f"{pre}.2.weight"]), G[f"{pre}.2.bias"], CZ, CZ),

@@ -344,13 +344,14 @@ def edge_mlp_pack(W1, W2, Wf, backward=False, out=None, W40=None):
 
 def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, qf=None, gamma=None, beta=None,
              rowscale=None, gate1=None, gate2=None, save1=None, save2=None, y=None, mean=None, rstd=None,
-             backward=False, blocks=0, ld_pq=0, ld_pqf=0, zb_out=None, zb_bias=None):
+             backward=False, blocks=0, ld_pq=0, ld_pqf=0, zb_out=None, zb_bias=None, mask1=None, mask2=None, gmask1=None,
+             gmask2=None):
     d = hip.FdEdgeMlpDesc()
     tens = []
     for name, t in (("x", x), ("img", img), ("p1", p1), ("q1", q1), ("bias2", bias2), ("gate1", gate1), ("gate2", gate2),
                     ("save1", save1), ("save2", save2), ("pf", pf), ("qf", qf), ("gamma", gamma), ("beta", beta),
                     ("rowscale", rowscale), ("y", y), ("mean", mean), ("rstd", rstd), ("out", out), ("zb_out", zb_out),
-                    ("zb_bias", zb_bias)):
+                    ("zb_bias", zb_bias), ("mask1", mask1), ("mask2", mask2), ("gmask1", gmask1), ("gmask2", gmask2)):
         setattr(d, name, None if t is None else t.data_ptr())
         if t is not None:
             tens.append(t)
@@ -386,13 +387,14 @@ def edge_embed_pack(W0, W2, W4, out=None, W40=None):
 
 
 def edge_embed(seq_idx, sc_ca, idenom, dg_lower, dg_upper, img, p, q, bias2, bias3, gamma, beta, out, rows, nres, *,
-               rowscale=None, h1=None, h2=None, h3=None, mean=None, rstd=None, blocks=0, zb_out=None, zb_bias=None):
+               rowscale=None, h1=None, h2=None, h3=None, mean=None, rstd=None, blocks=0, zb_out=None, zb_bias=None, mask1=None,
+               mask2=None):
     d = hip.FdEdgeEmbedDesc()
     tens = []
     for name, t in (("seq_idx", seq_idx), ("sc_ca", sc_ca), ("idenom", idenom), ("dg_lower", dg_lower), ("dg_upper", dg_upper),
                     ("img", img), ("p", p), ("q", q), ("bias2", bias2), ("bias3", bias3), ("gamma", gamma), ("beta", beta),
                     ("rowscale", rowscale), ("h1", h1), ("h2", h2), ("h3", h3), ("mean", mean), ("rstd", rstd), ("out", out),
-                    ("zb_out", zb_out), ("zb_bias", zb_bias)):
+                    ("zb_out", zb_out), ("zb_bias", zb_bias), ("mask1", mask1), ("mask2", mask2)):
         setattr(d, name, None if t is None else t.data_ptr())
         if t is not None:
             tens.append(t)
@@ -418,12 +420,14 @@ def edge_embed_bwd_pack(W2, W4, out=None):
     return img
 
 
-def edge_embed_bwd(dy, h3, mean, rstd, gamma, rowscale, h2, h1, img, dh3, dh2, dh1, dgamma, dbeta, rows, blocks=0):
+def edge_embed_bwd(dy, h3, mean, rstd, gamma, rowscale, h2, h1, img, dh3, dh2, dh1, dgamma, dbeta, rows, blocks=0, gmask2=None,
+                   gmask1=None):
     """The edge embedder's LayerNorm backward + dX chain in one launch (csrc/fd_edge_embed_bwd.hip)."""
     d = hip.FdEdgeEmbedBwdDesc()
     tens = []
     for name, t in (("dy", dy), ("h3", h3), ("mean", mean), ("rstd", rstd), ("gamma", gamma), ("rowscale", rowscale), ("h2", h2),
-                    ("h1", h1), ("img", img), ("dh3", dh3), ("dh2", dh2), ("dh1", dh1), ("dgamma", dgamma), ("dbeta", dbeta)):
+                    ("h1", h1), ("img", img), ("dh3", dh3), ("dh2", dh2), ("dh1", dh1), ("dgamma", dgamma), ("dbeta", dbeta),
+                    ("gmask2", gmask2), ("gmask1", gmask1)):
         setattr(d, name, None if t is None else t.data_ptr())
         if t is not None:
             tens.append(t)

@@ -40,6 +40,7 @@ class Options:
     grouped_pair_dw: bool = True      # FD_PAIR_DW: the edge transition's pair-row weight gradients in one grouped launch
     pair_dw_blocks: int = 160         # FD_PAIR_DW_BLOCKS: blocks of fd_pair_dw when it runs beside the main stream (0 = 256)
     edge_blocks: int = 0              # FD_EDGE_BLOCKS: persistent blocks of the fused edge kernels (0 = 512)
+    packed_gates: bool = True         # FD_PACKED_GATES: the fused edge backward gates on packed sign bits instead of reading h1 / h2
     zb_from_edge: bool = True         # FD_ZB_FUSED: the next IPA block's pair projection zb as a 4th layer of fd_edge_mlp
     fold_node_terms: bool = True      # FD_FOLD_NODE_TERMS: sampling -- per-residue terms of an edge transition as one GEMM
     # -- IPA
@@ -63,7 +64,7 @@ class Options:
             fused_edge=_flag("FD_EDGE_FUSED", True), fused_embed=_flag("FD_EMBED_FUSED", True),
             fused_embed_bwd=_flag("FD_EMBED_BWD_FUSED", True),
             grouped_pair_dw=_flag("FD_PAIR_DW", True), pair_dw_blocks=_int("FD_PAIR_DW_BLOCKS", 160),
-            edge_blocks=_int("FD_EDGE_BLOCKS", 0), zb_from_edge=_flag("FD_ZB_FUSED", True), fold_node_terms=_flag("FD_FOLD_NODE_TERMS", True),
+            edge_blocks=_int("FD_EDGE_BLOCKS", 0), zb_from_edge=_flag("FD_ZB_FUSED", True), packed_gates=_flag("FD_PACKED_GATES", True), fold_node_terms=_flag("FD_FOLD_NODE_TERMS", True),
             fused_ipa_attn=_flag("FD_IPA_ATTN_FUSED", True), flash_ipa=_flag("FD_IPA_FLASH", True),
             proj_merge=_flag("FD_PROJ_MERGE", True),
             fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),

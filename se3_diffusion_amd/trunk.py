@@ -116,6 +116,10 @@ def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None, zb_next
         h1 = empty((Pn, EH), dev); h2 = empty((Pn, EH), dev); y = empty((Pn, CZ), dev)
         mean = empty((Pn,), dev); rstd = empty((Pn,), dev)
         kw = dict(save1=h1, save2=h2, y=y, mean=mean, rstd=rstd)
+        if opts.packed_gates:
+            # sign bits of h1 / h2 (48 B per row each) for the backward's ReLU gates: its dX kernel then reads no h1 / h2
+            mh1 = empty((Pn, 12), dev, torch.int32); mh2 = empty((Pn, 12), dev, torch.int32)
+            kw.update(mask1=mh1, mask2=mh2)
     if use_zb:
         zb = empty((Pn, nw.ZB), dev)
         kw.update(zb_out=zb, zb_bias=zb_next[1])
@@ -123,7 +127,8 @@ def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None, zb_next
                  gamma=P[f"{pre}.layer_norm.weight"], beta=P[f"{pre}.layer_norm.bias"], rowscale=emask, **kw)
     if not save:
         return z2, None, zb
-    return z2, dict(n3=n3, z=z, e=e, h1=h1, h2=h2, y=y, mean=mean, rstd=rstd, emask=emask, B=B, N=N), zb
+    return z2, dict(n3=n3, z=z, e=e, h1=h1, h2=h2, y=y, mean=mean, rstd=rstd, emask=emask, B=B, N=N,
+                    mh1=kw.get("mask1"), mh2=kw.get("mask2")), zb
 
 
 def edge_transition_fwd_unfused(P, b, n3, z, emask, B, N):
@@ -192,8 +197,8 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
         # the dX chain in one launch: d2 = [h2 > 0] dy Wf, d1 = [h1 > 0] d2 W2, dz = dy Wf_z + d1 W1_z (fd_edge_mlp with
         # the transposed weight image); d2 / d1 are written once, for the weight-gradient GEMMs and the pair reductions
         dh2 = empty((Pn, EH), dev); dh1 = empty((Pn, EH), dev)
-        ops.edge_mlp(dy, _edge_mlp_image(P, pre, None, backward=True), dz, Pn, N, gate1=h2, gate2=h1, save1=dh2,
-                     save2=dh1, backward=True)
+        gk = dict(gmask1=sv["mh2"], gmask2=sv["mh1"]) if sv.get("mh1") is not None else dict(gate1=h2, gate2=h1)
+        ops.edge_mlp(dy, _edge_mlp_image(P, pre, None, backward=True), dz, Pn, N, save1=dh2, save2=dh1, backward=True, **gk)
         if grouped_dw:
             # every pair-row weight gradient of the transition in ONE grouped launch (fd_pair_dw): dW2 = d2^T h1 as three
             # 384 x 128 tiles (+ its bias gradient), dW1[:, z part] = d1^T z, dWf = dy^T (h2 + [z | 0]) stored transposed

@@ -42,6 +42,20 @@ def _run(dev, rows, seed=0, blocks=0, mask=True):
     for k, w in want.items():
         err = float((got[k].double().cpu() - w).abs().max() / w.abs().max())
         assert err < 2e-5, (k, err, rows, blocks)
+    # the same with the ReLU gates as packed sign bits (fd_edge_embed's mask outputs: bit 4 nb + e of word (row, g) <-> unit
+    # 16 nb + 4 g + e) instead of reads of h2 / h1: bit-identical
+    unit = torch.arange(C)
+    nb, gg, ee = unit // 16, (unit % 16) // 4, unit % 4
+    def pack(h):
+        w = torch.zeros(rows, 4, dtype=torch.int64)
+        for u in range(C):
+            w[:, gg[u]] |= (h[:, u] > 0).long() << int(4 * nb[u] + ee[u])
+        return (w & 0xFFFFFFFF).to(torch.int64).apply_(lambda v: v - (1 << 32) if v >= (1 << 31) else v).to(torch.int32).to(dev)
+    p3, p2, p1 = (torch.full((rows, C), float("nan"), device=dev) for _ in range(3))
+    dg2, db2 = to(dgam0.clone()), to(dbet0.clone())
+    ops.edge_embed_bwd(to(dy), to(h3), to(mean), to(rstd), to(gamma), to(rowscale), None, None, img, p3, p2, p1, dg2, db2, rows,
+                       blocks=blocks, gmask2=pack(h2), gmask1=pack(h1))
+    assert torch.equal(p3, o3) and torch.equal(p2, o2) and torch.equal(p1, o1)
 
 
 def test_edge_embed_bwd_emu(use_emu):

@@ -53,6 +53,7 @@ GROUPS = [
     (dict(grouped_node_dw=False), 5e-5),
     (dict(fused_embed_bwd=False), 5e-5),
     (dict(zb_from_edge=False), 5e-5),
+    (dict(packed_gates=False), 5e-5),
     (dict(fused_edge=False, fused_embed=False), 2e-4),
 ]
 
@@ -88,4 +89,4 @@ def test_options_override_restores():
 @pytest.mark.gpu
 def test_switches_gpu(hip_lib):
     _compare("cuda", B=2, N=24, blocks=2)
-    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:3] + GROUPS[4:7])
+    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:3] + GROUPS[4:8])
