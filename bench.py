@@ -168,14 +168,14 @@ _KERNELS = {
 # power-limited; 2.22 on zeros): the practical ceiling of the split-bf16 kernels is 1760 / 6 TFLOP/s of algorithmic fp32 flops
 SUSTAINED_SPLIT_PEAK = round(1760.0 / 6.0, 1)
 # profile tile code -> kernel-name prefix in rocprofv3's tables (tools/pmc_roofline.py keys its JSON by them)
-_PMC_NAMES = {7: ("edge_mlp16_kernel<false>", "edge_mlp16_kernel<true>"), 9: ("pair_dw_kernel",), 11: ("group_dw_kernel",),
+_PMC_NAMES = {7: ("edge_mlp16_kernel<false", "edge_mlp16_kernel<true"), 9: ("pair_dw_kernel",), 11: ("group_dw_kernel",),
               8: ("edge_embed_kernel",), 4: ("gemm_bx3p_kernel", "gemm_bx3_kernel<256"), 6: ("gemm_bx3_kernel<128",),
               10: ("gemm_s64_kernel",), 2: ("gemm_kernel<64, 64",), 1: ("gemm_kernel<128, 128",), 3: ("gemm_kernel<128, 32",),
               5: ("gemm_direct_kernel",)}
 # algorithmic HBM bytes per pair row of the fused edge-transition launches in TRAINING: forward reads z
-# (512 B) and writes z' (512), the saves h1, h2 (2 x 1536), y (512) and mean / rstd (8); backward reads dy (512) and the gates h2,
-# h1 (3072), writes d2, d1 (3072) and dz (512)
-_EDGE_ALGO_BYTES = {"edge_mlp16_kernel<false>": 512 + 512 + 3072 + 512 + 8, "edge_mlp16_kernel<true>": 512 + 3072 + 3072 + 512}
+# (512 B) and writes z' (512), the saves h1, h2 (2 x 1536), y (512), mean / rstd (8), the packed signs of h1 / h2 (96) and the
+# next block's zb (160); backward reads dy (512) and the packed gates (96), writes d2, d1 (3072) and dz (512)
+_EDGE_ALGO_BYTES = {"edge_mlp16_kernel<false": 512 + 512 + 3072 + 512 + 8 + 96 + 160, "edge_mlp16_kernel<true": 512 + 96 + 3072 + 512}
 
 
 def pmc_traffic(tile, rows):
@@ -196,8 +196,9 @@ def pmc_traffic(tile, rows):
         if any(name.startswith(pfx) for pfx in _PMC_NAMES[tile]):
             var[name] = {"launches_per_step": k["launches_per_step"], "bytes_per_launch": round(k["bytes_per_launch"]),
                          "raw_counter_bytes_per_launch": round(k["raw_bytes_per_launch"])}
-            if name in _EDGE_ALGO_BYTES:
-                var[name]["algorithmic_bytes_per_launch"] = _EDGE_ALGO_BYTES[name] * rows
+            for pfx, nbytes in _EDGE_ALGO_BYTES.items():
+                if name.startswith(pfx):
+                    var[name]["algorithmic_bytes_per_launch"] = nbytes * rows
             nl += k["launches_per_step"]
             tb += k["fetch_per_step"] + k["write_per_step"]
             raw += k["fetch_raw_per_step"] + k["write_raw_per_step"]
@@ -509,6 +510,13 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # FD_BENCH_MAIN_PRIORITY=n: run the step on a stream of that HIP priority instead of the default stream (A/B of stream
+    # priorities between the dX chain and the weight-gradient side stream)
+    main_prio = os.environ.get("FD_BENCH_MAIN_PRIORITY")
+    if main_prio is not None:
+        hp = torch.cuda.Stream(device=dev, priority=int(main_prio))
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)
     # Priming (part of set-up, before the W warm-up steps the contract names): the first steps of a process load ~60 code
     # objects, grow the caching allocator to its steady state (~40 GB at B=30 x N=128) and bind the flat optimiser's
     # views; with W = 3 one of those could still land in the timed region (one 28.7 ms outlier against 25.9 ms).

@@ -114,6 +114,13 @@ def linear_dx(dy, W, dx, M, N, K, *, beta=False, gate=None, rowscale=None, alpha
 _SIDE = {"streams": {}, "pending": [], "used": False}
 
 
+def _new_side_stream(device):
+    """The gradient side stream.  opts.side_stream_priority: HIP stream priority (lower number = higher priority; the value
+    is clamped to the device's range) -- a LOW priority lets the hardware dispatcher prefer the waves of the main stream's
+    (critical-path) kernels whenever both queues have work."""
+    return torch.cuda.Stream(device=device, priority=int(opts.side_stream_priority))
+
+
 def side(fn, tensors, rows):
     """Run fn() (weight-gradient launches reading `tensors`) on the gradient side stream."""
     t = tensors[0]
@@ -123,7 +130,7 @@ def side(fn, tensors, rows):
     key = t.device.index
     st = _SIDE["streams"].get(key)
     if st is None:
-        st = _SIDE["streams"][key] = torch.cuda.Stream(device=t.device)
+        st = _SIDE["streams"][key] = _new_side_stream(t.device)
     st.wait_stream(torch.cuda.current_stream())      # operands (and the zero-filled gradient buffers) are ready
     with torch.cuda.stream(st):
         fn()
@@ -143,7 +150,7 @@ def grad_stream(device):
         return None
     st = _SIDE["streams"].get(device.index)
     if st is None:
-        st = _SIDE["streams"][device.index] = torch.cuda.Stream(device=device)
+        st = _SIDE["streams"][device.index] = _new_side_stream(device)
     st.wait_stream(torch.cuda.current_stream())
     _SIDE["used"] = True
     return st

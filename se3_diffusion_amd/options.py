@@ -33,6 +33,7 @@ class Options:
     # -- streams
     grad_stream: bool = True          # FD_GRAD_STREAM: weight gradients on a second HIP stream beside the dX chain (ops.side)
     grad_stream_max_rows: int = 1 << 40   # FD_GRAD_STREAM_ROWS: row count above which a launch stays on the main stream
+    side_stream_priority: int = 0     # FD_SIDE_PRIORITY: HIP priority of that stream (lower = higher; clamped to the device's range)
     # -- pair level
     fused_edge: bool = True           # FD_EDGE_FUSED: fd_edge_mlp (whole edge-transition chain per pair row) vs the GEMM sequence
     fused_embed: bool = True          # FD_EMBED_FUSED: fd_edge_embed (features generated in registers) vs fd_edge_feats + GEMMs
@@ -61,6 +62,7 @@ class Options:
     def from_env(cls):
         return cls(
             grad_stream=_flag("FD_GRAD_STREAM", True), grad_stream_max_rows=_int("FD_GRAD_STREAM_ROWS", 1 << 40),
+            side_stream_priority=_int("FD_SIDE_PRIORITY", 0),
             fused_edge=_flag("FD_EDGE_FUSED", True), fused_embed=_flag("FD_EMBED_FUSED", True),
             fused_embed_bwd=_flag("FD_EMBED_BWD_FUSED", True),
             grouped_pair_dw=_flag("FD_PAIR_DW", True), pair_dw_blocks=_int("FD_PAIR_DW_BLOCKS", 160),
