@@ -161,6 +161,8 @@ _KERNELS = {
         "layers + LayerNorm, split-bf16 v_mfma_f32_16x16x32_bf16)", round(2500.0 / 6.0, 1)),
     10: ("gemm_s64_kernel<*,*> (64x64 split-bf16 tile, node-level / attention GEMMs, 6 x v_mfma_f32_32x32x16_bf16 per "
          "k-step)", round(2500.0 / 6.0, 1)),
+    11: ("group_dw_kernel (grouped node-level weight gradients: 128x128 tiles over a (tile, stage) sequence shared in equal pieces, "
+         "split-bf16 v_mfma_f32_32x32x16_bf16)", round(2500.0 / 6.0, 1)),
     9: ("pair_dw_kernel (grouped pair-row weight gradients: 384x128 tiles, float4 staging + ds_read_b64_tr_b16 operands, "
         "split-bf16 v_mfma_f32_32x32x16_bf16)", round(2500.0 / 6.0, 1)),
 }
@@ -193,7 +195,8 @@ def pmc_traffic(tile, rows):
         return None                               # the table was taken at B=30 x N=128
     var, nl, tb, raw = {}, 0.0, 0.0, 0.0
     for name, k in tab["kernels"].items():
-        if any(name.startswith(pfx) for pfx in _PMC_NAMES[tile]):
+        if any(name.startswith(pfx) for pfx in _PMC_NAMES[tile]) and k["launches_per_step"] >= 0.9:
+            # (< 0.9 launches per step: a variant that only the occasional extra no-grad forward of the traced run used)
             var[name] = {"launches_per_step": k["launches_per_step"], "bytes_per_launch": round(k["bytes_per_launch"]),
                          "raw_counter_bytes_per_launch": round(k["raw_bytes_per_launch"])}
             for pfx, nbytes in _EDGE_ALGO_BYTES.items():
@@ -553,7 +556,7 @@ def main():
     residues = sum(n * b for n, b in sched[a.warmup:])
     # the reference's training step with its 50 % self-conditioning forward (every other step here), same shapes
     sc_ms = None
-    if a.mode == "train" and not a.mixed_n:
+    if a.mode == "train" and not a.mixed_n and not os.environ.get("FD_BENCH_PROFILE"):   # (profiler runs: the plain step only)
         k = max(2, a.steps - a.steps % 2)
         barrier()
         t0 = time.perf_counter()

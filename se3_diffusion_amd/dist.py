@@ -21,12 +21,16 @@ def init_from_env(backend=None):
     """Initialise torch.distributed from torchrun's environment (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("FD_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+            # "nccl" is RCCL on ROCm.  FD_DIST_BACKEND=gloo: rehearsals of the multi-rank path on ONE GPU (RCCL refuses two
+            # ranks on a device) -- tests/test_dist.py, `FD_DIST_BACKEND=gloo FD_FORCE_DEVICE=0 torchrun ... bench.py --gpus 2`
+            backend = os.environ.get("FD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        if os.environ.get("FD_FORCE_DEVICE") is not None:
+            local = int(os.environ["FD_FORCE_DEVICE"])
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -1,0 +1,56 @@
+"""bench.py's output contract (one JSON line with the driver's fields + `roofline` + `cpu_baseline`) on a small configuration,
+and a rehearsal of its multi-rank path: two ranks launched by torch.distributed.run on ONE GPU (FD_DIST_BACKEND=gloo,
+FD_FORCE_DEVICE=0 -- RCCL refuses two ranks on a device), i.e. the per-rank data, parameter broadcast, flat all-reduce,
+barrier-bracketed timing and max-over-ranks code that `--gpus N` runs on an 8-GPU node."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+SMALL = ["--n-res", "32", "--batch", "2", "--blocks", "1", "--steps", "2", "--warmup", "1", "--no-sampling"]
+
+
+def _line(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def _check(d, n):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "residues/s" and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - n * 2 * 32 / d["ms_per_step"] * 1e3) < 0.02 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("mfma", "hbm") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_bench_line_single(hip_lib):
+    env = dict(os.environ, FD_BENCH_PRIME="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--cpu-sample-batch", "1"], capture_output=True,
+                       text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    _check(d, 1)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+
+
+def test_bench_two_ranks_on_one_gpu(hip_lib):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, FD_BENCH_PRIME="1", FD_DIST_BACKEND="gloo", FD_FORCE_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    _check(_line(r.stdout), 2)
