@@ -150,12 +150,10 @@ typedef struct FdEdgeMlpDesc {
   long ld_pqf;           /* row stride of pf / qf (0 = 128) */
   float* zb_out;         /* forward, optional: [rows,40] (see above) */
   const float* zb_bias;  /* forward, optional: [40] */
-  /* Packed ReLU signs (48 B per row): [ceil(rows / 64) * 4 waves][3 chunks][32] 64-bit words; word (w, c, 4 nb + e) bit l is
-   * the sign of hidden unit 128 c + 16 nb + 4 (l >> 4) + e of row 16 w + (l & 15) (w counts 16-row wave tiles). */
-  void* mask1;           /* forward, optional: signs of h1 */
-  void* mask2;           /* forward, optional: signs of h2 */
-  const void* gmask1;    /* backward, optional: the forward's mask2 (replaces gate1: 48 B instead of 1536 B read per row) */
-  const void* gmask2;    /* backward, optional: the forward's mask1 (replaces gate2) */
+  unsigned* mask1;       /* forward, optional: [rows,12] packed signs of h1: bit 4 nb + e of word 4 c + g <-> unit 128 c + 16 nb + 4 g + e */
+  unsigned* mask2;       /* forward, optional: [rows,12] packed signs of h2 */
+  const unsigned* gmask1; /* backward, optional: the forward's mask2 (replaces gate1: 48 B instead of 1536 B read per row) */
+  const unsigned* gmask2; /* backward, optional: the forward's mask1 (replaces gate2) */
 } FdEdgeMlpDesc;
 int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream);
 
@@ -196,8 +194,8 @@ typedef struct FdEdgeEmbedDesc {
   int blocks;             /* 0 = one persistent block per CU (256) */
   float* zb_out;          /* optional [rows,40] */
   const float* zb_bias;   /* optional [40] */
-  void* mask1;            /* optional: packed signs of h1, [ceil(rows / 64) * 4][32] u64 (layout: FdEdgeMlpDesc, one chunk) */
-  void* mask2;            /* optional: packed signs of h2 */
+  unsigned* mask1;        /* optional [rows,4]: packed signs of h1 (bit 4 nb + e of word g <-> unit 16 nb + 4 g + e) */
+  unsigned* mask2;        /* optional [rows,4]: packed signs of h2 */
 } FdEdgeEmbedDesc;
 int fd_edge_embed(const FdEdgeEmbedDesc* desc, void* stream);
 
@@ -224,8 +222,8 @@ typedef struct FdEdgeEmbedBwdDesc {
   float* dbeta;           /* optional [128], accumulated */
   long rows;
   int blocks;             /* 0 = two persistent blocks per CU (512) */
-  const void* gmask2;     /* optional: fd_edge_embed's mask2 -- replaces the read of h2 (h2 may then be null) */
-  const void* gmask1;     /* optional: fd_edge_embed's mask1 -- replaces the read of h1 */
+  const unsigned* gmask2; /* optional [rows,4]: fd_edge_embed's mask2 -- replaces the read of h2 (h2 may then be null) */
+  const unsigned* gmask1; /* optional [rows,4]: fd_edge_embed's mask1 -- replaces the read of h1 */
 } FdEdgeEmbedBwdDesc;
 int fd_edge_embed_bwd(const FdEdgeEmbedBwdDesc* desc, void* stream);
 

@@ -173,22 +173,19 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_kernel(FdEdgeEmbe
         if (hh == 1) stage_prefetch();
       }
     }
-    // packed ReLU signs (fd_edge_mlp.hip): one ballot per hidden unit slot (nb, e), the layer's 32 ballots parked in lanes 0..31
-    // and stored as one 256-byte record mask[(tile * waves + wave), 4 nb + e] (u64, bit l <-> row l & 15, unit 16 nb + 4 (l >> 4) + e)
-    const long mrec = ((long)first + (long)ti * G) * EM_WAVES + wave;
-    unsigned ml = 0u, mh = 0u;
+    unsigned bits = 0u;       // packed signs of the layer's 32 units of this lane: bit 4 nb + e <-> unit 16 nb + 4 g + e
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (d.mask1 != nullptr) fd::set_lane64(ml, mh, 4 * nb + e, fd::ballot(acc1[nb][e] > 0.f));
+        bits |= (acc1[nb][e] > 0.f ? 1u : 0u) << (4 * nb + e);
         acc1[nb][e] = acc1[nb][e] > 0.f ? acc1[nb][e] : 0.f;
       }
       if (d.h1 != nullptr && rok)
         *reinterpret_cast<float4*>(d.h1 + row * EE_C + 16 * nb + 4 * g) =
             make_float4(acc1[nb][0], acc1[nb][1], acc1[nb][2], acc1[nb][3]);
     }
-    if (d.mask1 != nullptr && lane < 32) reinterpret_cast<uint2*>(d.mask1)[mrec * 32 + lane] = make_uint2(ml, mh);
+    if (d.mask1 != nullptr && rok) d.mask1[row * 4 + g] = bits;
 
     // ---- layers 2 and 3: K = 128 of the previous layer's registers, bias as the initial value ----
     f32x4 acc2[8], acc3[8];
@@ -213,19 +210,19 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_kernel(FdEdgeEmbe
         if (hh == 1) stage_prefetch();
       }
     }
-    ml = 0u; mh = 0u;
+    bits = 0u;
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (d.mask2 != nullptr) fd::set_lane64(ml, mh, 4 * nb + e, fd::ballot(acc2[nb][e] > 0.f));
+        bits |= (acc2[nb][e] > 0.f ? 1u : 0u) << (4 * nb + e);
         acc2[nb][e] = acc2[nb][e] > 0.f ? acc2[nb][e] : 0.f;
       }
       if (d.h2 != nullptr && rok)
         *reinterpret_cast<float4*>(d.h2 + row * EE_C + 16 * nb + 4 * g) =
             make_float4(acc2[nb][0], acc2[nb][1], acc2[nb][2], acc2[nb][3]);
     }
-    if (d.mask2 != nullptr && lane < 32) reinterpret_cast<uint2*>(d.mask2)[mrec * 32 + lane] = make_uint2(ml, mh);
+    if (d.mask2 != nullptr && rok) d.mask2[row * 4 + g] = bits;
 #pragma clang loop unroll(full)
     for (int sg = 0; sg < 8 / EM_UPS; ++sg) {
       const char* st = stage_begin();

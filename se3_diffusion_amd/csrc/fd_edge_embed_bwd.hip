@@ -94,15 +94,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_bwd_kernel(FdEdge
     const bool rok = row < rows;
     const long rc = rok ? row : rows - 1;         // rows past the end are clamped on load, masked on store / in the sums
 
-    // packed ReLU gates (fd_edge_embed's mask outputs: record (tile * waves + wave) of 32 u64, word 4 nb + e, bit l <-> row
-    // l & 15, unit 16 nb + 4 (l >> 4) + e), fetched up front: a gate is two v_readlane + a v_cndmask on the mask
+    // packed ReLU gates (the forward's mask outputs: bit 4 nb + e of word (row, g) <-> unit 16 nb + 4 g + e), fetched up front
     const bool packed = d.gmask2 != nullptr;
-    unsigned g2l = 0u, g2h = 0u, g1l = 0u, g1h = 0u;
+    unsigned gm2 = 0u, gm1 = 0u;
     if (packed) {
-      const long mrec = ((long)first + (long)ti * G) * EM_WAVES + wave;
-      const uint2 a = reinterpret_cast<const uint2*>(d.gmask2)[mrec * 32 + (lane & 31)];
-      const uint2 bq = reinterpret_cast<const uint2*>(d.gmask1)[mrec * 32 + (lane & 31)];
-      g2l = a.x; g2h = a.y; g1l = bq.x; g1h = bq.y;
+      gm2 = d.gmask2[rc * 4 + g];
+      gm1 = d.gmask1[rc * 4 + g];
     }
 
     // ---- LayerNorm backward: dh3 in the register layout of a layer output (lane (m, g): columns 16 nb + 4 g + r) ----
@@ -174,7 +171,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_bwd_kernel(FdEdge
     for (int nb = 0; nb < 8; ++nb) {
       if (packed) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a2[nb][e] = fd::lane_bit(fd::get_lane64(g2l, g2h, 4 * nb + e)) ? a2[nb][e] : 0.f;
+        for (int e = 0; e < 4; ++e) a2[nb][e] = ((gm2 >> (4 * nb + e)) & 1u) ? a2[nb][e] : 0.f;
       } else {
         const float4 h = *reinterpret_cast<const float4*>(d.h2 + rc * EB_C + 16 * nb + 4 * g);
         a2[nb][0] = h.x > 0.f ? a2[nb][0] : 0.f;
@@ -210,10 +207,8 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_bwd_kernel(FdEdge
     for (int nb = 0; nb < 8; ++nb) {
       float4 o;
       if (packed) {
-        o = make_float4(fd::lane_bit(fd::get_lane64(g1l, g1h, 4 * nb)) ? a1[nb][0] : 0.f,
-                        fd::lane_bit(fd::get_lane64(g1l, g1h, 4 * nb + 1)) ? a1[nb][1] : 0.f,
-                        fd::lane_bit(fd::get_lane64(g1l, g1h, 4 * nb + 2)) ? a1[nb][2] : 0.f,
-                        fd::lane_bit(fd::get_lane64(g1l, g1h, 4 * nb + 3)) ? a1[nb][3] : 0.f);
+        o = make_float4(((gm1 >> (4 * nb)) & 1u) ? a1[nb][0] : 0.f, ((gm1 >> (4 * nb + 1)) & 1u) ? a1[nb][1] : 0.f,
+                        ((gm1 >> (4 * nb + 2)) & 1u) ? a1[nb][2] : 0.f, ((gm1 >> (4 * nb + 3)) & 1u) ? a1[nb][3] : 0.f);
       } else {
         const float4 h = *reinterpret_cast<const float4*>(d.h1 + rc * EB_C + 16 * nb + 4 * g);
         o = make_float4(h.x > 0.f ? a1[nb][0] : 0.f, h.y > 0.f ? a1[nb][1] : 0.f, h.z > 0.f ? a1[nb][2] : 0.f,

@@ -196,21 +196,16 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
       }
     }
 
-    // Packed ReLU gates.  Forward (MASK): the sign of hidden unit 128 c + 16 nb + 4 g + e of the wave's 16 rows is ONE wave-wide
-    // predicate -- a ballot (the relu's compare, into an SGPR pair); the 32 ballots of a chunk are parked in lanes 0..31 of a
-    // VGPR pair and leave as one 256-byte store: mask[(tile * waves + wave), c, 4 nb + e] (u64, bit l = lane l = row l & 15, g =
-    // l >> 4) -- 48 B per pair row.  Backward (gmask1 / gmask2 = the forward's mask2 / mask1): the six 256-byte records of the
-    // tile are fetched here, a gate is two v_readlane + one v_cndmask on the mask as condition register -- instead of 3 KB of
-    // h2 / h1 per row fetched (and waited for) inside the epilogues.
-    const long mrec = (((long)first + (long)ti * G) * EM_WAVES + wave) * 3;     // this wave's record index (x 32 u64)
-    unsigned gl1[3] = {0u, 0u, 0u}, gh1[3] = {0u, 0u, 0u}, gl2[3] = {0u, 0u, 0u}, gh2[3] = {0u, 0u, 0u};
+    // backward with packed ReLU gates (gmask1 / gmask2: the forward's mask2 / mask1 outputs): bit 4 nb + e of word (row, chunk c,
+    // g) says whether hidden unit 128 c + 16 nb + 4 g + e was positive -- 6 dwords per lane and tile, fetched here, instead of
+    // 3 KB of h2 / h1 per row fetched (and waited for) inside the epilogues
+    unsigned gm1[3] = {0u, 0u, 0u}, gm2[3] = {0u, 0u, 0u};
     const bool packed_gates = BWD && d.gmask1 != nullptr;
     if (packed_gates) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const uint2 a = reinterpret_cast<const uint2*>(d.gmask1)[(mrec + c) * 32 + (lane & 31)];
-        const uint2 bq = reinterpret_cast<const uint2*>(d.gmask2)[(mrec + c) * 32 + (lane & 31)];
-        gl1[c] = a.x; gh1[c] = a.y; gl2[c] = bq.x; gh2[c] = bq.y;
+        gm1[c] = d.gmask1[rc * 12 + 4 * c + g];
+        gm2[c] = d.gmask2[rc * 12 + 4 * c + g];
       }
     }
     uint4 b[3];          // activation planes (B operand) of the current k-step
@@ -246,7 +241,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
         }
       }
       // epilogue 1: forward  h1 = relu(acc + P1_i + Q1_j);  backward  d2 = acc gated by h2 > 0
-      unsigned ml = 0u, mh = 0u;
+      unsigned bits1 = 0u;
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) {
         const int col = 128 * c + 16 * nb + 4 * g;
@@ -259,12 +254,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
           v[0] += a.x + bq.x; v[1] += a.y + bq.y; v[2] += a.z + bq.z; v[3] += a.w + bq.w;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if (MASK) fd::set_lane64(ml, mh, 4 * nb + e, fd::ballot(v[e] > 0.f));
+            if (MASK) bits1 |= (v[e] > 0.f ? 1u : 0u) << (4 * nb + e);
             v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
         } else if (packed_gates) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fd::lane_bit(fd::get_lane64(gl1[c], gh1[c], 4 * nb + e)) ? v[e] : 0.f;
+          for (int e = 0; e < 4; ++e) v[e] = ((gm1[c] >> (4 * nb + e)) & 1u) ? v[e] : 0.f;
         } else {
           const float4 gt = *reinterpret_cast<const float4*>(d.gate1 + rc * EM_H + col);
           v[0] = gt.x > 0.f ? v[0] : 0.f; v[1] = gt.y > 0.f ? v[1] : 0.f;
@@ -275,7 +270,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
         if (d.save1 != nullptr && rok)
           *reinterpret_cast<float4*>(d.save1 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
       }
-      if (!BWD && MASK && lane < 32) reinterpret_cast<uint2*>(d.mask1)[(mrec + c) * 32 + lane] = make_uint2(ml, mh);
+      if (!BWD && MASK && rok) d.mask1[row * 12 + 4 * c + g] = bits1;
       // ---- layer 2, k in chunk c: units (k-step u2 / 6, n-group u2 % 6) ----
 #pragma clang loop unroll(full)
       for (int sg = 0; sg < 24 / EM_UPS; ++sg) {
@@ -294,7 +289,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
     }
 
     // epilogue 2: forward  h2 = relu(acc2);  backward  d1 = acc2 gated by h1 > 0
-    unsigned ml2 = 0u, mh2 = 0u;
+    unsigned bits2 = 0u;
 #pragma unroll
     for (int nb = 0; nb < 24; ++nb) {
       const int col = 16 * nb + 4 * g;
@@ -304,13 +299,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
       if (!BWD) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (MASK) fd::set_lane64(ml2, mh2, 4 * (nb & 7) + e, fd::ballot(v[e] > 0.f));
+          if (MASK) bits2 |= (v[e] > 0.f ? 1u : 0u) << (4 * (nb & 7) + e);
           v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
       } else if (packed_gates) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[e] = fd::lane_bit(fd::get_lane64(gl2[nb >> 3], gh2[nb >> 3], 4 * (nb & 7) + e)) ? v[e] : 0.f;
+        for (int e = 0; e < 4; ++e) v[e] = ((gm2[nb >> 3] >> (4 * (nb & 7) + e)) & 1u) ? v[e] : 0.f;
       } else {
         const float4 gt = *reinterpret_cast<const float4*>(d.gate2 + rc * EM_H + col);
         v[0] = gt.x > 0.f ? v[0] : 0.f; v[1] = gt.y > 0.f ? v[1] : 0.f;
@@ -320,8 +314,10 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
       for (int e = 0; e < 4; ++e) acc2[nb][e] = v[e];
       if (d.save2 != nullptr && rok)
         *reinterpret_cast<float4*>(d.save2 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
-      if (!BWD && MASK && (nb & 7) == 7 && lane < 32)
-        reinterpret_cast<uint2*>(d.mask2)[(mrec + (nb >> 3)) * 32 + lane] = make_uint2(ml2, mh2);
+      if (!BWD && MASK && (nb & 7) == 7) {
+        if (rok) d.mask2[row * 12 + 4 * (nb >> 3) + g] = bits2;
+        bits2 = 0u;
+      }
     }
 
     // ---- layer 3: 128 outputs x (K = 128 of x, then K = 384 of the hidden layer) ----

@@ -120,34 +120,6 @@ __device__ __forceinline__ void wait_vmem_keep6() { asm volatile("s_waitcnt vmcn
 // the instruction scheduler moves nothing across this point (pins a software-pipelined order)
 __device__ __forceinline__ void sched_pin() { __builtin_amdgcn_sched_barrier(0); }
 
-// ---- wave-wide predicate masks ----
-// ballot: bit l = predicate of lane l (a v_cmp into an SGPR pair: no VGPR, no extra instruction beside the compare)
-__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-// park a wave-uniform 64-bit value in lane `l` of a VGPR pair (two v_writelane_b32): 32 masks -> one 256-byte store.
-// The lane select must be an inline constant (a second SGPR would break gfx9's one-scalar-operand rule): call sites pass an
-// index that is a constant after unrolling, the switch folds to its one case.
-template <int L>
-__device__ __forceinline__ void set_lane64_c(unsigned& lo, unsigned& hi, unsigned long long m) {
-  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"((unsigned)m), "n"(L));
-  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"((unsigned)(m >> 32)), "n"(L));
-}
-__device__ __forceinline__ void set_lane64(unsigned& lo, unsigned& hi, int l, unsigned long long m) {
-  switch (l) {
-#define FD_SL(K) case K: set_lane64_c<K>(lo, hi, m); break;
-    FD_SL(0) FD_SL(1) FD_SL(2) FD_SL(3) FD_SL(4) FD_SL(5) FD_SL(6) FD_SL(7) FD_SL(8) FD_SL(9) FD_SL(10) FD_SL(11) FD_SL(12)
-    FD_SL(13) FD_SL(14) FD_SL(15) FD_SL(16) FD_SL(17) FD_SL(18) FD_SL(19) FD_SL(20) FD_SL(21) FD_SL(22) FD_SL(23) FD_SL(24)
-    FD_SL(25) FD_SL(26) FD_SL(27) FD_SL(28) FD_SL(29) FD_SL(30) FD_SL(31)
-#undef FD_SL
-    default: break;
-  }
-}
-// ... and back: the 64-bit value parked in lane `l` as a wave-uniform scalar (two v_readlane_b32)
-__device__ __forceinline__ unsigned long long get_lane64(unsigned lo, unsigned hi, int l) {
-  return ((unsigned long long)__builtin_amdgcn_readlane(hi, l) << 32) | (unsigned long long)__builtin_amdgcn_readlane(lo, l);
-}
-// this lane's bit of a wave-uniform mask, as a predicate (the mask becomes the condition register of a v_cndmask)
-__device__ __forceinline__ bool lane_bit(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
-
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 

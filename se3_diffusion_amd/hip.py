@@ -91,12 +91,6 @@ class FdEdgeMlpDesc(Structure):
 
 
 EDGE_MLP_IMAGE_BYTES = 132 * 12288
-EDGE_TILE_ROWS = 64            # rows per block tile of the fused pair kernels (4 waves x 16)
-
-
-def edge_mask_words(rows, chunks):
-    """64-bit words of a packed-sign tensor of the fused pair kernels: [ceil(rows / 64) * 4 waves][chunks][32]."""
-    return ((int(rows) + EDGE_TILE_ROWS - 1) // EDGE_TILE_ROWS) * 4 * chunks * 32
 
 
 class FdEdgeEmbedDesc(Structure):

@@ -153,8 +153,7 @@ def embed_fwd(P, feats, B, N, cache=None, save=True, zb_next=None):
         mean = empty((Pn,), dev); rstd = empty((Pn,), dev)
         kw.update(h1=h1, h2=h2, h3=h3, mean=mean, rstd=rstd)
         if opts.packed_gates:
-            nw_ = hip.edge_mask_words(Pn, 1)
-            mh1 = empty((nw_,), dev, torch.int64); mh2 = empty((nw_,), dev, torch.int64)
+            mh1 = empty((Pn, 4), dev, torch.int32); mh2 = empty((Pn, 4), dev, torch.int32)
             kw.update(mask1=mh1, mask2=mh2)
     ops.edge_embed(seq, feats["sc_ca_t"], idenom, lower, upper, img, p_, q_, P[f"{pre}.2.bias"], P[f"{pre}.4.bias"],
                    P[f"{pre}.5.weight"], P[f"{pre}.5.bias"], edge, Pn, N, rowscale=emask, **kw)

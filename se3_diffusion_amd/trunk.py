@@ -118,8 +118,7 @@ def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None, zb_next
         kw = dict(save1=h1, save2=h2, y=y, mean=mean, rstd=rstd)
         if opts.packed_gates:
             # sign bits of h1 / h2 (48 B per row each) for the backward's ReLU gates: its dX kernel then reads no h1 / h2
-            nw_ = hip.edge_mask_words(Pn, 3)
-            mh1 = empty((nw_,), dev, torch.int64); mh2 = empty((nw_,), dev, torch.int64)
+            mh1 = empty((Pn, 12), dev, torch.int32); mh2 = empty((Pn, 12), dev, torch.int32)
             kw.update(mask1=mh1, mask2=mh2)
     if use_zb:
         zb = empty((Pn, nw.ZB), dev)

@@ -160,22 +160,6 @@ static inline void sched_fence() {}
 static inline void sched_pin() {}
 
 
-// wave-wide predicate masks (gfx950/fd_intrin.h): collectives over the lanes of the emulated wave
-static inline unsigned long long ballot(bool p) {
-  unsigned char b = p ? 1 : 0;
-  auto tab = hipemu::wave_exchange(&b, 1);
-  unsigned long long m = 0;
-  for (int l = 0; l < 64; ++l) m |= (unsigned long long)(tab[l][0] & 1) << l;
-  return m;
-}
-static inline void set_lane64(unsigned& lo, unsigned& hi, int l, unsigned long long m) {
-  if (hipemu::g_cur->lane == l) { lo = (unsigned)m; hi = (unsigned)(m >> 32); }
-}
-static inline unsigned long long get_lane64(unsigned lo, unsigned hi, int l) {
-  return ((unsigned long long)__shfl(hi, l) << 32) | (unsigned long long)__shfl(lo, l);
-}
-static inline bool lane_bit(unsigned long long m) { return (m >> hipemu::g_cur->lane) & 1ull; }
-
 static inline int lane_id() { return hipemu::g_cur->lane; }
 static inline int wave_id() { return hipemu::g_cur->wave; }
 

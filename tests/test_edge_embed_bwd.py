@@ -44,17 +44,13 @@ def _run(dev, rows, seed=0, blocks=0, mask=True):
         assert err < 2e-5, (k, err, rows, blocks)
     # the same with the ReLU gates as packed sign bits (fd_edge_embed's mask outputs: bit 4 nb + e of word (row, g) <-> unit
     # 16 nb + 4 g + e) instead of reads of h2 / h1: bit-identical
-    from se3_diffusion_amd import hip as fhip
-
+    unit = torch.arange(C)
+    nb, gg, ee = unit // 16, (unit % 16) // 4, unit % 4
     def pack(h):
-        # word (16-row wave tile w, 4 nb + e), bit l <-> row 16 w + (l & 15), unit 16 nb + 4 (l >> 4) + e (fd_edge_embed's masks)
-        nwords = fhip.edge_mask_words(rows, 1)
-        hp = torch.zeros(nwords // 32 * 16, C, dtype=torch.bool)
-        hp[:rows] = h > 0
-        hp = hp.view(-1, 16, 8, 4, 4)                      # [w, m, nb, g, e]
-        bit = (torch.arange(16)[:, None] + 16 * torch.arange(4)[None, :]).view(1, 16, 1, 4, 1)
-        words = (hp.long() << bit).sum(dim=(1, 3))         # [w, nb, e]  (bit 63 = lane 63 wraps into the sign bit: intended)
-        return words.reshape(-1).to(torch.int64).to(dev)
+        w = torch.zeros(rows, 4, dtype=torch.int64)
+        for u in range(C):
+            w[:, gg[u]] |= (h[:, u] > 0).long() << int(4 * nb[u] + ee[u])
+        return (w & 0xFFFFFFFF).to(torch.int64).apply_(lambda v: v - (1 << 32) if v >= (1 << 31) else v).to(torch.int32).to(dev)
     p3, p2, p1 = (torch.full((rows, C), float("nan"), device=dev) for _ in range(3))
     dg2, db2 = to(dgam0.clone()), to(dbet0.clone())
     ops.edge_embed_bwd(to(dy), to(h3), to(mean), to(rstd), to(gamma), to(rowscale), None, None, img, p3, p2, p1, dg2, db2, rows,

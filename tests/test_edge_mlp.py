@@ -83,23 +83,17 @@ def _run(dev, B, N, seed=0, blocks=0):
         assert rel(d2, rd2) < 5e-6 and rel(d1, rd1) < 5e-6 and rel(dz, rdz) < 5e-6
     # packed ReLU gates: the forward's sign masks (bit 4 nb + e of word (row, chunk c, g) <-> unit 128 c + 16 nb + 4 g + e) and
     # the backward that gates on them instead of reading h1 / h2 -- bit-identical to the gated backward above
-    from se3_diffusion_amd import hip as fhip
-    nwords = fhip.edge_mask_words(P, 3)
-    mh1 = torch.zeros(nwords, dtype=torch.int64, device=dev); mh2 = torch.zeros(nwords, dtype=torch.int64, device=dev)
+    mh1 = torch.zeros(P, 12, dtype=torch.int32, device=dev); mh2 = torch.zeros(P, 12, dtype=torch.int32, device=dev)
     out5, h1b, h2b = e(P, 128), e(P, 384), e(P, 384)
     ops.edge_mlp(t["z"], img, out5, P, N, p1=t["P1"], q1=t["Q1"], bias2=t["b2"], pf=t["Pf"], qf=t["Qf"], gamma=t["gamma"],
                  beta=t["beta"], rowscale=t["emask"], save1=h1b, save2=h2b, y=e(P, 128), mean=e(P), rstd=e(P), blocks=blocks,
                  mask1=mh1, mask2=mh2)
     assert torch.equal(out5, out) and torch.equal(h1b, h1) and torch.equal(h2b, h2)
-    # word (16-row wave tile w, chunk c, 4 nb + e), bit l <-> row 16 w + (l & 15), unit 128 c + 16 nb + 4 (l >> 4) + e
-    rows_i = torch.arange(P)[:, None]
-    unit = torch.arange(384)[None, :]
-    w, m = rows_i // 16, rows_i % 16
+    unit = torch.arange(384)
     c, nb, g, ee = unit // 128, (unit % 128) // 16, (unit % 16) // 4, unit % 4
-    word = (w * 3 + c) * 32 + 4 * nb + ee
     for mh, h in ((mh1, h1), (mh2, h2)):
-        words = mh.cpu()
-        bits = (words[word] >> (m + 16 * g)) & 1
+        words = mh.cpu().long() & 0xFFFFFFFF
+        bits = (words[:, (4 * c + g)] >> (4 * nb + ee)) & 1
         assert torch.equal(bits.bool(), h.cpu() > 0)
     dz2, d22, d12 = e(P, 128), e(P, 384), e(P, 384)
     ops.edge_mlp(t["dy"], imgT, dz2, P, N, gmask1=mh2, gmask2=mh1, save1=d22, save2=d12, backward=True, blocks=blocks)

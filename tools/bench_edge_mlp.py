@@ -55,25 +55,14 @@ def main():
             print(f"B={B} N={N}: fused fwd(no save) {t_inf:.3f} ms ({flops / t_inf / 1e9:.0f} TF)")
             continue
         t_trn = timeit(lambda: ops.edge_mlp(z, img, out, Pn, N, save1=h1, save2=h2, y=y, mean=mean, rstd=rstd, **kw))
-        # as the training step runs it: + packed sign masks of h1 / h2, + the next block's zb layer
-        m1, m2 = torch.empty(Pn, 12, dtype=torch.int32, device=dev), torch.empty(Pn, 12, dtype=torch.int32, device=dev)
-        W40, b40, zb = torch.randn(40, 128, device=dev) * 0.1, torch.randn(40, device=dev), e(Pn, 40)
-        img4 = ops.edge_mlp_pack(W1, W2, Wf, W40=W40)
-        t_trn_m = timeit(lambda: ops.edge_mlp(z, img, out, Pn, N, save1=h1, save2=h2, y=y, mean=mean, rstd=rstd, mask1=m1, mask2=m2,
-                                              **kw))
-        t_trn_mz = timeit(lambda: ops.edge_mlp(z, img4, out, Pn, N, save1=h1, save2=h2, y=y, mean=mean, rstd=rstd, mask1=m1,
-                                               mask2=m2, zb_out=zb, zb_bias=b40, **kw))
         dz, d2, d1 = e(Pn, 128), e(Pn, 384), e(Pn, 384)
         t_bwd = timeit(lambda: ops.edge_mlp(y, imgT, dz, Pn, N, gate1=h2, gate2=h1, save1=d2, save2=d1, backward=True,
                                             blocks=a.blocks))
         t_bwd_ns = timeit(lambda: ops.edge_mlp(y, imgT, dz, Pn, N, gate1=h2, gate2=h1, backward=True, blocks=a.blocks))
-        t_bwd_pk = timeit(lambda: ops.edge_mlp(y, imgT, dz, Pn, N, gmask1=m2, gmask2=m1, save1=d2, save2=d1, backward=True,
-                                               blocks=a.blocks))
         tf = lambda ms: flops / ms / 1e9
         print(f"B={B} N={N} rows={Pn}: unfused fwd {t_unf:.3f} ms ({tf(t_unf):.0f} TF) | fused fwd(no save) {t_inf:.3f} ms "
               f"({tf(t_inf):.0f} TF) | fused fwd(+h1,h2,y) {t_trn:.3f} ms ({tf(t_trn):.0f} TF) | fused bwd chain(+d2,d1) "
-              f"{t_bwd:.3f} ms ({tf(t_bwd):.0f} TF) | bwd chain no save {t_bwd_ns:.3f} ms | pack {t_pack * 1e3:.1f} us | "
-              f"fwd + saves + masks {t_trn_m:.3f} ms, + zb {t_trn_mz:.3f} ms | bwd chain, packed gates (+d2,d1) {t_bwd_pk:.3f} ms",
+              f"{t_bwd:.3f} ms ({tf(t_bwd):.0f} TF) | bwd chain no save {t_bwd_ns:.3f} ms | pack {t_pack * 1e3:.1f} us",
               flush=True)
 
 
