@@ -619,7 +619,9 @@ def main():
         "steps": a.steps, "warmup": a.warmup, "priming_steps": int(os.environ.get("FD_BENCH_PRIME", "4")),
         "ms_per_step": round(ms, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload, "parallelism": f"dp{world}", "global_batch": world * B, "n_res": N,
+        "config": {"workload": workload,
+                   "batches": "one pre-generated batch per step of the schedule" if a.mixed_n else
+                              "one HBM-resident synthetic batch per rank, reused by every step (priming, warm-up and timed)", "parallelism": f"dp{world}", "global_batch": world * B, "n_res": N,
                    "ms_per_step_exact_f32_gemms": None if exact_ms is None else round(exact_ms, 3),
                    "self_conditioning_50pct": None if sc_ms is None else {
                        "ms_per_step": round(sc_ms, 3), "residues_per_s": round(world * B * N / sc_ms * 1e3, 1),
