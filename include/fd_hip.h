@@ -120,6 +120,9 @@ int fd_rowscale(const float* x, long ldx, const float* rs, float* y, long ldy, l
  * (fd_edge_mlp_pack_zb, after fd_edge_mlp_pack). */
 #define FD_EDGE_MLP_IMAGE_BYTES (132 * 12288)
 int fd_edge_mlp_pack_zb(const float* W40, void* image, void* stream);
+/* backward image for the fused-prologue backward (FdEdgeMlpDesc.ln_y): Wf [128,384], W2 [384,384], W1 [384,384] row-major with
+ * row stride ld; W40 [40,128] of the IPA block BEHIND the transition or null (then no dzb term) */
+int fd_edge_mlp_pack_bwd(const float* Wf, const float* W2, const float* W1, long ld, const float* W40, void* image, void* stream);
 int fd_edge_mlp_pack(const float* A1, long rs1, long cs1, const float* A2, long rs2, long cs2, const float* A3,
                      long rs3, long cs3, const float* A4, long rs4, long cs4, void* image, void* stream);
 typedef struct FdEdgeMlpDesc {
@@ -154,6 +157,19 @@ typedef struct FdEdgeMlpDesc {
   unsigned* mask2;       /* forward, optional: [rows,12] packed signs of h2 */
   const unsigned* gmask1; /* backward, optional: the forward's mask2 (replaces gate1: 48 B instead of 1536 B read per row) */
   const unsigned* gmask2; /* backward, optional: the forward's mask1 (replaces gate2) */
+  /* Backward, optional -- fused prologue (image from fd_edge_mlp_pack_bwd): x is then the UPSTREAM gradient of the transition's
+   * output (may be null with dzb), the kernel's own input dy = LayerNorm-backward(x [+ dzb W40]; ln_y, ln_mean, ln_rstd,
+   * ln_gamma, ln_rowscale) is formed in registers, written to dy_out (optional) and ln_dgamma / ln_dbeta (+=, optional). */
+  const float* ln_y;        /* [rows,128] the forward's pre-LayerNorm save */
+  const float* ln_mean;     /* [rows] */
+  const float* ln_rstd;     /* [rows] */
+  const float* ln_gamma;    /* [128] */
+  const float* ln_rowscale; /* optional [rows] */
+  float* dy_out;            /* optional [rows,128] */
+  float* ln_dgamma;         /* optional [128], accumulated */
+  float* ln_dbeta;          /* optional [128], accumulated */
+  const float* dzb;         /* optional [rows,40]: adds dzb W40 to the upstream gradient (autograd of the next IPA block's linear_b /
+                               down_z w.r.t. this transition's output; W40 = the four leading units of the image) */
 } FdEdgeMlpDesc;
 int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream);
 

@@ -51,6 +51,26 @@ constexpr int EM_ZB = 40;
 #endif
 constexpr int EM_H = 384, EM_C = 128;
 
+// Probe build only (tools/probes/edge_phases.py compiles this file with -DEM_PHASE_TIMING into its own library): wave-level
+// cycle counts per phase of a tile, read with s_memtime at stage boundaries (where no LDS read is outstanding) and summed over
+// all waves into em_phase[]: 0 tile prologue, 1 stage waits (vmcnt + barrier), 2 layer-1 stages, 3 epilogue 1, 4 layer-2 stages,
+// 5 epilogue 2, 6 layer-3 stages, 7 final epilogue (backward), 8 final epilogue + fourth layer (forward), 9 fused backward prologue.
+#ifdef EM_PHASE_TIMING
+__device__ unsigned long long em_phase[12];
+#define EM_TICK_TO(var)                                                \
+  if (!MASK) { /* (the MASK instantiations trip a code-generator assertion with the timers in: not timed) */ \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    const long long t_ = (long long)__builtin_amdgcn_s_memtime();      \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    var += t_ - tl_;                                                   \
+    tl_ = t_;                                                          \
+  }
+#define EM_BODY_TO(i) { EM_TICK_TO(tb_); em_add(i, tb_); tb_ = 0; }
+#else
+#define EM_TICK_TO(var)
+#define EM_BODY_TO(i)
+#endif
+
 struct EmMat {
   const float* p;
   long rs, cs;
@@ -61,7 +81,10 @@ struct EmMat {
 // memory): k = k0 + 8 g + e'; chained k order (operand = the previous layer's accumulator): k = k0 + 16 (e' >> 2) +
 // 4 g + (e' & 3).  Unit order inside a region: k-step major, n-group minor (the activation planes of a k-step are split
 // once and reused by its n-groups).
-__global__ __launch_bounds__(256) void edge_mlp_pack16_kernel(EmMat A1, EmMat A2, EmMat A3, EmMat A4, char* __restrict__ img) {
+// x_chained: the two regions that consume the kernel's INPUT (layer 1, layer 3's x part) in chained k order too -- the backward
+// with the fused LayerNorm-backward prologue holds its input in layer-output register layout
+__global__ __launch_bounds__(256) void edge_mlp_pack16_kernel(EmMat A1, EmMat A2, EmMat A3, EmMat A4, char* __restrict__ img,
+                                                              int x_chained) {
   const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x);   // (unit, n-block, lane)
   if (gid >= EM_UNITS * 4 * 64) return;
   const int lane = gid & 63, i = (gid >> 6) & 3, u = gid >> 8;
@@ -72,14 +95,14 @@ __global__ __launch_bounds__(256) void edge_mlp_pack16_kernel(EmMat A1, EmMat A2
   if (u < 96) {
     const int c = u / 32, r = u % 32;
     if (r < 8) {                    // layer 1: k-step r >> 1, n-group r & 1 of chunk c
-      M = A1; n = 128 * c + 64 * (r & 1) + 16 * i + m; k0 = 32 * (r >> 1); chained = false;
+      M = A1; n = 128 * c + 64 * (r & 1) + 16 * i + m; k0 = 32 * (r >> 1); chained = x_chained != 0;
     } else {                        // layer 2: k-step (r - 8) / 6 of chunk c, n-group (r - 8) % 6
       const int r2 = r - 8;
       M = A2; n = 64 * (r2 % 6) + 16 * i + m; k0 = 128 * c + 32 * (r2 / 6); chained = true;
     }
   } else if (u < 104) {             // layer 3, x part
     const int r = u - 96;
-    M = A3; n = 64 * (r & 1) + 16 * i + m; k0 = 32 * (r >> 1); chained = false;
+    M = A3; n = 64 * (r & 1) + 16 * i + m; k0 = 32 * (r >> 1); chained = x_chained != 0;
   } else {                          // layer 3, hidden part
     const int v = u - 104;
     M = A4; n = 64 * (v & 1) + 16 * i + m; k0 = 32 * (v >> 1); chained = true;
@@ -120,18 +143,63 @@ __global__ __launch_bounds__(256) void edge_mlp_pack_zb_kernel(const float* __re
   *reinterpret_cast<uint4*>(dst + 2 * EM_PIECE) = s2;
 }
 
+// four LEADING units of a backward image with the dzb W40 prologue: W40^T -- n = the 128 columns of z (two n-groups), k = the 40
+// columns of dzb in natural order (operand loaded from memory), zero beyond k = 40; unit = (k-step, n-group), n-group minor
+__global__ __launch_bounds__(256) void edge_mlp_pack_zbw_kernel(const float* __restrict__ W40, char* __restrict__ img) {
+  const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x);   // (unit, n-block, lane)
+  if (gid >= EM_ZB_UNITS * 4 * 64) return;
+  const int lane = gid & 63, i = (gid >> 6) & 3, u = gid >> 8;
+  const int m = lane & 15, g = lane >> 4;
+  const int n = 64 * (u & 1) + 16 * i + m, k0 = 32 * (u >> 1);
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = k0 + 8 * g + e;
+    x[e] = k < EM_ZB ? W40[k * EM_C + n] : 0.f;
+  }
+  uint4 s0, s1, s2;
+  em_split8(x, s0, s1, s2);
+  char* dst = img + (long)u * EM_UNIT + (i * 3) * EM_PIECE + lane * 16;
+  *reinterpret_cast<uint4*>(dst) = s0;
+  *reinterpret_cast<uint4*>(dst + EM_PIECE) = s1;
+  *reinterpret_cast<uint4*>(dst + 2 * EM_PIECE) = s2;
+}
+
 // ZB (forward only): a fourth chained layer on the kernel's own output -- zb = [linear_b ; down_z] z' + b40 of the next
 // trunk block's IPA -- so that block needs no pass over z' [P,128] for it (fd_gemm: 119 us per block at B=30 x N=128, 252 MB
 // read); +3 % of the chain's MFMAs, 160 B more written per pair row
 // MASK (forward, training): also write the packed signs of h1 / h2 for the backward's gates
-template <bool BWD, bool ZB = false, bool MASK = false>
+// LNB (backward): the kernel's input dy is formed HERE from the upstream gradient of the transition's output -- the LayerNorm
+// backward of ipa_pytorch.py:232 (dgamma / dbeta accumulated in LDS, one atomic per column and block) -- in layer-output
+// register layout; the backward image then holds its two x-consuming regions in chained k order (fd_edge_mlp_pack x_chained).
+// ZBW (with LNB): and the upstream gradient first gets the IPA pair-projection term  dz += dzb W40  of the block behind this
+// transition (autograd of linear_b / down_z w.r.t. z, ipa_pytorch.py:380-386,455) as a K = 40 product on four leading units.
+template <bool BWD, bool ZB = false, bool MASK = false, bool LNB = false, bool ZBW = false>
 __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpDesc d) {
-  constexpr int EM_NSTAGE = (EM_UNITS + (ZB ? EM_ZB_UNITS : 0)) / EM_UPS;
+  constexpr int EM_NSTAGE = (EM_UNITS + (ZB ? EM_ZB_UNITS : 0) + (ZBW ? EM_ZB_UNITS : 0)) / EM_UPS;
   __shared__ __attribute__((aligned(16))) char lds[EM_RING * EM_STAGE];
+  __shared__ float lnacc[LNB ? 2 * EM_C : 1];      // dgamma | dbeta of the fused LayerNorm backward
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
   const long rows = d.rows;
+#ifdef EM_PHASE_TIMING
+  long long p0_ = 0, p1_ = 0, p2_ = 0, p3_ = 0, p4_ = 0, p5_ = 0, p6_ = 0, p7_ = 0, p8_ = 0, p9_ = 0;
+  long long tb_ = 0, tl_ = (long long)__builtin_amdgcn_s_memtime();
+  auto em_add = [&](int i, long long v) {       // (i is a literal at every call site)
+    switch (i) {
+      case 0: p0_ += v; break;
+      case 2: p2_ += v; break;
+      case 3: p3_ += v; break;
+      case 4: p4_ += v; break;
+      case 5: p5_ += v; break;
+      case 6: p6_ += v; break;
+      case 7: p7_ += v; break;
+      case 8: p8_ += v; break;
+      default: p9_ += v; break;
+    }
+  };
+#endif
   // row strides of the per-residue terms (0 = dense [B*nres, 384] / [B*nres, 128]; a caller that forms all four with one
   // GEMM passes the width of that GEMM's output)
   const long ld_pq = d.ld_pq > 0 ? d.ld_pq : EM_H, ld_pqf = d.ld_pqf > 0 ? d.ld_pqf : EM_C;
@@ -145,7 +213,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
   const char* __restrict__ img_lane = static_cast<const char*>(d.img) + wave * (EM_STAGE / EM_WAVES) + lane * 16;
   char* const lds_wave = lds + wave * (EM_STAGE / EM_WAVES);
   int issued = 0, consumed = 0;
-  auto issue_stage = [&]() {
+  auto issue_stage = [&]() __attribute__((always_inline)) {
     const char* src = img_lane + (long)(issued % EM_NSTAGE) * EM_STAGE;
     char* dst = lds_wave + (issued % EM_RING) * EM_STAGE;
     fd::glds16x4(src, dst);
@@ -154,27 +222,33 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
   };
   // begin the next stage: its copy (issued one stage ago) has landed and is visible to the block; every wave is done
   // with the previous stage, whose buffer takes the copy after next.  Returns the stage's LDS address + 16 * lane.
-  auto stage_begin = [&]() -> const char* {
+  auto stage_begin = [&]() __attribute__((always_inline)) -> const char* {
     // EM_RING == 3: the copy of the stage AFTER this one (6 LDS-DMA instructions per wave, issued during the previous
     // stage) may stay in flight across the barrier -- vmcnt retires in issue order, so "at most 6 outstanding" means this
     // stage's copy, issued before them, has landed (any other memory operation issued since only makes the wait stricter)
     // (no younger copy in flight -- the last stage of the launch: wait for everything)
+    EM_TICK_TO(tb_);
     if (EM_RING == 3 && issued > consumed + 1)
       fd::wait_vmem_keep6();
     else
       fd::wait_vmem();
     __syncthreads();
+    EM_TICK_TO(p1_);
     const char* cur = lds + (consumed % EM_RING) * EM_STAGE + lane * 16;
     ++consumed;
     return cur;
   };
   // the copy of the stage after this one goes out behind the first unit's fragment reads and MFMAs (it has the other
   // three units' time to land; issuing it first would put ~500 cycles of LDS-DMA issue in front of every stage)
-  auto stage_prefetch = [&]() {
+  auto stage_prefetch = [&]() __attribute__((always_inline)) {
     if (issued < total_stages) issue_stage();
   };
   issue_stage();
   if (EM_RING == 3 && total_stages > 1) issue_stage();
+  if (LNB) {
+    if (tid < 2 * EM_C) lnacc[tid] = 0.f;           // (ordered before its first use by the first stage barrier / the one below)
+    __syncthreads();
+  }
 
   for (int ti = 0; ti < nmine; ++ti) {
     const long row = ((long)first + (long)ti * G) * EM_ROWS + wave * 16 + m;
@@ -183,9 +257,9 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
     const long qi = rc / d.nres;                  // (b, i)
     const long qj = (qi / d.nres) * d.nres + (rc - qi * d.nres);   // (b, j)
 
-    // x in B-operand layout: k = 32 ks + 8 g + e
+    // x in B-operand layout: k = 32 ks + 8 g + e  (LNB: slot e' of k-step ks holds k = 32 ks + 16 (e' >> 2) + 4 g + (e' & 3))
     float xr[4][8];
-    {
+    if (!LNB) {
       const float* xp = d.x + rc * EM_C + 8 * g;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -194,8 +268,104 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
         xr[ks][0] = v.x; xr[ks][1] = v.y; xr[ks][2] = v.z; xr[ks][3] = v.w;
         xr[ks][4] = w.x; xr[ks][5] = w.y; xr[ks][6] = w.z; xr[ks][7] = w.w;
       }
+    } else {
+      // ---- fused prologue of the backward: dz (upstream) [+ dzb W40]  ->  LayerNorm backward  ->  dy, in layer-output layout
+      // (lane (m, g): columns 16 nb + 4 g + r) ----
+      f32x4 X[8];
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d.x != nullptr) v = *reinterpret_cast<const float4*>(d.x + rc * EM_C + 16 * nb + 4 * g);
+        X[nb][0] = v.x; X[nb][1] = v.y; X[nb][2] = v.z; X[nb][3] = v.w;
+      }
+      if (ZBW) {
+        // X += dzb W40: operand = the row's 40 values of dzb in natural k order (two 32-k steps, zero beyond k = 40), four
+        // leading units of the image = W40^T (n = 128 columns in two n-groups), the upstream gradient as the initial value
+        float kz[2][8];
+        {
+          const float* zp = d.dzb + rc * EM_ZB + 8 * g;
+          const float4 v = *reinterpret_cast<const float4*>(zp);
+          const float4 w = *reinterpret_cast<const float4*>(zp + 4);
+          kz[0][0] = v.x; kz[0][1] = v.y; kz[0][2] = v.z; kz[0][3] = v.w;
+          kz[0][4] = w.x; kz[0][5] = w.y; kz[0][6] = w.z; kz[0][7] = w.w;
+          float4 v1 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = v1;
+          if (g == 0) {
+            v1 = *reinterpret_cast<const float4*>(d.dzb + rc * EM_ZB + 32);
+            w1 = *reinterpret_cast<const float4*>(d.dzb + rc * EM_ZB + 36);
+          }
+          kz[1][0] = v1.x; kz[1][1] = v1.y; kz[1][2] = v1.z; kz[1][3] = v1.w;
+          kz[1][4] = w1.x; kz[1][5] = w1.y; kz[1][6] = w1.z; kz[1][7] = w1.w;
+        }
+        uint4 bz[3];
+        Em16Half Hz[2];
+#pragma clang loop unroll(full)
+        for (int sg = 0; sg < EM_ZB_UNITS / EM_UPS; ++sg) {
+          const char* st = stage_begin();
+          em16_read_half(Hz[0], st);
+#pragma clang loop unroll(full)
+          for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
+            const int r = EM_UPS * sg + (hh >> 1), g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
+            if (hh + 1 < 2 * EM_UPS) em16_read_half(Hz[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
+            fd::sched_pin();
+            if (g2 == 0 && (hh & 1) == 0) em_split8(kz[r >> 1], bz[0], bz[1], bz[2]);
+            em16_mma_half(X[a], X[a + 1], Hz[hh & 1], bz);
+            if (hh == 1) stage_prefetch();
+          }
+        }
+      }
+      {
+        const float rs = (d.ln_rowscale != nullptr ? d.ln_rowscale[rc] : 1.f) * (rok ? 1.f : 0.f);
+        const float mean = d.ln_mean[rc], rstd = d.ln_rstd[rc];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+          const int col = 16 * nb + 4 * g;
+          const float4 yv = *reinterpret_cast<const float4*>(d.ln_y + rc * EM_C + col);
+          const float4 gm = *reinterpret_cast<const float4*>(d.ln_gamma + col);
+          const float hv[4] = {yv.x, yv.y, yv.z, yv.w}, gv[4] = {gm.x, gm.y, gm.z, gm.w};
+          float cg[4], cb[4];      // this tile's 16-row sums for dgamma / dbeta of columns col .. col + 3 (DPP row reduction)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = (hv[e] - mean) * rstd;
+            const float gy = X[nb][e] * rs;
+            cg[e] = fd::row16_sum(gy * xh);
+            cb[e] = fd::row16_sum(gy);
+            const float t = gy * gv[e];
+            X[nb][e] = t;
+            s1 += t;
+            s2 += t * xh;
+          }
+          if (m == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              fd::lds_add(&lnacc[col + e], cg[e]);
+              fd::lds_add(&lnacc[EM_C + col + e], cb[e]);
+            }
+          }
+        }
+        s1 += __shfl_xor(s1, 16);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 16);
+        s2 += __shfl_xor(s2, 32);
+        const float m1 = s1 * (1.0f / 128.0f), m2 = s2 * (1.0f / 128.0f);
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+          const int col = 16 * nb + 4 * g;
+          const float4 yv = *reinterpret_cast<const float4*>(d.ln_y + rc * EM_C + col);   // (second read: an L1 / L2 hit)
+          const float hv[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) X[nb][e] = rstd * (X[nb][e] - m1 - (hv[e] - mean) * rstd * m2);
+          if (d.dy_out != nullptr && rok)
+            *reinterpret_cast<float4*>(d.dy_out + row * EM_C + col) = make_float4(X[nb][0], X[nb][1], X[nb][2], X[nb][3]);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xr[ks][e] = X[2 * ks + (e >> 2)][e & 3];
     }
 
+    EM_BODY_TO(LNB ? 9 : 0);
     // backward with packed ReLU gates (gmask1 / gmask2: the forward's mask2 / mask1 outputs): bit 4 nb + e of word (row, chunk c,
     // g) says whether hidden unit 128 c + 16 nb + 4 g + e was positive -- 6 dwords per lane and tile, fetched here, instead of
     // 3 KB of h2 / h1 per row fetched (and waited for) inside the epilogues
@@ -241,6 +411,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
         }
       }
       // epilogue 1: forward  h1 = relu(acc + P1_i + Q1_j);  backward  d2 = acc gated by h2 > 0
+      EM_BODY_TO(2);
       unsigned bits1 = 0u;
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) {
@@ -271,6 +442,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
           *reinterpret_cast<float4*>(d.save1 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
       }
       if (!BWD && MASK && rok) d.mask1[row * 12 + 4 * c + g] = bits1;
+      EM_BODY_TO(3);
       // ---- layer 2, k in chunk c: units (k-step u2 / 6, n-group u2 % 6) ----
 #pragma clang loop unroll(full)
       for (int sg = 0; sg < 24 / EM_UPS; ++sg) {
@@ -289,6 +461,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
     }
 
     // epilogue 2: forward  h2 = relu(acc2);  backward  d1 = acc2 gated by h1 > 0
+    EM_BODY_TO(4);
     unsigned bits2 = 0u;
 #pragma unroll
     for (int nb = 0; nb < 24; ++nb) {
@@ -320,6 +493,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
       }
     }
 
+    EM_BODY_TO(5);
     // ---- layer 3: 128 outputs x (K = 128 of x, then K = 384 of the hidden layer) ----
     f32x4 acc3[8];
 #pragma unroll
@@ -356,6 +530,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
     }
 
     // ---- final epilogue ----
+    EM_BODY_TO(6);
     if (!BWD) {
       // y = acc + Pf_i + Qf_j ; z' = rowscale * LayerNorm(y).  A row's 128 values sit in four lanes (l & 15 fixed).
       float s = 0.f;
@@ -440,10 +615,39 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
           *reinterpret_cast<float4*>(d.out + row * EM_C + 16 * nb + 4 * g) =
               make_float4(acc3[nb][0], acc3[nb][1], acc3[nb][2], acc3[nb][3]);
     }
+    EM_BODY_TO(BWD ? 7 : 8);
+  }
+#ifdef EM_PHASE_TIMING
+  if (lane == 0) {
+    const long long pv[10] = {p0_, p1_, p2_, p3_, p4_, p5_, p6_, p7_, p8_, p9_};
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+      __hip_atomic_fetch_add(&em_phase[i], (unsigned long long)pv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid == 0) __hip_atomic_fetch_add(&em_phase[10], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+  if (LNB) {
+    __syncthreads();
+    if (tid < EM_C) {
+      if (d.ln_dgamma != nullptr) atomicAdd(d.ln_dgamma + tid, lnacc[tid]);
+    } else if (tid < 2 * EM_C) {
+      if (d.ln_dbeta != nullptr) atomicAdd(d.ln_dbeta + (tid - EM_C), lnacc[tid]);
+    }
   }
 }
 
 }  // namespace
+
+#ifdef EM_PHASE_TIMING
+extern "C" int fd_edge_mlp_phases(unsigned long long* host12, int reset) {
+  if (host12 != nullptr && hipMemcpyFromSymbol(host12, HIP_SYMBOL(em_phase), sizeof(em_phase)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[12] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(em_phase), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 extern "C" int fd_edge_mlp_pack(const float* A1, long rs1, long cs1, const float* A2, long rs2, long cs2,
                                 const float* A3, long rs3, long cs3, const float* A4, long rs4, long cs4, void* img,
@@ -452,8 +656,26 @@ extern "C" int fd_edge_mlp_pack(const float* A1, long rs1, long cs1, const float
   FD_CHECK_ARG(fd_aligned16(img), "fd_edge_mlp_pack: image must be 16-byte aligned");
   EmMat m1{A1, rs1, cs1}, m2{A2, rs2, cs2}, m3{A3, rs3, cs3}, m4{A4, rs4, cs4};
   hipLaunchKernelGGL(edge_mlp_pack16_kernel, dim3(EM_UNITS * 4 * 64 / 256), dim3(256), 0, (hipStream_t)stream, m1, m2, m3,
-                     m4, static_cast<char*>(img));
+                     m4, static_cast<char*>(img), 0);
   FD_CHECK_LAUNCH("fd_edge_mlp_pack");
+  return FD_OK;
+}
+
+extern "C" int fd_edge_mlp_pack_bwd(const float* Wf, const float* W2, const float* W1, long ld, const float* W40, void* img,
+                                    void* stream) {
+  // backward image for the fused-prologue kernel: [4 units W40^T (optional, when W40 != null)] + 128 units of the transposed
+  // chain (A1 = Wf^T, A2 = W2^T, A3 = Wf[:, :128]^T, A4 = W1[:, :128]^T) with the x-consuming regions in chained k order
+  FD_CHECK_ARG(Wf && W2 && W1 && img, "fd_edge_mlp_pack_bwd: null operand");
+  FD_CHECK_ARG(fd_aligned16(img), "fd_edge_mlp_pack_bwd: image must be 16-byte aligned");
+  char* base = static_cast<char*>(img);
+  if (W40 != nullptr) {
+    hipLaunchKernelGGL(edge_mlp_pack_zbw_kernel, dim3(EM_ZB_UNITS * 4 * 64 / 256), dim3(256), 0, (hipStream_t)stream, W40, base);
+    base += (long)EM_ZB_UNITS * EM_UNIT;
+  }
+  EmMat m1{Wf, 1, ld}, m2{W2, 1, ld}, m3{Wf, 1, ld}, m4{W1, 1, ld};
+  hipLaunchKernelGGL(edge_mlp_pack16_kernel, dim3(EM_UNITS * 4 * 64 / 256), dim3(256), 0, (hipStream_t)stream, m1, m2, m3, m4, base,
+                     1);
+  FD_CHECK_LAUNCH("fd_edge_mlp_pack_bwd");
   return FD_OK;
 }
 
@@ -469,7 +691,10 @@ extern "C" int fd_edge_mlp_pack_zb(const float* W40, void* img, void* stream) {
 extern "C" int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream) {
   FD_CHECK_ARG(desc != nullptr, "fd_edge_mlp: null descriptor");
   const FdEdgeMlpDesc& d = *desc;
-  FD_CHECK_ARG(d.x && d.img && d.out, "fd_edge_mlp: x / img / out are required");
+  FD_CHECK_ARG(d.img && d.out && (d.x || (d.backward && d.ln_y && d.dzb)), "fd_edge_mlp: x / img / out are required");
+  FD_CHECK_ARG(d.ln_y == nullptr || (d.backward && d.ln_mean && d.ln_rstd && d.ln_gamma),
+               "fd_edge_mlp: the fused LayerNorm backward (ln_y) is a backward option and needs ln_mean / ln_rstd / ln_gamma");
+  FD_CHECK_ARG(d.dzb == nullptr || d.ln_y != nullptr, "fd_edge_mlp: dzb needs the fused LayerNorm-backward prologue (ln_y)");
   FD_CHECK_ARG(d.nres > 0 && d.rows >= 0, "fd_edge_mlp: bad extents");
   if (d.backward) {
     FD_CHECK_ARG((d.gate1 && d.gate2) || (d.gmask1 && d.gmask2),
@@ -479,7 +704,7 @@ extern "C" int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream) {
                  "fd_edge_mlp(forward): p1 / q1 / bias2 / pf / qf / gamma / beta are required");
   }
   const void* ptrs[] = {d.x, d.img, d.out, d.p1, d.q1, d.bias2, d.gate1, d.gate2, d.save1, d.save2, d.pf, d.qf,
-                        d.gamma, d.beta, d.y};
+                        d.gamma, d.beta, d.y, d.ln_y, d.ln_gamma, d.dy_out, d.dzb};
   for (const void* p : ptrs) FD_CHECK_ARG(fd_aligned16(p), "fd_edge_mlp: operands must be 16-byte aligned");
   if (d.rows == 0) return FD_OK;
   const long ntiles = (d.rows + EM_ROWS - 1) / EM_ROWS;
@@ -492,7 +717,11 @@ extern "C" int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream) {
   const dim3 g3(grid), b3(64 * EM_WAVES);
   hipStream_t st = (hipStream_t)stream;
   const bool zbv = d.zb_out != nullptr, mk = d.mask1 != nullptr;
-  if (d.backward)
+  if (d.backward && d.ln_y != nullptr && d.dzb != nullptr)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false, true, true>), g3, b3, 0, st, d);
+  else if (d.backward && d.ln_y != nullptr)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false, true, false>), g3, b3, 0, st, d);
+  else if (d.backward)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false>), g3, b3, 0, st, d);
   else if (zbv && mk)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true, true>), g3, b3, 0, st, d);

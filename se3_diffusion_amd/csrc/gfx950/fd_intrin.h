@@ -129,6 +129,20 @@ __device__ __forceinline__ T wave_sum(T v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// LDS float accumulate without a return value (ds_add_f32): p must point into __shared__ memory
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+}
+
+// sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), the total in every lane: four data-parallel-primitive adds
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), no LDS crossbar
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+  return v;
+}
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
 #pragma unroll

@@ -87,6 +87,8 @@ class FdEdgeMlpDesc(Structure):
         ("rows", c_long), ("nres", c_int), ("backward", c_int), ("eps", c_float), ("blocks", c_int),
         ("ld_pq", c_long), ("ld_pqf", c_long), ("zb_out", c_void_p), ("zb_bias", c_void_p),
         ("mask1", c_void_p), ("mask2", c_void_p), ("gmask1", c_void_p), ("gmask2", c_void_p),
+        ("ln_y", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_gamma", c_void_p), ("ln_rowscale", c_void_p),
+        ("dy_out", c_void_p), ("ln_dgamma", c_void_p), ("ln_dbeta", c_void_p), ("dzb", c_void_p),
     ]
 
 
@@ -162,6 +164,7 @@ _SIGS = {
     "fd_edge_mlp_pack": "pllpllpllpllps",
     "fd_edge_mlp": "Ss",
     "fd_edge_mlp_pack_zb": "pps",
+    "fd_edge_mlp_pack_bwd": "ppplpps",
     "fd_edge_embed_pack": "pppps",
     "fd_edge_embed": "Ss",
     "fd_edge_embed_pack_zb": "pps",

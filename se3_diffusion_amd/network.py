@@ -332,9 +332,10 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None):
     return x1, sv
 
 
-def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True):
+def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True, defer_dz=False):
     """dx1 [R,256] -> accumulates ds (view, +=), dz [P,128] (+= ; = when dz_accumulate is False), dframe [R,12] (+=);
-    param grads into G."""
+    param grads into G.  defer_dz: leave dz alone and return (dzb, W40) -- the consumer of dz adds dzb W40 itself (the fused
+    backward of the edge transition in front of this block); returns None otherwise."""
     B, N = sv["B"], sv["N"]
     R, Pn = B * N, B * N * N
     dev = dx1
@@ -383,7 +384,9 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True):
            a_bs=(H * N * N, N * N), b_bs=(N * LDP, C), c_bs=(N * LDP, 2 * C), alpha=sc)
     L.call("fd_ipa_points_bwd", proj, quat, dqp, dkp, dvp, dproj, dframe, R, H, C, PQ, PV)
     # z path: dz += dzb W40 (streaming kernel, W40 resident in registers) ; dW40 += dzb^T z
-    if sv["W40"].is_contiguous():
+    if defer_dz:
+        pass
+    elif sv["W40"].is_contiguous():
         L.call("fd_ipa_dz_acc", dzb, sv["W40"], dz, Pn, int(bool(dz_accumulate)))
     else:
         ops.linear_dx(mv(dzb), mv(sv["W40"]), mv(dz), Pn, ZB, CZ, beta=bool(dz_accumulate))
@@ -411,11 +414,12 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True):
         ops.linear_dx(mv(dproj), mv(pv[0]), ds, R, LDP, CS, beta=True)
         if not ops.queue_dw(mv(dproj), s, mv(gv[0]), R, LDP, CS, db=gv[1]):
             ops.side(lambda: ops.linear_dw(mv(dproj), s, mv(gv[0]), R, LDP, CS, db=gv[1]), (dproj, s[0]), R)
-        return
+        return (dzb, sv["W40"]) if defer_dz else None
     for name, off, n in (("linear_q", 0, 2048), ("linear_kv", 2048, 4096), ("linear_q_points", 6144, 192),
                          ("linear_kv_points", 6336, 480)):
         ops.linear_dx((dproj, off, LDP), mv(P[f"{pre}.{name}.weight"]), ds, R, n, CS, beta=True)
         _lin_grads(G, f"{pre}.{name}.weight", f"{pre}.{name}.bias", (dproj, off, LDP), s, R, n, CS)
+    return (dzb, sv["W40"]) if defer_dz else None
 
 
 # --------------------------------------------------------------------------- LN + skip concat

@@ -349,16 +349,28 @@ def edge_mlp_pack(W1, W2, Wf, backward=False, out=None, W40=None):
     return img
 
 
+def edge_mlp_pack_bwd(Wf, W2, W1, W40=None, out=None):
+    """Backward image for edge_mlp(..., backward=True, ln_y=...): the transposed chain with its input-consuming regions in
+    chained k order, preceded by W40^T [128 <- 40] (the IPA block behind the transition) when the dzb term is fused."""
+    img = out if out is not None else torch.empty(hip.EDGE_MLP_IMAGE_BYTES, dtype=torch.uint8, device=W1.device)
+    assert W40 is None or (W40.is_contiguous() and tuple(W40.shape) == (40, 128))
+    lib().call("fd_edge_mlp_pack_bwd", Wf, W2, W1, 384, W40, img)
+    return img
+
+
 def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, qf=None, gamma=None, beta=None,
              rowscale=None, gate1=None, gate2=None, save1=None, save2=None, y=None, mean=None, rstd=None,
              backward=False, blocks=0, ld_pq=0, ld_pqf=0, zb_out=None, zb_bias=None, mask1=None, mask2=None, gmask1=None,
-             gmask2=None):
+             gmask2=None, ln_y=None, ln_mean=None, ln_rstd=None, ln_gamma=None, ln_rowscale=None, dy_out=None, ln_dgamma=None,
+             ln_dbeta=None, dzb=None):
     d = hip.FdEdgeMlpDesc()
     tens = []
     for name, t in (("x", x), ("img", img), ("p1", p1), ("q1", q1), ("bias2", bias2), ("gate1", gate1), ("gate2", gate2),
                     ("save1", save1), ("save2", save2), ("pf", pf), ("qf", qf), ("gamma", gamma), ("beta", beta),
                     ("rowscale", rowscale), ("y", y), ("mean", mean), ("rstd", rstd), ("out", out), ("zb_out", zb_out),
-                    ("zb_bias", zb_bias), ("mask1", mask1), ("mask2", mask2), ("gmask1", gmask1), ("gmask2", gmask2)):
+                    ("zb_bias", zb_bias), ("mask1", mask1), ("mask2", mask2), ("gmask1", gmask1), ("gmask2", gmask2),
+                    ("ln_y", ln_y), ("ln_mean", ln_mean), ("ln_rstd", ln_rstd), ("ln_gamma", ln_gamma), ("ln_rowscale", ln_rowscale),
+                    ("dy_out", dy_out), ("ln_dgamma", ln_dgamma), ("ln_dbeta", ln_dbeta), ("dzb", dzb)):
         setattr(d, name, None if t is None else t.data_ptr())
         if t is not None:
             tens.append(t)

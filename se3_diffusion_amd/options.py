@@ -42,18 +42,18 @@ class Options:
     pair_dw_blocks: int = 160         # FD_PAIR_DW_BLOCKS: blocks of fd_pair_dw when it runs beside the main stream (0 = 256)
     edge_blocks: int = 0              # FD_EDGE_BLOCKS: persistent blocks of the fused edge kernels (0 = 512)
     packed_gates: bool = True         # FD_PACKED_GATES: the fused edge backward gates on packed sign bits instead of reading h1 / h2
+    fused_ln_bwd: bool = True         # FD_EDGE_LN_BWD: the edge transition's LayerNorm backward (and the IPA term dz += dzb W40 of
+                                      # the block behind it) as the prologue of its fused backward kernel
     zb_from_edge: bool = True         # FD_ZB_FUSED: the next IPA block's pair projection zb as a 4th layer of fd_edge_mlp
     fold_node_terms: bool = True      # FD_FOLD_NODE_TERMS: sampling -- per-residue terms of an edge transition as one GEMM
     # -- IPA
     fused_ipa_attn: bool = True       # FD_IPA_ATTN_FUSED: logits + softmax + o_pair of a query row in one launch
-    flash_ipa: bool = True            # FD_IPA_FLASH: q k^T, softmax, a v, o_pt, o_pair in one kernel (A never in HBM)
     proj_merge: bool = True           # FD_PROJ_MERGE: IPA's four projections of s as one GEMM over back-to-back weights
     # -- node level
     fused_seq_attn: bool = True       # FD_SEQ_ATTN_FUSED: sequence-transformer attention in one launch ...
     seq_attn_min_rows: int = 1024     # FD_SEQ_ATTN_MIN_ROWS: ... from this many residue rows up
     grouped_node_dw: bool = True      # FD_NODE_DW: the node-level weight gradients of a trunk block in one grouped launch
     node_dw_blocks: int = 0           # FD_NODE_DW_BLOCKS: its persistent blocks (0 = 512: two per CU)
-    node_chain: bool = True           # FD_NODE_CHAIN: sampling (M = B*N <= 1024 rows) -- the node-level chain of a block fused
     # -- backward bookkeeping
     zero_arena: bool = True           # FD_ZERO_ARENA: one memset for every zero-initialised accumulator of a backward pass
     dx_splitk: bool = True            # FD_DX_SPLITK: accumulating dX GEMMs with a long reduction split over K (atomics)
@@ -66,12 +66,13 @@ class Options:
             fused_edge=_flag("FD_EDGE_FUSED", True), fused_embed=_flag("FD_EMBED_FUSED", True),
             fused_embed_bwd=_flag("FD_EMBED_BWD_FUSED", True),
             grouped_pair_dw=_flag("FD_PAIR_DW", True), pair_dw_blocks=_int("FD_PAIR_DW_BLOCKS", 160),
-            edge_blocks=_int("FD_EDGE_BLOCKS", 0), zb_from_edge=_flag("FD_ZB_FUSED", True), packed_gates=_flag("FD_PACKED_GATES", True), fold_node_terms=_flag("FD_FOLD_NODE_TERMS", True),
-            fused_ipa_attn=_flag("FD_IPA_ATTN_FUSED", True), flash_ipa=_flag("FD_IPA_FLASH", True),
+            edge_blocks=_int("FD_EDGE_BLOCKS", 0), zb_from_edge=_flag("FD_ZB_FUSED", True),
+            fused_ln_bwd=_flag("FD_EDGE_LN_BWD", True), packed_gates=_flag("FD_PACKED_GATES", True),
+            fold_node_terms=_flag("FD_FOLD_NODE_TERMS", True),
+            fused_ipa_attn=_flag("FD_IPA_ATTN_FUSED", True),
             proj_merge=_flag("FD_PROJ_MERGE", True),
             fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),
             grouped_node_dw=_flag("FD_NODE_DW", True), node_dw_blocks=_int("FD_NODE_DW_BLOCKS", 0),
-            node_chain=_flag("FD_NODE_CHAIN", True),
             zero_arena=_flag("FD_ZERO_ARENA", True), dx_splitk=_flag("FD_DX_SPLITK", True))
 
 

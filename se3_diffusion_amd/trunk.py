@@ -159,22 +159,46 @@ def edge_transition_fwd_unfused(P, b, n3, z, emask, B, N):
     return z2, dict(n3=n3, z=z, e=e, h1=h1, h2=h2, y=y, mean=mean, rstd=rstd, emask=emask, B=B, N=N)
 
 
-def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
-    """dz2 [P,128] -> dz [P,128] (=), dn3 (+=)."""
+def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3, dzb_next=None):
+    """dz2 [P,128] (gradient of the transition's output; None when dzb_next carries all of it) -> dz [P,128] (=), dn3 (+=).
+    dzb_next = (dzb [P,40], W40 [40,128]) of the IPA block BEHIND this transition: its pair-projection term dzb W40 still has
+    to be added to dz2 (the fused backward kernel does it in its prologue; the other paths through fd_ipa_dz_acc here)."""
     pre = f"score_model.trunk.edge_transition_{b}"
     B, N = sv["B"], sv["N"]
     R, Pn = B * N, B * N * N
-    dev = dz2
+    dev = sv["z"]
     L = lib()
     W1, W2, Wf = P[f"{pre}.trunk.0.weight"], P[f"{pre}.trunk.2.weight"], P[f"{pre}.final_layer.weight"]
     z, e, h1, h2 = sv["z"], sv["e"], sv["h1"], sv["h2"]
-    dy = empty((Pn, CZ), dev)
-    ops.layernorm_bwd(mv(dz2), mv(sv["y"]), P[f"{pre}.layer_norm.weight"], sv["mean"], sv["rstd"], mv(dy), Pn, CZ,
-                      rowscale=sv["emask"], dgamma=G[f"{pre}.layer_norm.weight"], dbeta=G[f"{pre}.layer_norm.bias"])
-    # y = Wf h2 + Wf[:, :128] z + Pf_i + Qf_j (+bf inside Qf)
-    gWf = G[f"{pre}.final_layer.weight"]
     fused = fused_edge()
+    fused_ln = fused and opts.fused_ln_bwd and (dzb_next is None or dzb_next[1].is_contiguous())
+    if dzb_next is not None and not fused_ln:
+        # materialise the IPA term first (streaming kernel, W40 resident in registers)
+        dzb, W40 = dzb_next
+        if dz2 is None:
+            dz2 = empty((Pn, CZ), dev)
+            L.call("fd_ipa_dz_acc", dzb, W40.contiguous(), dz2, Pn, 0)
+        else:
+            L.call("fd_ipa_dz_acc", dzb, W40.contiguous(), dz2, Pn, 1)
+    dy = empty((Pn, CZ), dev)
+    gWf = G[f"{pre}.final_layer.weight"]
+    gW1 = G[f"{pre}.trunk.0.weight"]
     grouped_dw = fused and opts.grouped_pair_dw
+    dh2 = dh1 = None
+    if fused_ln:
+        # ONE launch: (dz2 + dzb W40) -> LayerNorm backward (dgamma, dbeta) -> dy -> d2 = [h2 > 0] dy Wf -> d1 = [h1 > 0] d2 W2 ->
+        # dz = dy Wf_z + d1 W1_z; dy, d2, d1 are written once for the weight gradients and the pair reductions
+        dh2 = empty((Pn, EH), dev); dh1 = empty((Pn, EH), dev)
+        img = ops.edge_mlp_pack_bwd(Wf, W2, W1, W40=dzb_next[1] if dzb_next is not None else None)
+        gk = dict(gmask1=sv["mh2"], gmask2=sv["mh1"]) if sv.get("mh1") is not None else dict(gate1=h2, gate2=h1)
+        ops.edge_mlp(dz2, img, dz, Pn, N, save1=dh2, save2=dh1, backward=True, ln_y=sv["y"], ln_mean=sv["mean"],
+                     ln_rstd=sv["rstd"], ln_gamma=P[f"{pre}.layer_norm.weight"], ln_rowscale=sv["emask"], dy_out=dy,
+                     ln_dgamma=G[f"{pre}.layer_norm.weight"], ln_dbeta=G[f"{pre}.layer_norm.bias"],
+                     dzb=dzb_next[0] if dzb_next is not None else None, **gk)
+    else:
+        ops.layernorm_bwd(mv(dz2), mv(sv["y"]), P[f"{pre}.layer_norm.weight"], sv["mean"], sv["rstd"], mv(dy), Pn, CZ,
+                          rowscale=sv["emask"], dgamma=G[f"{pre}.layer_norm.weight"], dbeta=G[f"{pre}.layer_norm.bias"])
+    # y = Wf h2 + Wf[:, :128] z + Pf_i + Qf_j (+bf inside Qf)
     if not grouped_dw:
         def _grads_y():
             ops.linear_dw(mv(dy), mv(h2), mv(gWf), Pn, CZ, EH)
@@ -192,13 +216,13 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3):
     de = empty((R, CE), dev)
     ops.linear_dx(mv(dPf), (Wf, CZ, EH), mv(de), R, CZ, CE)
     ops.linear_dx(mv(dQf), (Wf, CZ + CE, EH), mv(de), R, CZ, CE, beta=True)
-    gW1 = G[f"{pre}.trunk.0.weight"]
     if fused:
-        # the dX chain in one launch: d2 = [h2 > 0] dy Wf, d1 = [h1 > 0] d2 W2, dz = dy Wf_z + d1 W1_z (fd_edge_mlp with
-        # the transposed weight image); d2 / d1 are written once, for the weight-gradient GEMMs and the pair reductions
-        dh2 = empty((Pn, EH), dev); dh1 = empty((Pn, EH), dev)
-        gk = dict(gmask1=sv["mh2"], gmask2=sv["mh1"]) if sv.get("mh1") is not None else dict(gate1=h2, gate2=h1)
-        ops.edge_mlp(dy, _edge_mlp_image(P, pre, None, backward=True), dz, Pn, N, save1=dh2, save2=dh1, backward=True, **gk)
+        if not fused_ln:
+            # the dX chain in one launch: d2 = [h2 > 0] dy Wf, d1 = [h1 > 0] d2 W2, dz = dy Wf_z + d1 W1_z (fd_edge_mlp with
+            # the transposed weight image); d2 / d1 are written once, for the weight-gradient GEMMs and the pair reductions
+            dh2 = empty((Pn, EH), dev); dh1 = empty((Pn, EH), dev)
+            gk = dict(gmask1=sv["mh2"], gmask2=sv["mh1"]) if sv.get("mh1") is not None else dict(gate1=h2, gate2=h1)
+            ops.edge_mlp(dy, _edge_mlp_image(P, pre, None, backward=True), dz, Pn, N, save1=dh2, save2=dh1, backward=True, **gk)
         if grouped_dw:
             # every pair-row weight gradient of the transition in ONE grouped launch (fd_pair_dw): dW2 = d2^T h1 as three
             # 384 x 128 tiles (+ its bias gradient), dW1[:, z part] = d1^T z, dWf = dy^T (h2 + [z | 0]) stored transposed
@@ -495,6 +519,7 @@ def _backward(P, G, sv, d_out, notify):
     notify("heads")
     dinit = zeros((R, CS), dev)
     dz = None
+    pend = None     # (dzb, W40) of the IPA block just processed whose term dz += dzb W40 the next consumer still has to add
     for b in reversed(range(nb)):
         st = sv["stages"][b]
         dn3 = dnode
@@ -502,7 +527,8 @@ def _backward(P, G, sv, d_out, notify):
         if st["et"] is not None:
             dz_in = empty((Pn, CZ), dev)
             with rng(f"edge_transition_{b}.bwd"):
-                edge_transition_bwd(P, G, b, st["et"], dz, dz_in, dn3)
+                edge_transition_bwd(P, G, b, st["et"], dz, dz_in, dn3, dzb_next=pend)
+            pend = None
         dframe = zeros((R, 12), dev)
         # IPA backward needs dx1, which needs dn3 complete (incl. bb_update's contribution), but bb_update's
         # input-frame gradient needs the IPA's dframe: split bb_update in two steps via a zero dframe first.
@@ -518,12 +544,16 @@ def _backward(P, G, sv, d_out, notify):
             dx1 = empty((R, CS), dev)
             nw.ln_skip_bwd(P, G, b, st["ln"], du0, dx1, dinit)
         ds = zeros((R, CS), dev)
+        # the z gradient of this IPA (dzb W40) is added by the consumer of dz when that is a fused edge-transition backward
+        # (the transition of block b - 1: its kernel's prologue); else here (fd_ipa_dz_acc)
+        defer = b > 0 and fused_edge() and opts.fused_ln_bwd and sv["stages"][b - 1]["et"] is not None
         dz_acc = dz_in is not None
-        if dz_in is None:
+        if dz_in is None and not defer:
             # last block: no edge transition behind this IPA, its z gradient IS dz (ipa_bwd assigns)
             dz_in = empty((Pn, CZ), dev)
         with rng(f"ipa_{b}.bwd"):
-            nw.ipa_bwd(P, G, f"score_model.trunk.ipa_{b}", st["ipa"], dx1, mv(ds), dz_in, dframe, dz_accumulate=dz_acc)
+            pend = nw.ipa_bwd(P, G, f"score_model.trunk.ipa_{b}", st["ipa"], dx1, mv(ds), dz_in, dframe, dz_accumulate=dz_acc,
+                              defer_dz=defer)
         # fold the IPA frame gradients (dL/dR, dL/dt of the block's input frame) into (dq, dt)
         _frame_grad_fold(st["bb"]["quat"], dframe, dq_in, dt_in, R)
         dq, dt, dnode, dz = dq_in, dt_in, ds, dz_in

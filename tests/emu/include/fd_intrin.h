@@ -168,6 +168,17 @@ static inline T wave_sum(T v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+static inline void lds_add(float* p, float v) { *p += v; }      // (fibers of a block run one at a time)
+
+// (the same four exchanges as the DPP controls of the device version, so the additions pair up identically)
+static inline float row16_sum(float v) {
+  const int l = hipemu::g_cur->lane;
+  v += __shfl(v, l ^ 1);
+  v += __shfl(v, l ^ 2);
+  v += __shfl(v, (l & ~7) | (7 - (l & 7)));
+  v += __shfl(v, (l & ~15) | (15 - (l & 15)));
+  return v;
+}
 template <typename T>
 static inline T wave_max(T v) {
   for (int o = 32; o > 0; o >>= 1) { T u = __shfl_xor(v, o); v = v > u ? v : u; }

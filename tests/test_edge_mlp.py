@@ -98,6 +98,35 @@ def _run(dev, B, N, seed=0, blocks=0):
     dz2, d22, d12 = e(P, 128), e(P, 384), e(P, 384)
     ops.edge_mlp(t["dy"], imgT, dz2, P, N, gmask1=mh2, gmask2=mh1, save1=d22, save2=d12, backward=True, blocks=blocks)
     assert torch.equal(dz2, dz) and torch.equal(d22, d2) and torch.equal(d12, d1)
+    # fused prologue: the kernel's input dy = LayerNorm backward of the upstream gradient (x emask), with and without the IPA
+    # pair-projection term dzb W40 (of the block behind the transition) added to the upstream gradient first -- against the
+    # unfused pieces: fd_layernorm_bwd (+ a float64 dzb W40) and the plain gated backward
+    gu = torch.Generator().manual_seed(seed + 200)
+    up = torch.randn(P, 128, generator=gu).to(dev)
+    dzb = (torch.randn(P, 40, generator=gu) * 0.5).to(dev)
+    mvw = lambda a: (a, 0, a.shape[-1])
+    for with_zb, with_up in ((False, True), (True, True), (True, False)):
+        up_full = (up.double() if with_up else 0) + (dzb.double() @ W40.double() if with_zb else 0)
+        up32 = up_full.float().contiguous()
+        dyr, dgr, dbr = e(P, 128), torch.zeros(128, device=dev), torch.zeros(128, device=dev)
+        ops.layernorm_bwd(mvw(up32), mvw(y), t["gamma"], mean, rstd, mvw(dyr), P, 128, rowscale=t["emask"], dgamma=dgr, dbeta=dbr)
+        dzr, d2r, d1r = e(P, 128), e(P, 384), e(P, 384)
+        ops.edge_mlp(dyr, imgT, dzr, P, N, gmask1=mh2, gmask2=mh1, save1=d2r, save2=d1r, backward=True, blocks=blocks)
+        imgB = ops.edge_mlp_pack_bwd(t["Wf"], t["W2"], t["W1"], W40=W40 if with_zb else None)
+        dyf, dzf, d2f, d1f = e(P, 128), e(P, 128), e(P, 384), e(P, 384)
+        dgf, dbf = torch.zeros(128, device=dev), torch.zeros(128, device=dev)
+        ops.edge_mlp(up if with_up else None, imgB, dzf, P, N, gmask1=mh2, gmask2=mh1, save1=d2f, save2=d1f, backward=True,
+                     blocks=blocks, ln_y=y, ln_mean=mean, ln_rstd=rstd, ln_gamma=t["gamma"], ln_rowscale=t["emask"], dy_out=dyf,
+                     ln_dgamma=dgf, ln_dbeta=dbf, dzb=dzb if with_zb else None)
+        ref = lambda a: a.double().cpu()
+        assert rel(dyf, ref(dyr)) < 1e-5, (with_zb, with_up, rel(dyf, ref(dyr)))
+        assert rel(dgf, ref(dgr)) < 1e-5 and rel(dbf, ref(dbr)) < 1e-5
+        assert rel(d2f, ref(d2r)) < 1e-5 and rel(d1f, ref(d1r)) < 1e-5 and rel(dzf, ref(dzr)) < 1e-5
+        # the gate-tensor form of the same launch
+        dzg = e(P, 128)
+        ops.edge_mlp(up if with_up else None, imgB, dzg, P, N, gate1=h2, gate2=h1, backward=True, blocks=blocks, ln_y=y,
+                     ln_mean=mean, ln_rstd=rstd, ln_gamma=t["gamma"], ln_rowscale=t["emask"], dzb=dzb if with_zb else None)
+        assert torch.equal(dzg, dzf)
 
 
 def test_edge_mlp_emu(use_emu):

@@ -54,6 +54,8 @@ GROUPS = [
     (dict(fused_embed_bwd=False), 5e-5),
     (dict(zb_from_edge=False), 5e-5),
     (dict(packed_gates=False), 5e-5),
+    (dict(fused_ln_bwd=False), 5e-5),
+    (dict(fused_ln_bwd=False, packed_gates=False), 5e-5),
     (dict(fused_edge=False, fused_embed=False), 2e-4),
 ]
 
@@ -76,6 +78,11 @@ def test_switches_emu(use_emu):
     _compare("cpu", B=2, N=8, blocks=1)
 
 
+def test_switches_two_blocks_emu(use_emu):
+    # with an edge transition between the blocks: the fused LayerNorm-backward / dzb W40 prologue against the separate kernels
+    _compare("cpu", B=1, N=8, blocks=2, groups=[GROUPS[7], GROUPS[8], GROUPS[9]])
+
+
 def test_options_override_restores():
     was = options.opts.fused_edge
     with options.override(fused_edge=not was):
@@ -89,4 +96,4 @@ def test_options_override_restores():
 @pytest.mark.gpu
 def test_switches_gpu(hip_lib):
     _compare("cuda", B=2, N=24, blocks=2)
-    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:3] + GROUPS[4:8])
+    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:3] + GROUPS[4:10])

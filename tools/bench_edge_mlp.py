@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--shapes", default="30x128,1x256,8x128,1x128,1x512")
     ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--fwd-only", action="store_true", help="only the no-save forward (PMC runs)")
+    ap.add_argument("--lnb", action="store_true", help="the backward with the fused LayerNorm-backward / dzb W40 prologue "
+                    "against the separate kernels")
     a = ap.parse_args()
     dev = "cuda"
     P = {k: v.to(dev) for k, v in fo.synth_params(seed=0, conf=dict(fo.CONF, num_blocks=2)).items()}
@@ -53,6 +55,30 @@ def main():
         t_inf = timeit(lambda: ops.edge_mlp(z, img, out, Pn, N, **kw))
         if a.fwd_only:
             print(f"B={B} N={N}: fused fwd(no save) {t_inf:.3f} ms ({flops / t_inf / 1e9:.0f} TF)")
+            continue
+        if a.lnb:
+            mh1 = torch.zeros(Pn, 12, dtype=torch.int32, device=dev); mh2 = torch.zeros(Pn, 12, dtype=torch.int32, device=dev)
+            ops.edge_mlp(z, img, out, Pn, N, save1=h1, save2=h2, y=y, mean=mean, rstd=rstd, mask1=mh1, mask2=mh2, **kw)
+            up, dzb, dy = e(Pn, 128).normal_(), e(Pn, 40).normal_(), e(Pn, 128)
+            W40 = e(40, 128).normal_()
+            dz, d2, d1, dg, db = e(Pn, 128), e(Pn, 384), e(Pn, 384), torch.zeros(128, device=dev), torch.zeros(128, device=dev)
+            mv = lambda t_: (t_, 0, t_.shape[-1])
+            L = ops.lib()
+            t_acc = timeit(lambda: L.call("fd_ipa_dz_acc", dzb, W40, up, Pn, 1))
+            t_ln = timeit(lambda: ops.layernorm_bwd(mv(up), mv(y), gm, mean, rstd, mv(dy), Pn, 128, rowscale=emask, dgamma=dg,
+                                                    dbeta=db))
+            gk = dict(gmask1=mh2, gmask2=mh1, save1=d2, save2=d1, backward=True, blocks=a.blocks)
+            t_b = timeit(lambda: ops.edge_mlp(dy, imgT, dz, Pn, N, **gk))
+            lk = dict(ln_y=y, ln_mean=mean, ln_rstd=rstd, ln_gamma=gm, ln_rowscale=emask, dy_out=dy, ln_dgamma=dg, ln_dbeta=db)
+            imgB = ops.edge_mlp_pack_bwd(Wf, W2, W1)
+            imgZ = ops.edge_mlp_pack_bwd(Wf, W2, W1, W40=W40)
+            t_f = timeit(lambda: ops.edge_mlp(up, imgB, dz, Pn, N, **gk, **lk))
+            t_fz = timeit(lambda: ops.edge_mlp(up, imgZ, dz, Pn, N, dzb=dzb, **gk, **lk))
+            lk2 = dict(lk, ln_dgamma=None, ln_dbeta=None)
+            t_fn = timeit(lambda: ops.edge_mlp(up, imgB, dz, Pn, N, **gk, **lk2))
+            print(f"B={B} N={N} rows={Pn}: dz_acc {t_acc:.3f} | LN bwd {t_ln:.3f} | backward {t_b:.3f} | sum {t_acc + t_ln + t_b:.3f}"
+                  f" || fused LN {t_f:.3f} (vs {t_ln + t_b:.3f}) | fused LN + dzb {t_fz:.3f} | fused LN, no dgamma flush "
+                  f"{t_fn:.3f} ms", flush=True)
             continue
         t_trn = timeit(lambda: ops.edge_mlp(z, img, out, Pn, N, save1=h1, save2=h2, y=y, mean=mean, rstd=rstd, **kw))
         dz, d2, d1 = e(Pn, 128), e(Pn, 384), e(Pn, 384)
