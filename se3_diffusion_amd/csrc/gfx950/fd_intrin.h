@@ -116,6 +116,8 @@ __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" 
 // (gfx9 retires loads, stores and LDS-DMA in issue order on this counter): with the six LDS-DMA instructions of the NEXT
 // stage issued last, the current stage's copy has landed while the next one stays in flight
 __device__ __forceinline__ void wait_vmem_keep6() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_vmem_keep() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // the instruction scheduler moves nothing across this point (pins a software-pipelined order)
 __device__ __forceinline__ void sched_pin() { __builtin_amdgcn_sched_barrier(0); }

@@ -151,6 +151,8 @@ static inline void glds16x4(const void* g_lane, void* lds_wave_base) {
 }
 static inline void wait_vmem() {}
 static inline void wait_vmem_keep6() {}
+template <int N>
+static inline void wait_vmem_keep() {}
 
 static inline void raise_wave_priority() {}
 
