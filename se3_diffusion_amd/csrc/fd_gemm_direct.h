@@ -44,6 +44,29 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(GemmArgs g) {
   const float* pb = B + (long)rb * d.b_cs + (long)(4 * h) * d.b_rs;
   const long ag = (long)DG * d.a_cs, bg = (long)DG * d.b_rs;   // pointer step per k group
 
+  // epilogue operands of this thread's four outputs (thread -> row tid >> 3, columns 4 (tid & 7) ..): fetched HERE, in front of
+  // the operand loads, so that their round trip runs under the K loop instead of after the reduction barrier (a launch of this
+  // kernel is a chain of dependent latencies; this removes one of them)
+  const int erow = tid >> 3, ec4 = tid & 7;
+  const int em = m0 + erow;
+  const bool erow_ok = em < d.M;
+  float e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_res[4] = {0.f, 0.f, 0.f, 0.f}, e_old[4] = {0.f, 0.f, 0.f, 0.f};
+  float e_gate[4] = {1.f, 1.f, 1.f, 1.f};
+  float e_rs = 1.f;
+  if (erow_ok) {
+    if (d.rowscale) e_rs = d.rowscale[em];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + 4 * ec4 + e;
+      if (n < d.N) {
+        if (d.bias) e_bias[e] = d.bias[n];
+        if (d.gate) e_gate[e] = d.gate[(long)em * d.ld_gate + n];
+        if (d.resid) e_res[e] = d.resid[(long)em * d.ld_resid + n];
+        if (d.beta) e_old[e] = C[(long)em * d.ldc + n];
+      }
+    }
+  }
+
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -89,29 +112,22 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(GemmArgs g) {
   __syncthreads();
 
   // thread -> (row, 4 consecutive columns) of the 32 x 32 tile
-  const int row = tid >> 3, c4 = tid & 7;
-  const int m = m0 + row;
-  if (m >= d.M) return;
-  float v[4];
+  const int row = erow, c4 = ec4;
+  const int m = em;
+  if (!erow_ok) return;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int col = 4 * c4 + e;
-    v[e] = d.alpha * ((part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]));
-  }
-  const float rs = d.rowscale ? d.rowscale[m] : 1.f;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int n = n0 + 4 * c4 + e;
+    const int n = n0 + col;
     if (n >= d.N) continue;
-    float x = v[e];
-    if (d.bias) x += d.bias[n];
+    float x = d.alpha * ((part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]));
+    if (d.bias) x += e_bias[e];
     if (d.relu) x = x > 0.f ? x : 0.f;
-    if (d.gate) x = d.gate[(long)m * d.ld_gate + n] > 0.f ? x : 0.f;
-    x *= rs;
-    if (d.resid) x += d.resid[(long)m * d.ld_resid + n];
-    float* cp = C + (long)m * d.ldc + n;
-    if (d.beta) x += *cp;
-    *cp = x;
+    if (d.gate) x = e_gate[e] > 0.f ? x : 0.f;
+    x *= e_rs;
+    if (d.resid) x += e_res[e];
+    if (d.beta) x += e_old[e];
+    C[(long)m * d.ldc + n] = x;
   }
 }
 
