@@ -269,10 +269,9 @@ __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __res
   const float sq13 = sqrtf(1.0f / 3.0f);
   const float gscale = sqrtf(1.0f / (3.0f * ((float)PQ * 9.0f / 2.0f)));
   if (FUSED) {
-    for (int e = (int)threadIdx.x; e < H * N; e += 256) {
-      const int h = e / N, j = e % N;
-      Ai[h][j] = A[(((long)b * H + h) * N + i) * N + j];
-    }
+    // (thread -> head tid >> 5, keys tid & 31 + 32 k: no division by the run-time N in the element loops)
+    const int eh = (int)threadIdx.x >> 5, ej = (int)threadIdx.x & 31;
+    for (int j = ej; j < N; j += 32) Ai[eh][j] = A[(((long)b * H + eh) * N + i) * N + j];
     dout[threadIdx.x / CZ4][threadIdx.x % CZ4] = dfeats[bi * LDF + F_PAIR + threadIdx.x];
     if (SLAB) {
       const float4* src = reinterpret_cast<const float4*>(zb + bi * N * ZB);
@@ -284,13 +283,12 @@ __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __res
     }
     __syncthreads();
     // dA[b,h,i,j] + sum_c dout[h][c] * pair_z[b,i,j,c]
-    for (int e = (int)threadIdx.x; e < H * N; e += 256) {
-      const int h = e / N, j = e % N;
+    for (int j = ej; j < N; j += 32) {
       const float* z = SLAB ? zs + j * ZPAD + H : zb + (bi * N + j) * ZB + H;
       float acc = 0.f;
 #pragma unroll
-      for (int c = 0; c < CZ4; ++c) acc += dout[h][c] * z[c];
-      dl_s[h][j] = dA[(((long)b * H + h) * N + i) * N + j] + acc;
+      for (int c = 0; c < CZ4; ++c) acc += dout[eh][c] * z[c];
+      dl_s[eh][j] = dA[(((long)b * H + eh) * N + i) * N + j] + acc;
     }
     if (SLAB) __syncthreads();   // every read of the zb image is done before dzb goes into it
     // d pair_z[b,i,j,c] = sum_h A[h][j] * dout[h][c]

@@ -20,11 +20,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
   const int npl = C / 64;
   for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
     const float* xr = x + row * ldx;
-    float v[MAXC_PER_LANE];
+    float v[MAXC_PER_LANE], gm[MAXC_PER_LANE], bt[MAXC_PER_LANE];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXC_PER_LANE; ++k)
       if (k < npl) { v[k] = xr[lane + 64 * k]; s += v[k]; }
+    // (the scale / shift / row-scale operands are fetched beside x, not behind the two reductions: at sampling sizes a launch of
+    // this kernel is one row per wave, i.e. a chain of dependent latencies)
+    const float rs = rowscale ? rowscale[row] : 1.f;
+#pragma unroll
+    for (int k = 0; k < MAXC_PER_LANE; ++k)
+      if (k < npl) { gm[k] = gamma[lane + 64 * k]; bt[k] = beta[lane + 64 * k]; }
     const float mean = fd::wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
@@ -32,13 +38,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
       if (k < npl) { float d = v[k] - mean; q += d * d; }
     const float var = fd::wave_sum(q) / (float)C;
     const float rstd = 1.0f / sqrtf(var + eps);
-    const float rs = rowscale ? rowscale[row] : 1.f;
     float* yr = y + row * ldy;
 #pragma unroll
     for (int k = 0; k < MAXC_PER_LANE; ++k)
       if (k < npl) {
         int c = lane + 64 * k;
-        yr[c] = ((v[k] - mean) * rstd * gamma[c] + beta[c]) * rs;
+        yr[c] = ((v[k] - mean) * rstd * gm[k] + bt[k]) * rs;
       }
     if (lane == 0) {
       if (mean_out) mean_out[row] = mean;

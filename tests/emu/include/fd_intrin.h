@@ -165,11 +165,6 @@ static inline void sched_pin() {}
 static inline int lane_id() { return hipemu::g_cur->lane; }
 static inline int wave_id() { return hipemu::g_cur->wave; }
 
-template <typename T>
-static inline T wave_sum(T v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
 static inline void lds_add(float* p, float v) { *p += v; }      // (fibers of a block run one at a time)
 
 // (the same four exchanges as the DPP controls of the device version, so the additions pair up identically)
@@ -179,6 +174,17 @@ static inline float row16_sum(float v) {
   v += __shfl(v, l ^ 2);
   v += __shfl(v, (l & ~7) | (7 - (l & 7)));
   v += __shfl(v, (l & ~15) | (15 - (l & 15)));
+  return v;
+}
+static inline float wave_sum(float v) {       // (same order of additions as the device version)
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+template <typename T>
+static inline T wave_sum(T v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
 template <typename T>

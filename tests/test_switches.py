@@ -6,7 +6,7 @@ transition + grouped weight gradients (fused_edge, grouped_pair_dw), the grouped
 (grouped_node_dw), the fused edge embedder (fused_embed), the zero arena,
 split-K dX, and the gradient side stream -- model/ipa_pytorch.py:340-374,584-593.
 
-Tolerance: 5e-5 of (each gradient's maximum + 1e-3) -- the merged GEMM has other tile shapes, the fused attention another
+Tolerance: 1e-4 of (each gradient's maximum + 1e-3) -- the merged GEMM has other tile shapes, the fused attention another
 summation order, both fp32-accurate (measured 2.1e-5 at B=4 x N=128, the size of either path's distance to the oracle).  linear_b.bias is left out: its gradient is analytically zero (a softmax is invariant
 to a shift of its logits) and numerically the round-off of a sum of O(1) terms (|g| ~ 5e-8 at either setting)."""
 import os
@@ -43,19 +43,22 @@ def _step(dev, B, N, blocks, **kw):
         return float(loss.detach()), {n: p.grad.detach().double().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}
 
 
+# (1e-4: the alternative launch sequences sum in different orders; the least well conditioned gradient, the two-entry bias of
+# torsion_pred.linear_final -- a sum over all residues with cancellation -- moves by 5e-5 of its size between sequences and by
+# 0.3e-5 from run to run of the SAME sequence (atomic accumulation order).)
 # one group per comparison: (fields switched OFF together, gradient tolerance).  The fused edge kernels compute in split-bf16
 # (fp32-accurate) against fp32 fmaf chains in the unfused sequence: ReLU-kink entries aside, 2e-4.
 GROUPS = [
-    (dict(proj_merge=False, fused_seq_attn=False), 5e-5),
-    (dict(fused_ipa_attn=False), 5e-5),
-    (dict(zero_arena=False, dx_splitk=False, grad_stream=False), 5e-5),
-    (dict(grouped_pair_dw=False), 5e-5),
-    (dict(grouped_node_dw=False), 5e-5),
-    (dict(fused_embed_bwd=False), 5e-5),
-    (dict(zb_from_edge=False), 5e-5),
-    (dict(packed_gates=False), 5e-5),
-    (dict(fused_ln_bwd=False), 5e-5),
-    (dict(fused_ln_bwd=False, packed_gates=False), 5e-5),
+    (dict(proj_merge=False, fused_seq_attn=False), 1e-4),
+    (dict(fused_ipa_attn=False), 1e-4),
+    (dict(zero_arena=False, dx_splitk=False, grad_stream=False), 1e-4),
+    (dict(grouped_pair_dw=False), 1e-4),
+    (dict(grouped_node_dw=False), 1e-4),
+    (dict(fused_embed_bwd=False), 1e-4),
+    (dict(zb_from_edge=False), 1e-4),
+    (dict(packed_gates=False), 1e-4),
+    (dict(fused_ln_bwd=False), 1e-4),
+    (dict(fused_ln_bwd=False, packed_gates=False), 1e-4),
     (dict(fused_edge=False, fused_embed=False), 2e-4),
 ]
 
