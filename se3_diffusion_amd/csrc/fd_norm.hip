@@ -317,8 +317,9 @@ __global__ __launch_bounds__(256) void pair_reduce2_kernel(const float* __restri
       }
     }
     // lanes of a wave with equal c4 differ in lane bits 3..5
+    rs.x += fd::lane_xor8(rs.x); rs.y += fd::lane_xor8(rs.y); rs.z += fd::lane_xor8(rs.z); rs.w += fd::lane_xor8(rs.w);   // (DPP)
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
+    for (int o = 16; o < 64; o <<= 1) {
       rs.x += __shfl_xor(rs.x, o); rs.y += __shfl_xor(rs.y, o); rs.z += __shfl_xor(rs.z, o); rs.w += __shfl_xor(rs.w, o);
     }
     if ((tid & 63) < 8) red[il][wave][c4] = rs;

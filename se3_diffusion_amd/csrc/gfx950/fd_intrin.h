@@ -139,6 +139,10 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
   return v;
 }
+// the value of lane l ^ 8 (row_ror:8 within the 16-lane DPP row): no LDS crossbar
+__device__ __forceinline__ float lane_xor8(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));
+}
 // float sums over the wave: the 16-lane rows by DPP, the four rows by two LDS-crossbar exchanges (6 exchanges in the generic
 // form below -- a kernel that reduces 26 values per head spends more LDS instructions on them than on its data)
 __device__ __forceinline__ float wave_sum(float v) {

@@ -176,6 +176,7 @@ static inline float row16_sum(float v) {
   v += __shfl(v, (l & ~15) | (15 - (l & 15)));
   return v;
 }
+static inline float lane_xor8(float v) { return __shfl(v, hipemu::g_cur->lane ^ 8); }
 static inline float wave_sum(float v) {       // (same order of additions as the device version)
   v = row16_sum(v);
   v += __shfl_xor(v, 16);
