@@ -176,8 +176,13 @@ _PMC_NAMES = {7: ("edge_mlp16_kernel<false", "edge_mlp16_kernel<true"), 9: ("pai
               5: ("gemm_direct_kernel",)}
 # algorithmic HBM bytes per pair row of the fused edge-transition launches in TRAINING: forward reads z
 # (512 B) and writes z' (512), the saves h1, h2 (2 x 1536), y (512), mean / rstd (8), the packed signs of h1 / h2 (96) and the
-# next block's zb (160); backward reads dy (512) and the packed gates (96), writes d2, d1 (3072) and dz (512)
-_EDGE_ALGO_BYTES = {"edge_mlp16_kernel<false": 512 + 512 + 3072 + 512 + 8 + 96 + 160, "edge_mlp16_kernel<true": 512 + 96 + 3072 + 512}
+# next block's zb (160); backward reads dy (512) and the packed gates (96), writes d2, d1 (3072) and dz (512); backward with the
+# fused LayerNorm-backward / dzb W40 prologue (template arguments 4, 5) reads the upstream gradient (512), dzb (160), y (512),
+# mean / rstd (8) and the gates (96), writes dy (512), d2, d1 (3072) and dz (512)
+_EDGE_ALGO_BYTES = {"edge_mlp16_kernel<false": 512 + 512 + 3072 + 512 + 8 + 96 + 160,
+                    "edge_mlp16_kernel<true, false, false, true": 512 + 160 + 512 + 8 + 96 + 512 + 3072 + 512,
+                    "edge_mlp16_kernel<true, false, false, false": 512 + 96 + 3072 + 512,
+                    "edge_mlp16_kernel<true, false, false>": 512 + 96 + 3072 + 512}
 
 
 def pmc_traffic(tile, rows):
