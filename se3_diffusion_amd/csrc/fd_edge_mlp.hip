@@ -420,8 +420,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc1[nb][e];
         if (!BWD) {
+#ifdef EM_ABLATE_PQ      // (probe build only: what the kernel would take if the per-residue terms cost no fetch)
+          const float4 a = make_float4(0.1f, 0.2f, -0.1f, 0.f), bq = make_float4(0.f, 0.1f, 0.f, -0.2f);
+#else
           const float4 a = *reinterpret_cast<const float4*>(d.p1 + qi * ld_pq + col);
           const float4 bq = *reinterpret_cast<const float4*>(d.q1 + qj * ld_pq + col);
+#endif
           v[0] += a.x + bq.x; v[1] += a.y + bq.y; v[2] += a.z + bq.z; v[3] += a.w + bq.w;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -537,8 +541,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) {
         const int col = 16 * nb + 4 * g;
+#ifdef EM_ABLATE_PQ
+        const float4 pa = make_float4(0.1f, 0.2f, -0.1f, 0.f), qa = make_float4(0.f, 0.1f, 0.f, -0.2f);
+#else
         const float4 pa = *reinterpret_cast<const float4*>(d.pf + qi * ld_pqf + col);
         const float4 qa = *reinterpret_cast<const float4*>(d.qf + qj * ld_pqf + col);
+#endif
         acc3[nb][0] += pa.x + qa.x; acc3[nb][1] += pa.y + qa.y; acc3[nb][2] += pa.z + qa.z; acc3[nb][3] += pa.w + qa.w;
         s += (acc3[nb][0] + acc3[nb][1]) + (acc3[nb][2] + acc3[nb][3]);
         if (d.y != nullptr && rok)

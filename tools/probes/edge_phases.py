@@ -19,20 +19,27 @@ PHASES = ["tile prologue", "stage waits (vmcnt + barrier)", "layer-1 stages", "e
           "layer-3 stages", "final epilogue (backward)", "final epilogue + layer 4 (forward)", "fused bwd prologue"]
 
 
-def build_probe():
+def build_probe(extra=(), tag="phases"):
     build.build(verbose=False)
-    out = os.path.join(ROOT, "tools", "probes", "libfd_phases.so")
-    obj = os.path.join(ROOT, "tools", "probes", "fd_edge_mlp_phases.o")
+    out = os.path.join(ROOT, "tools", "probes", f"libfd_{tag}.so")
+    obj = os.path.join(ROOT, "tools", "probes", f"fd_edge_mlp_{tag}.o")
     src = os.path.join(build.CSRC, "fd_edge_mlp.hip")
     if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-        subprocess.check_call([build.HIPCC, *build.FLAGS, "-DEM_PHASE_TIMING", "-c", src, "-o", obj])
+        flags = list(extra) if extra else ["-DEM_PHASE_TIMING"]
+        subprocess.check_call([build.HIPCC, *build.FLAGS, *flags, "-c", src, "-o", obj])
         objs = [os.path.join(build.OBJ, f) for f in sorted(os.listdir(build.OBJ)) if f.endswith(".o") and f != "fd_edge_mlp.o"]
         subprocess.check_call([build.HIPCC, f"--offload-arch={build.ARCH}", "-shared", "-fPIC", obj, *objs, "-o", out])
     return out
 
 
 def main():
-    L = ctypes.CDLL(build_probe())
+    if "--plain" in sys.argv:
+        L = ctypes.CDLL(hip.LIB_PATH)          # the product library, same harness: the reference time of the ablations
+    elif "--ablate-pq" in sys.argv:
+        # the same run with the per-residue terms P1_i / Q1_j / Pf_i / Qf_j replaced by constants: what their fetches cost
+        L = ctypes.CDLL(build_probe(("-DEM_ABLATE_PQ",), "ablate_pq"))
+    else:
+        L = ctypes.CDLL(build_probe())
     dev = "cuda"
     B, N = 30, 128
     R, P = B * N, B * N * N
@@ -80,7 +87,8 @@ def main():
         for _ in range(2):
             assert L.fd_edge_mlp(ctypes.byref(d), None) == 0
         torch.cuda.synchronize()
-        L.fd_edge_mlp_phases(None, 1)
+        if hasattr(L, "fd_edge_mlp_phases"):
+            L.fd_edge_mlp_phases(None, 1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 5
         e0.record()
@@ -88,8 +96,11 @@ def main():
             assert L.fd_edge_mlp(ctypes.byref(d), None) == 0
         e1.record()
         torch.cuda.synchronize()
-        L.fd_edge_mlp_phases(buf, 0)
         ms = e0.elapsed_time(e1) / reps
+        if not hasattr(L, "fd_edge_mlp_phases"):
+            print(f"{name}: {ms:.3f} ms per launch (no timers)")
+            continue
+        L.fd_edge_mlp_phases(buf, 0)
         tot = float(sum(buf[i] for i in range(10)))
         blocks = buf[10] / reps
         print(f"\n{name}: {ms:.3f} ms per launch (instrumented), {blocks:.0f} blocks; wave cycles by phase "
