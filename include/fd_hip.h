@@ -243,6 +243,34 @@ typedef struct FdEdgeEmbedBwdDesc {
 } FdEdgeEmbedBwdDesc;
 int fd_edge_embed_bwd(const FdEdgeEmbedBwdDesc* desc, void* stream);
 
+/* ---- LayerNorm folded into the Linear that consumes it (se3_diffusion_amd/csrc/fd_ln_gemm.hip), sampling sizes (M <= ~1024) ----
+ *   out[m, n] = epi( sum_k y[m, k] W[n, k] + bias[n] ),   y = ln_rowscale[m] * (LayerNorm(x[m, :]) * gamma + beta)
+ *   epi: ReLU (relu != 0), then + resid[m, n].   ln_out (optional): y itself, for a later launch (a residual branch).
+ * norm1 -> linear1 and norm2 -> the next consumer (self_attn.in_proj of the next layer, post_tfmr) of the sequence transformer's
+ * TransformerEncoderLayer (post-norm; built at model/ipa_pytorch.py:584-595, post_tfmr :638).  LayerNorm arithmetic as
+ * fd_layernorm_fwd (two-pass, eps inside the square root); exact fp32 products (v_mfma_f32_32x32x2_f32).
+ * K % 8 == 0, K <= 320; x, W, gamma, beta, ln_out 16-byte aligned, row strides multiples of 4. */
+typedef struct FdLnGemmDesc {
+  const float* x;          /* [M, K], row stride ldx */
+  long ldx;
+  const float* gamma;      /* [K] */
+  const float* beta;       /* [K] */
+  const float* ln_rowscale;/* optional [M] */
+  float* ln_out;           /* optional [M, K], row stride ld_ln_out */
+  long ld_ln_out;
+  const float* W;          /* [N, K], row stride ldw */
+  long ldw;
+  const float* bias;       /* optional [N] */
+  const float* resid;      /* optional [M, N], row stride ld_resid */
+  long ld_resid;
+  float* out;              /* [M, N], row stride ldo */
+  long ldo;
+  int M, N, K;
+  int relu;
+  float eps;
+} FdLnGemmDesc;
+int fd_ln_gemm(const FdLnGemmDesc* desc, void* stream);
+
 /* ---- weight gradients of the pair-row MLPs, grouped (autograd of the Linear layers of EdgeTransition,
  * model/ipa_pytorch.py:194-233: dW = dY^T X with the B*N*N pair rows as the reduction index) ----
  * One launch for up to FD_PAIR_DW_MAX_ITEMS output tiles of 384 x 128 that share the row count

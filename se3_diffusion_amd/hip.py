@@ -119,6 +119,15 @@ class FdEdgeEmbedBwdDesc(Structure):
 
 EDGE_EMBED_BWD_IMAGE_BYTES = 16 * 12288
 
+class FdLnGemmDesc(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_long), ("gamma", c_void_p), ("beta", c_void_p), ("ln_rowscale", c_void_p),
+        ("ln_out", c_void_p), ("ld_ln_out", c_long), ("W", c_void_p), ("ldw", c_long), ("bias", c_void_p),
+        ("resid", c_void_p), ("ld_resid", c_long), ("out", c_void_p), ("ldo", c_long),
+        ("M", c_int), ("N", c_int), ("K", c_int), ("relu", c_int), ("eps", c_float),
+    ]
+
+
 PAIR_DW_MAX_ITEMS = 8
 
 
@@ -170,6 +179,7 @@ _SIGS = {
     "fd_edge_embed_pack_zb": "pps",
     "fd_edge_embed_bwd_pack": "ppps",
     "fd_edge_embed_bwd": "Ss",
+    "fd_ln_gemm": "Ss",
     "fd_pair_dw": "Ss",
     "fd_group_dw": "Ss",
     "fd_layernorm_fwd": "plpppplpplifs",

@@ -444,12 +444,23 @@ def ln_skip_bwd(P, G, b, sv, du0, dx1, dinit):
 
 
 # --------------------------------------------------------------------------- transformer layer
-def tfmr_layer_fwd(P, pre, x, key_add, B, N, save=True, out_rowscale=None):
-    dev = x
+def tfmr_layer_fwd(P, pre, x, key_add, B, N, save=True, out_rowscale=None, x_ln=None, defer_out_ln=False):
+    """One post-norm TransformerEncoderLayer.  Inference at sampling sizes (save False, ops.ln_linear_ok): its LayerNorms run
+    inside the GEMM launches that consume them (fd_ln_gemm) -- x_ln = (t, gamma, beta, rowscale): the layer input is
+    LayerNorm(t) of the layer in front, not yet formed (x is ignored); defer_out_ln: return the pre-norm2 tensor and
+    (gamma, beta, rowscale) for the consumer instead of running norm2.  Returns (y2 | t2, saves, pending-LN | None)."""
+    dev = key_add
     R = B * N
     L = lib()
     qkv = empty((R, 3 * TD), dev)
-    ops.linear(mv(x), mv(P[f"{pre}.self_attn.in_proj_weight"]), P[f"{pre}.self_attn.in_proj_bias"], mv(qkv), R, 3 * TD, TD)
+    if x_ln is not None:
+        # in_proj on LayerNorm(t) of the layer in front; the normalised rows are written out too (this layer's residual)
+        t_in, g_in, b_in, rs_in = x_ln
+        x = empty((R, TD), dev)
+        ops.ln_linear(mv(t_in), g_in, b_in, mv(P[f"{pre}.self_attn.in_proj_weight"]), P[f"{pre}.self_attn.in_proj_bias"], mv(qkv),
+                      R, 3 * TD, TD, ln_rowscale=rs_in, ln_out=mv(x))
+    else:
+        ops.linear(mv(x), mv(P[f"{pre}.self_attn.in_proj_weight"]), P[f"{pre}.self_attn.in_proj_bias"], mv(qkv), R, 3 * TD, TD)
     o = empty((R, TD), dev)
     if opts.fused_seq_attn and R >= opts.seq_attn_min_rows:
         # scores + key mask + softmax + value product of every (batch, head) in one launch; the probabilities reach HBM
@@ -466,15 +477,24 @@ def tfmr_layer_fwd(P, pre, x, key_add, B, N, save=True, out_rowscale=None):
                a_bs=(TH * N * N, N * N), b_bs=(N * 3 * TD, THD), c_bs=(N * TD, THD))
     t1 = empty((R, TD), dev)
     ops.linear(mv(o), mv(P[f"{pre}.self_attn.out_proj.weight"]), P[f"{pre}.self_attn.out_proj.bias"], mv(t1), R, TD, TD, resid=mv(x))
-    y1 = empty((R, TD), dev); m1 = empty((R,), dev); r1 = empty((R,), dev)
-    ops.layernorm(mv(t1), P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"], mv(y1), R, TD, save=(m1, r1))
+    fold = (not save) and ops.ln_linear_ok(mv(t1), mv(P[f"{pre}.linear1.weight"]), R, TD, TD)
+    y1 = empty((R, TD), dev); m1 = r1 = None
     f = empty((R, TD), dev)
-    ops.linear(mv(y1), mv(P[f"{pre}.linear1.weight"]), P[f"{pre}.linear1.bias"], mv(f), R, TD, TD, relu=True)
+    if fold:
+        # norm1 inside linear1's launch; y1 (the residual of linear2) is written by the same launch
+        ops.ln_linear(mv(t1), P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"], mv(P[f"{pre}.linear1.weight"]),
+                      P[f"{pre}.linear1.bias"], mv(f), R, TD, TD, relu=True, ln_out=mv(y1))
+    else:
+        m1 = empty((R,), dev); r1 = empty((R,), dev)
+        ops.layernorm(mv(t1), P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"], mv(y1), R, TD, save=(m1, r1))
+        ops.linear(mv(y1), mv(P[f"{pre}.linear1.weight"]), P[f"{pre}.linear1.bias"], mv(f), R, TD, TD, relu=True)
     t2 = empty((R, TD), dev)
     ops.linear(mv(f), mv(P[f"{pre}.linear2.weight"]), P[f"{pre}.linear2.bias"], mv(t2), R, TD, TD, resid=mv(y1))
+    if fold and defer_out_ln:
+        return t2, None, (t2, P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"], out_rowscale)
     y2 = empty((R, TD), dev); m2 = empty((R,), dev); r2 = empty((R,), dev)
     ops.layernorm(mv(t2), P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"], mv(y2), R, TD, rowscale=out_rowscale, save=(m2, r2))
-    return y2, dict(x=x, qkv=qkv, A=A, o=o, t1=t1, m1=m1, r1=r1, y1=y1, f=f, t2=t2, m2=m2, r2=r2, B=B, N=N)
+    return y2, dict(x=x, qkv=qkv, A=A, o=o, t1=t1, m1=m1, r1=r1, y1=y1, f=f, t2=t2, m2=m2, r2=r2, B=B, N=N), None
 
 
 def tfmr_layer_bwd(P, G, pre, sv, dy2):
@@ -519,12 +539,18 @@ def tfmr_layer_bwd(P, G, pre, sv, dy2):
 
 
 # --------------------------------------------------------------------------- post-tfmr + node transition
-def post_node_fwd(P, b, u2, u0, mask, R):
-    """n2 = u0[:, :256] + W_post u2 ; n3 = mask * LN(n2 + W3 relu(W2 relu(W1 n2)))."""
+def post_node_fwd(P, b, u2, u0, mask, R, u2_ln=None):
+    """n2 = u0[:, :256] + W_post u2 ; n3 = mask * LN(n2 + W3 relu(W2 relu(W1 n2))).  u2_ln = (t, gamma, beta, rowscale): u2 is
+    LayerNorm(t) of the last transformer layer, formed inside post_tfmr's launch (tfmr_layer_fwd defer_out_ln)."""
     pre = "score_model.trunk"
-    dev = u2
+    dev = u0
     n2 = empty((R, CS), dev)
-    ops.linear(mv(u2), mv(P[f"{pre}.post_tfmr_{b}.weight"]), P[f"{pre}.post_tfmr_{b}.bias"], mv(n2), R, CS, TD, resid=(u0, 0, TD))
+    if u2_ln is not None:
+        t_in, g_in, b_in, rs_in = u2_ln
+        ops.ln_linear(mv(t_in), g_in, b_in, mv(P[f"{pre}.post_tfmr_{b}.weight"]), P[f"{pre}.post_tfmr_{b}.bias"], mv(n2), R, CS, TD,
+                      resid=(u0, 0, TD), ln_rowscale=rs_in)
+    else:
+        ops.linear(mv(u2), mv(P[f"{pre}.post_tfmr_{b}.weight"]), P[f"{pre}.post_tfmr_{b}.bias"], mv(n2), R, CS, TD, resid=(u0, 0, TD))
     nt = f"{pre}.node_transition_{b}"
     h1 = empty((R, CS), dev); h2 = empty((R, CS), dev); t = empty((R, CS), dev); n3 = empty((R, CS), dev)
     mean = empty((R,), dev); rstd = empty((R,), dev)

@@ -306,6 +306,37 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, rows, C, *, rowscale=None, dgamm
                int(accum), dgamma, dbeta, rows, C)
 
 
+def ln_linear_ok(x, W, M, N, K):
+    """Can ln_linear fold this LayerNorm into its Linear?  (the latency regime of sampling, M = B*N <= 1024 rows -- where fd_gemm
+    picks its 32 x 32 latency kernel for the node-level layers --, K <= 320, contiguous 16-byte aligned operands)"""
+    return bool(opts.ln_fold and M <= 1024 and K % 8 == 0 and K <= 320 and x[1] == 0 and W[1] == 0 and x[2] % 4 == 0
+                and W[2] % 4 == 0)
+
+
+def ln_linear(x, gamma, beta, W, b, out, M, N, K, *, relu=False, resid=None, ln_rowscale=None, ln_out=None):
+    """out[M,N] = epi(LN(x)[M,K] @ W[N,K]^T + b) with LN(x) = ln_rowscale * (LayerNorm(x) * gamma + beta) formed inside the GEMM
+    launch (csrc/fd_ln_gemm.hip); ln_out (a matrix view): LN(x) written out too.  x, W, out, resid are matrix views."""
+    d = hip.FdLnGemmDesc()
+    tens = []
+
+    def ptr(t, off=0):
+        if t is None:
+            return None
+        tens.append(t)
+        return t.data_ptr() + 4 * off
+    d.x, d.ldx = ptr(x[0], x[1]), x[2]
+    d.gamma, d.beta, d.ln_rowscale = ptr(gamma), ptr(beta), ptr(ln_rowscale)
+    if ln_out is not None:
+        d.ln_out, d.ld_ln_out = ptr(ln_out[0], ln_out[1]), ln_out[2]
+    d.W, d.ldw, d.bias = ptr(W[0], W[1]), W[2], ptr(b)
+    if resid is not None:
+        d.resid, d.ld_resid = ptr(resid[0], resid[1]), resid[2]
+    d.out, d.ldo = ptr(out[0], out[1]), out[2]
+    d.M, d.N, d.K, d.relu, d.eps = int(M), int(N), int(K), int(bool(relu)), 1e-5
+    L = lib()
+    L._check(L.cdll.fd_ln_gemm(hip.ctypes.byref(d), L._stream(tens)), "fd_ln_gemm")
+
+
 # ---------------------------------------------------------------------------
 # host-computed constant tables (reference op sequence, so arguments are bit-identical)
 # ---------------------------------------------------------------------------

@@ -54,6 +54,8 @@ class Options:
     seq_attn_min_rows: int = 1024     # FD_SEQ_ATTN_MIN_ROWS: ... from this many residue rows up
     grouped_node_dw: bool = True      # FD_NODE_DW: the node-level weight gradients of a trunk block in one grouped launch
     node_dw_blocks: int = 0           # FD_NODE_DW_BLOCKS: its persistent blocks (0 = 512: two per CU)
+    ln_fold: bool = True              # FD_LN_FOLD: sampling -- the sequence transformer's LayerNorms inside the GEMM launches that
+                                      # consume them (fd_ln_gemm) instead of launches of their own
     # -- backward bookkeeping
     zero_arena: bool = True           # FD_ZERO_ARENA: one memset for every zero-initialised accumulator of a backward pass
     dx_splitk: bool = True            # FD_DX_SPLITK: accumulating dX GEMMs with a long reduction split over K (atomics)
@@ -73,6 +75,7 @@ class Options:
             proj_merge=_flag("FD_PROJ_MERGE", True),
             fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),
             grouped_node_dw=_flag("FD_NODE_DW", True), node_dw_blocks=_int("FD_NODE_DW_BLOCKS", 0),
+            ln_fold=_flag("FD_LN_FOLD", True),
             zero_arena=_flag("FD_ZERO_ARENA", True), dx_splitk=_flag("FD_DX_SPLITK", True))
 
 

@@ -461,15 +461,18 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
             u, sv_ln = nw.ln_skip_fwd(P, b, x1, init_node, R)
             u0 = u
             sv_t = []
+            pend_ln = None      # sampling: a LayerNorm whose launch is folded into its consumer's (nw.tfmr_layer_fwd)
             nl = _tfmr_layers(P, b)
             for l in range(nl):
                 # eval + no_grad fast path of nn.TransformerEncoder: padded rows of its output are zeroed (nested-tensor
                 # round trip) -- the row mask rides on the last layer's LayerNorm instead of a launch of its own
-                u, s_ = nw.tfmr_layer_fwd(P, f"score_model.trunk.seq_tfmr_{b}.layers.{l}", u, key_add, B, N, save=save,
-                                          out_rowscale=mask.view(-1) if (tfmr_bool_mask and l == nl - 1) else None)
+                u, s_, pend_ln = nw.tfmr_layer_fwd(P, f"score_model.trunk.seq_tfmr_{b}.layers.{l}", u, key_add, B, N, save=save,
+                                                   out_rowscale=mask.view(-1) if (tfmr_bool_mask and l == nl - 1) else None,
+                                                   x_ln=pend_ln, defer_out_ln=not save)
                 sv_t.append(s_)
         with rng(f"node_transition_{b}.fwd"):
-            n3, sv_pn = nw.post_node_fwd(P, b, u, u0, mask.view(-1), R)
+            n3, sv_pn = nw.post_node_fwd(P, b, u, u0, mask.view(-1), R, u2_ln=pend_ln)
+            pend_ln = None
             q2, t2, sv_bb = bb_update_fwd(P, b, n3, dmask.view(-1), quat, trans, R)
         sv_et = None
         if b < num_blocks - 1:
