@@ -456,6 +456,13 @@ int fd_se3_reverse_step(const float* rig_t, const double* rot_score, const doubl
                         double b_t, const double* tparams /* optional device {g_rot, b_t}: overrides the scalars,
                         lets one captured hipGraph serve every t */, double dt, double noise_scale,
                         double coord_scale, int center, int diffuse_rot, int diffuse_trans, float* out, void* stream);
+/* the same step with the scores as the network stores them (float32, widened in registers: the same numbers the reference
+ * passes after its .to(float64)); out may be rig_t (in place) in both forms */
+int fd_se3_reverse_step_f32(const float* rig_t, const float* rot_score, const float* trans_score,
+                        const double* z_rot, const double* z_trans, const float* mask, int B, int N, double g_rot,
+                        double b_t, const double* tparams /* optional device {g_rot, b_t}: overrides the scalars,
+                        lets one captured hipGraph serve every t */, double dt, double noise_scale,
+                        double coord_scale, int center, int diffuse_rot, int diffuse_trans, float* out, void* stream);
 
 /* ---- training loss (the step next to the hot path): experiments/train_se3_diffusion.py:524-693 ----
  * Experiment.loss_fn, both rotation branches: translation score / x0 loss, rotation axis + angle (or joint MSE) loss,

@@ -204,12 +204,16 @@ __global__ __launch_bounds__(256) void forward_marginal_batch_kernel(
                          rot_score, trans_score);
 }
 
-// one block per batch element (centering needs the mean over its N residues)
+// one block per batch element (centering needs the mean over its N residues).  ST = the scores' storage type: the network writes
+// float32, the reference widens them to float64 before the step -- a float32 argument widened in registers is the same number
+// and saves the two conversion launches of every reverse step.  out may alias rig_t (in place): every read of a row's
+// translation for the mean happens before the barrier, after it each thread reads and writes only its own rows.
+template <typename ST>
 __global__ __launch_bounds__(256) void reverse_step_kernel(
-    const float* __restrict__ rig_t, const double* __restrict__ rot_score, const double* __restrict__ trans_score,
+    const float* rig_t, const ST* __restrict__ rot_score, const ST* __restrict__ trans_score,
     const double* __restrict__ z_rot, const double* __restrict__ z_trans, const float* __restrict__ mask, int N,
     double g_rot, double b_t, const double* __restrict__ tparams, double dt, double noise_scale, double cs, int center,
-    int diffuse_rot, int diffuse_trans, float* __restrict__ out) {
+    int diffuse_rot, int diffuse_trans, float* out) {
   __shared__ double red[4][3];
   __shared__ double com[3];
   const int b = (int)blockIdx.x;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(
     for (int k = 0; k < 3; ++k) {
       const double x = (double)rig_t[r * 7 + 4 + k] * cs;
       const double f = -0.5 * b_t * x;
-      const double pert = (f - gb * gb * trans_score[r * 3 + k]) * dt + gb * sdt * (noise_scale * z_trans[r * 3 + k]);
+      const double pert = (f - gb * gb * (double)trans_score[r * 3 + k]) * dt + gb * sdt * (noise_scale * z_trans[r * 3 + k]);
       acc[k] += x - pert;
     }
   }
@@ -236,14 +240,15 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(
   __syncthreads();
   for (int n = tid; n < N; n += 256) {
     const long r = (long)b * N + n;
-    const float* in = rig_t + r * 7;
+    float in[7];
+    for (int k = 0; k < 7; ++k) in[k] = rig_t[r * 7 + k];
     float* o = out + r * 7;
     const bool diff = mask ? mask[r] > 0.5f : true;
     // rotation: R' = R_t Exp(g^2 s dt + g sqrt(dt) z)
     if (diff && diffuse_rot) {
       double v[3], qe[4], qt[4] = {in[0], in[1], in[2], in[3]}, qn[4];
       for (int k = 0; k < 3; ++k)
-        v[k] = g_rot * g_rot * rot_score[r * 3 + k] * dt + g_rot * sdt * (noise_scale * z_rot[r * 3 + k]);
+        v[k] = g_rot * g_rot * (double)rot_score[r * 3 + k] * dt + g_rot * sdt * (noise_scale * z_rot[r * 3 + k]);
       rotvec_to_quat(v, qe);
       quat_normalize(qt);
       quat_mul(qt, qe, qn);
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(
       if (diff && diffuse_trans) {
         const double x = (double)in[4 + k] * cs;
         const double f = -0.5 * b_t * x;
-        const double pert = (f - gb * gb * trans_score[r * 3 + k]) * dt + gb * sdt * (noise_scale * z_trans[r * 3 + k]);
+        const double pert = (f - gb * gb * (double)trans_score[r * 3 + k]) * dt + gb * sdt * (noise_scale * z_trans[r * 3 + k]);
         o[4 + k] = (float)((x - pert - com[k]) / cs);
       } else {
         o[4 + k] = in[4 + k];
@@ -323,9 +328,22 @@ extern "C" int fd_se3_reverse_step(const float* rig_t, const double* rot_score, 
                                    double coord_scale, int center, int diffuse_rot, int diffuse_trans, float* out,
                                    void* stream) {
   if (B == 0 || N == 0) return FD_OK;
-  hipLaunchKernelGGL(reverse_step_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, rig_t, rot_score,
+  hipLaunchKernelGGL(reverse_step_kernel<double>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, rig_t, rot_score,
                      trans_score, z_rot, z_trans, mask, N, g_rot, b_t, tparams, dt, noise_scale, coord_scale, center,
                      diffuse_rot, diffuse_trans, out);
   FD_CHECK_LAUNCH("fd_se3_reverse_step");
+  return FD_OK;
+}
+
+extern "C" int fd_se3_reverse_step_f32(const float* rig_t, const float* rot_score, const float* trans_score,
+                                       const double* z_rot, const double* z_trans, const float* mask, int B, int N,
+                                       double g_rot, double b_t, const double* tparams, double dt, double noise_scale,
+                                       double coord_scale, int center, int diffuse_rot, int diffuse_trans, float* out,
+                                       void* stream) {
+  if (B == 0 || N == 0) return FD_OK;
+  hipLaunchKernelGGL(reverse_step_kernel<float>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, rig_t, rot_score,
+                     trans_score, z_rot, z_trans, mask, N, g_rot, b_t, tparams, dt, noise_scale, coord_scale, center,
+                     diffuse_rot, diffuse_trans, out);
+  FD_CHECK_LAUNCH("fd_se3_reverse_step_f32");
   return FD_OK;
 }

@@ -217,6 +217,7 @@ _SIGS = {
     "fd_forward_marginal": "ppppppipdddipppp" + "ls",
     "fd_forward_marginal_batch": "ppppppippdipppp" + "iis",
     "fd_se3_reverse_step": "ppppppiiddpdddiiips",
+    "fd_se3_reverse_step_f32": "ppppppiiddpdddiiips",
     "fd_dsm_loss": "Ss",
     "fd_adam_step": "pppplffffffs",
 }

@@ -59,7 +59,6 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
     z_rot = torch.zeros((B, N, 3), dtype=torch.float64, device=dev)
     z_trans = torch.zeros((B, N, 3), dtype=torch.float64, device=dev)
     tparams = torch.zeros(2, dtype=torch.float64, device=dev)
-    new_rig = torch.empty((B, N, 7), dtype=torch.float32, device=dev)
     psi = torch.zeros((B, N, 2), device=dev)
     so3, r3 = diffuser._so3_diffuser, diffuser._r3_diffuser
 
@@ -90,10 +89,10 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
         if embed_sc:
             st["sc_ca_t"].copy_(out["rigids"][..., 4:])
         psi.copy_(out["psi"])
+        # (in place: fd_se3_reverse_step reads every row it needs for the centring mean before it writes any)
         diffuser.reverse_device(st["rigids_t"], out["rot_score"], out["trans_score"], 0.5, dt, diffuse_mask=diffuse_mask,
                                 center=center, noise_scale=noise_scale, noise=(z_rot, z_trans), tparams=tparams,
-                                out=new_rig)
-        st["rigids_t"].copy_(new_rig)
+                                out=st["rigids_t"])
 
     try:
         traj = []
