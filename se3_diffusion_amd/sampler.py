@@ -56,8 +56,8 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
     st["rigids_t"] = st["rigids_t"].to(torch.float32).contiguous()
     st["t"] = torch.ones(B, device=dev)
     diffuse_mask = ((1 - st["fixed_mask"]) * st["res_mask"]).contiguous()
-    z_rot = torch.zeros((B, N, 3), dtype=torch.float64, device=dev)
-    z_trans = torch.zeros((B, N, 3), dtype=torch.float64, device=dev)
+    z_both = torch.zeros((2, B, N, 3), dtype=torch.float64, device=dev)      # (one normal_ launch fills both draws: rot, then trans)
+    z_rot, z_trans = z_both[0], z_both[1]
     tparams = torch.zeros(2, dtype=torch.float64, device=dev)
     psi = torch.zeros((B, N, 2), device=dev)
     so3, r3 = diffuser._so3_diffuser, diffuser._r3_diffuser
@@ -73,8 +73,7 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
 
     def draw(i):
         if noise_fn is None:
-            z_rot.normal_(generator=generator)
-            z_trans.normal_(generator=generator)
+            z_both.normal_(generator=generator)
         else:
             zr, zt = noise_fn(i, (B, N, 3))
             z_rot.copy_(_f64(zr, dev))
@@ -88,11 +87,11 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
         out = model(st)
         if embed_sc:
             st["sc_ca_t"].copy_(out["rigids"][..., 4:])
-        psi.copy_(out["psi"])
         # (in place: fd_se3_reverse_step reads every row it needs for the centring mean before it writes any)
         diffuser.reverse_device(st["rigids_t"], out["rot_score"], out["trans_score"], 0.5, dt, diffuse_mask=diffuse_mask,
                                 center=center, noise_scale=noise_scale, noise=(z_rot, z_trans), tparams=tparams,
                                 out=st["rigids_t"])
+        return out
 
     try:
         traj = []
@@ -113,7 +112,7 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                step_body()
+                cap_out = step_body()          # (static buffers: every replay rewrites them)
             for k, v in saved.items():
                 st[k].copy_(v)
         out = None
@@ -126,13 +125,15 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
                 draw(i)
                 if graph is not None:
                     graph.replay()
+                    out = cap_out
                 else:
-                    step_body()
+                    out = step_body()
+                psi = out["psi"]               # (the torsion head's output of the latest forward: no copy per step)
             else:
                 # reference quirk kept: the final forward still carries the previous step's t (train_se3_diffusion.py:778-779)
                 out = model(st)
                 st["rigids_t"].copy_(out["rigids"])
-                psi.copy_(out["psi"])
+                psi = out["psi"]
             if return_traj:
                 traj.append(st["rigids_t"].clone())
         if stats is not None and lib.is_device:
