@@ -268,6 +268,7 @@ typedef struct FdLnGemmDesc {
   int M, N, K;
   int relu;
   float eps;
+  int ln_cols;             /* 0 = K; else only columns [0, ln_cols) of x are normalised (gamma / beta [ln_cols]), the rest pass through */
 } FdLnGemmDesc;
 int fd_ln_gemm(const FdLnGemmDesc* desc, void* stream);
 

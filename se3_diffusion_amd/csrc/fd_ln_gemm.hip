@@ -57,28 +57,35 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(FdLnGemmDesc d, int nblk_n
       const int k = 8 * (wave + 4 * u);
       const float4 a = *reinterpret_cast<const float4*>(pa + k);
       const float4 b = *reinterpret_cast<const float4*>(pb + k);
-      const float4 g4 = *reinterpret_cast<const float4*>(d.gamma + k + 4 * h);
-      const float4 b4 = *reinterpret_cast<const float4*>(d.beta + k + 4 * h);
+      float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (d.ln_cols <= 0 || k < d.ln_cols) {           // (gamma / beta are [ln_cols])
+        g4 = *reinterpret_cast<const float4*>(d.gamma + k + 4 * h);
+        b4 = *reinterpret_cast<const float4*>(d.beta + k + 4 * h);
+      }
       av[u][0] = a.x; av[u][1] = a.y; av[u][2] = a.z; av[u][3] = a.w;
       bv[u][0] = b.x; bv[u][1] = b.y; bv[u][2] = b.z; bv[u][3] = b.w;
       gm[u][0] = g4.x; gm[u][1] = g4.y; gm[u][2] = g4.z; gm[u][3] = g4.w;
       bt[u][0] = b4.x; bt[u][1] = b4.y; bt[u][2] = b4.z; bt[u][3] = b4.w;
     }
   const float rsl = d.ln_rowscale ? d.ln_rowscale[ra] : 1.f;
+  // ln_cols < K: only the first ln_cols columns of x are normalised (statistics over them alone), the rest pass through -- the
+  // concatenation [LayerNorm(ipa output) | skip_embed] that the first transformer layer reads (ipa_pytorch.py:632-636)
+  const int lnc = d.ln_cols > 0 ? d.ln_cols : d.K;
+  const int nln = (lnc / 8 - wave + 3) >> 2;         // this wave's groups inside the normalised range (ln_cols % 8 == 0)
 
-  // ---- row statistics: lane (row l31, half h) of wave w holds 4 * nmine of the row's K values ----
+  // ---- row statistics: lane (row l31, half h) of wave w holds 4 * nln of the row's normalised K values ----
   float s = 0.f;
 #pragma unroll
   for (int u = 0; u < LG_MAXG; ++u)
-    if (u < nmine) s += (av[u][0] + av[u][1]) + (av[u][2] + av[u][3]);
+    if (u < nln) s += (av[u][0] + av[u][1]) + (av[u][2] + av[u][3]);
   s += __shfl_xor(s, 32);
   if (h == 0) red[0][wave][l31] = s;
   __syncthreads();
-  const float mean = ((red[0][0][l31] + red[0][1][l31]) + (red[0][2][l31] + red[0][3][l31])) / (float)d.K;
+  const float mean = ((red[0][0][l31] + red[0][1][l31]) + (red[0][2][l31] + red[0][3][l31])) / (float)lnc;
   float q = 0.f;
 #pragma unroll
   for (int u = 0; u < LG_MAXG; ++u)
-    if (u < nmine) {
+    if (u < nln) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         av[u][e] -= mean;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(FdLnGemmDesc d, int nblk_n
   q += __shfl_xor(q, 32);
   if (h == 0) red[1][wave][l31] = q;
   __syncthreads();
-  const float var = ((red[1][0][l31] + red[1][1][l31]) + (red[1][2][l31] + red[1][3][l31])) / (float)d.K;
+  const float var = ((red[1][0][l31] + red[1][1][l31]) + (red[1][2][l31] + red[1][3][l31])) / (float)lnc;
   const float rstd = 1.0f / sqrtf(var + d.eps);
 
   // ---- normalise in place, write the rows out (block column 0), multiply ----
@@ -98,8 +105,10 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(FdLnGemmDesc d, int nblk_n
 #pragma unroll
   for (int u = 0; u < LG_MAXG; ++u)
     if (u < nmine) {
+      if (u < nln) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) av[u][e] = (av[u][e] * rstd * gm[u][e] + bt[u][e]) * rsl;
+        for (int e = 0; e < 4; ++e) av[u][e] = (av[u][e] * rstd * gm[u][e] + bt[u][e]) * rsl;
+      }
       if (d.ln_out != nullptr && bn == 0 && m0 + l31 < d.M)
         *reinterpret_cast<float4*>(d.ln_out + (long)ra * d.ld_ln_out + 8 * (wave + 4 * u) + 4 * h) =
             make_float4(av[u][0], av[u][1], av[u][2], av[u][3]);
@@ -132,6 +141,8 @@ extern "C" int fd_ln_gemm(const FdLnGemmDesc* desc, void* stream) {
   FD_CHECK_ARG(d.x && d.W && d.out && d.gamma && d.beta, "fd_ln_gemm: x / W / out / gamma / beta are required");
   FD_CHECK_ARG(d.M >= 0 && d.N > 0 && d.K > 0 && d.K % 8 == 0 && d.K <= 32 * LG_MAXG,
                "fd_ln_gemm: K=%d must be a multiple of 8, at most 320", d.K);
+  FD_CHECK_ARG(d.ln_cols >= 0 && d.ln_cols <= d.K && d.ln_cols % 8 == 0, "fd_ln_gemm: ln_cols=%d must be a multiple of 8, at most K",
+               d.ln_cols);
   FD_CHECK_ARG((d.ldx & 3) == 0 && (d.ldw & 3) == 0 && (d.ld_ln_out & 3) == 0 && fd_aligned16(d.x) && fd_aligned16(d.W) &&
                    fd_aligned16(d.gamma) && fd_aligned16(d.beta) && fd_aligned16(d.ln_out),
                "fd_ln_gemm: x / W / gamma / beta / ln_out must be 16-byte aligned with row strides that are multiples of 4");

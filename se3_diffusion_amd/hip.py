@@ -124,7 +124,7 @@ class FdLnGemmDesc(Structure):
         ("x", c_void_p), ("ldx", c_long), ("gamma", c_void_p), ("beta", c_void_p), ("ln_rowscale", c_void_p),
         ("ln_out", c_void_p), ("ld_ln_out", c_long), ("W", c_void_p), ("ldw", c_long), ("bias", c_void_p),
         ("resid", c_void_p), ("ld_resid", c_long), ("out", c_void_p), ("ldo", c_long),
-        ("M", c_int), ("N", c_int), ("K", c_int), ("relu", c_int), ("eps", c_float),
+        ("M", c_int), ("N", c_int), ("K", c_int), ("relu", c_int), ("eps", c_float), ("ln_cols", c_int),
     ]
 
 

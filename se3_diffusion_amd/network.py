@@ -274,7 +274,7 @@ def ipa_w40(P, pre, cache=None):
     return W40, b40
 
 
-def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None):
+def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None, out_view=None):
     """x1 = s + mask * IPA(s, z, T).  s: matrix view [R,256].  zb: [P,40] = W40 z + b40 when the kernel that produced z
     already formed it (the previous block's fused edge transition)."""
     dev = z
@@ -324,9 +324,11 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None):
     L.call("fd_ipa_opt_fwd", optg, quat, trans, feats, R)
     if not fused_attn:
         L.call("fd_ipa_opair_fwd", A, zb, feats, B, N)
-    x1 = empty((R, CS), dev)
-    ops.linear(mv(feats), mv(P[f"{pre}.linear_out.weight"]), P[f"{pre}.linear_out.bias"], mv(x1), R, CS, LDF,
-               rowscale=mask, resid=s)
+    # out_view (a matrix view, sampling): x1 goes straight into the [R, 320] buffer whose columns 256.. take skip_embed -- the
+    # operand of the first transformer layer's in_proj, which then normalises the first 256 columns itself (trunk.forward)
+    x1 = empty((R, CS), dev) if out_view is None else out_view[0]
+    ops.linear(mv(feats), mv(P[f"{pre}.linear_out.weight"]), P[f"{pre}.linear_out.bias"], mv(x1) if out_view is None else out_view,
+               R, CS, LDF, rowscale=mask, resid=s)
     sv = dict(s=s, z=z, quat=quat, trans=trans, mask=mask, proj=proj, qp=qp, kp=kp, kpT=kpT, vp=vp, W40=W40, b40=b40, zb=zb, A=A,
               feats=feats, B=B, N=N, fused_attn=fused_attn)
     return x1, sv
@@ -446,8 +448,8 @@ def ln_skip_bwd(P, G, b, sv, du0, dx1, dinit):
 # --------------------------------------------------------------------------- transformer layer
 def tfmr_layer_fwd(P, pre, x, key_add, B, N, save=True, out_rowscale=None, x_ln=None, defer_out_ln=False):
     """One post-norm TransformerEncoderLayer.  Inference at sampling sizes (save False, ops.ln_linear_ok): its LayerNorms run
-    inside the GEMM launches that consume them (fd_ln_gemm) -- x_ln = (t, gamma, beta, rowscale): the layer input is
-    LayerNorm(t) of the layer in front, not yet formed (x is ignored); defer_out_ln: return the pre-norm2 tensor and
+    inside the GEMM launches that consume them (fd_ln_gemm) -- x_ln = (t, gamma, beta, rowscale[, ln_cols, x_out]): the layer input
+    is LayerNorm(t[:, :ln_cols]) | t[:, ln_cols:] of the stage in front, not yet formed (x is ignored; x_out receives it); defer_out_ln: return the pre-norm2 tensor and
     (gamma, beta, rowscale) for the consumer instead of running norm2.  Returns (y2 | t2, saves, pending-LN | None)."""
     dev = key_add
     R = B * N
@@ -455,10 +457,10 @@ def tfmr_layer_fwd(P, pre, x, key_add, B, N, save=True, out_rowscale=None, x_ln=
     qkv = empty((R, 3 * TD), dev)
     if x_ln is not None:
         # in_proj on LayerNorm(t) of the layer in front; the normalised rows are written out too (this layer's residual)
-        t_in, g_in, b_in, rs_in = x_ln
-        x = empty((R, TD), dev)
+        t_in, g_in, b_in, rs_in, lnc, x = x_ln + (0, None)[len(x_ln) - 4:]
+        x = empty((R, TD), dev) if x is None else x
         ops.ln_linear(mv(t_in), g_in, b_in, mv(P[f"{pre}.self_attn.in_proj_weight"]), P[f"{pre}.self_attn.in_proj_bias"], mv(qkv),
-                      R, 3 * TD, TD, ln_rowscale=rs_in, ln_out=mv(x))
+                      R, 3 * TD, TD, ln_rowscale=rs_in, ln_out=mv(x), ln_cols=lnc)
     else:
         ops.linear(mv(x), mv(P[f"{pre}.self_attn.in_proj_weight"]), P[f"{pre}.self_attn.in_proj_bias"], mv(qkv), R, 3 * TD, TD)
     o = empty((R, TD), dev)
@@ -539,7 +541,7 @@ def tfmr_layer_bwd(P, G, pre, sv, dy2):
 
 
 # --------------------------------------------------------------------------- post-tfmr + node transition
-def post_node_fwd(P, b, u2, u0, mask, R, u2_ln=None):
+def post_node_fwd(P, b, u2, u0, mask, R, u2_ln=None, defer_ln=False):
     """n2 = u0[:, :256] + W_post u2 ; n3 = mask * LN(n2 + W3 relu(W2 relu(W1 n2))).  u2_ln = (t, gamma, beta, rowscale): u2 is
     LayerNorm(t) of the last transformer layer, formed inside post_tfmr's launch (tfmr_layer_fwd defer_out_ln)."""
     pre = "score_model.trunk"
@@ -557,6 +559,9 @@ def post_node_fwd(P, b, u2, u0, mask, R, u2_ln=None):
     ops.linear(mv(n2), mv(P[f"{nt}.linear_1.weight"]), P[f"{nt}.linear_1.bias"], mv(h1), R, CS, CS, relu=True)
     ops.linear(mv(h1), mv(P[f"{nt}.linear_2.weight"]), P[f"{nt}.linear_2.bias"], mv(h2), R, CS, CS, relu=True)
     ops.linear(mv(h2), mv(P[f"{nt}.linear_3.weight"]), P[f"{nt}.linear_3.bias"], mv(t), R, CS, CS, resid=mv(n2))
+    if defer_ln:
+        # sampling: the transition's LayerNorm (x node mask) runs inside the launch of its first GEMM consumer, which writes n3
+        return None, (t, P[f"{nt}.ln.weight"], P[f"{nt}.ln.bias"], mask, 0, n3)
     ops.layernorm(mv(t), P[f"{nt}.ln.weight"], P[f"{nt}.ln.bias"], mv(n3), R, CS, rowscale=mask, save=(mean, rstd))
     return n3, dict(u2=u2, n2=n2, h1=h1, h2=h2, t=t, mean=mean, rstd=rstd, mask=mask, R=R)
 

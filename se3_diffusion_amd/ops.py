@@ -313,9 +313,9 @@ def ln_linear_ok(x, W, M, N, K):
                 and W[2] % 4 == 0)
 
 
-def ln_linear(x, gamma, beta, W, b, out, M, N, K, *, relu=False, resid=None, ln_rowscale=None, ln_out=None):
+def ln_linear(x, gamma, beta, W, b, out, M, N, K, *, relu=False, resid=None, ln_rowscale=None, ln_out=None, ln_cols=0):
     """out[M,N] = epi(LN(x)[M,K] @ W[N,K]^T + b) with LN(x) = ln_rowscale * (LayerNorm(x) * gamma + beta) formed inside the GEMM
-    launch (csrc/fd_ln_gemm.hip); ln_out (a matrix view): LN(x) written out too.  x, W, out, resid are matrix views."""
+    launch (csrc/fd_ln_gemm.hip); ln_out (a matrix view): LN(x) written out too; ln_cols: only x[:, :ln_cols] is normalised.  x, W, out, resid are matrix views."""
     d = hip.FdLnGemmDesc()
     tens = []
 
@@ -332,7 +332,7 @@ def ln_linear(x, gamma, beta, W, b, out, M, N, K, *, relu=False, resid=None, ln_
     if resid is not None:
         d.resid, d.ld_resid = ptr(resid[0], resid[1]), resid[2]
     d.out, d.ldo = ptr(out[0], out[1]), out[2]
-    d.M, d.N, d.K, d.relu, d.eps = int(M), int(N), int(K), int(bool(relu)), 1e-5
+    d.M, d.N, d.K, d.relu, d.eps, d.ln_cols = int(M), int(N), int(K), int(bool(relu)), 1e-5, int(ln_cols)
     L = lib()
     L._check(L.cdll.fd_ln_gemm(hip.ctypes.byref(d), L._stream(tens)), "fd_ln_gemm")
 

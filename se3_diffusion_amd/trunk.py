@@ -64,7 +64,12 @@ def fused_edge():
     return opts.fused_edge and not lib().exact_f32
 
 
-def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None, zb_next=None):
+def et_folds_node_terms(cache, save):
+    """sampling: edge_transition_fwd forms the per-residue terms with ONE GEMM of n3 (against a matrix folded once per trajectory)"""
+    return cache is not None and not save and opts.fold_node_terms and fused_edge()
+
+
+def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None, zb_next=None, n3_ln=None):
     """z' = emask * LN(W_f (relu(W_2 relu(W_1 x)) + x) + b_f), x = [z | e_i | e_j], e = W_init n3 -- the whole pair-level
     chain in ONE launch (fd_edge_mlp): h1 / h2 never reach HBM unless the backward needs them (save).
     zb_next = (W40 [40,128], b40 [40]) of the next block's IPA: its pair projection zb = W40 z' + b40 is formed by the same
@@ -76,7 +81,8 @@ def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None, zb_next
     R, Pn = B * N, B * N * N
     W1, Wf = P[f"{pre}.trunk.0.weight"], P[f"{pre}.final_layer.weight"]
     kw = {}
-    if cache is not None and not save and opts.fold_node_terms:
+    assert n3_ln is None or et_folds_node_terms(cache, save)
+    if et_folds_node_terms(cache, save):
         # static weights (sampling): the per-residue terms P1 | Q1 | Pf | Qf = [W1_i; W1_j; Wf_i; Wf_j] (W_init n3 + b_init)
         # (+ b1, b_f) are ONE GEMM of n3 against a matrix folded once per trajectory (5 launches -> 1); the fused kernel
         # reads the four column blocks of its [R, 1024] output through their row stride
@@ -94,7 +100,12 @@ def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None, zb_next
         Wfold, bfold = cache[key]
         LDT = 2 * EH + 2 * CZ
         PQ = empty((R, LDT), dev)
-        ops.linear(mv(n3), mv(Wfold), bfold, mv(PQ), R, LDT, CS)
+        if n3_ln is not None:
+            # n3 = mask * LayerNorm(t) of the node transition, formed (and written out for the other consumers) by this launch
+            t_in, g_in, b_in, rs_in, _, n3_out = n3_ln
+            ops.ln_linear(mv(t_in), g_in, b_in, mv(Wfold), bfold, mv(PQ), R, LDT, CS, ln_rowscale=rs_in, ln_out=mv(n3_out))
+        else:
+            ops.linear(mv(n3), mv(Wfold), bfold, mv(PQ), R, LDT, CS)
         P1, Q1, Pf, Qf = PQ[:, 0:], PQ[:, EH:], PQ[:, 2 * EH:], PQ[:, 2 * EH + CZ:]
         kw = dict(ld_pq=LDT, ld_pqf=LDT)
         e = None
@@ -455,14 +466,28 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
     stages = []
     for b in range(num_blocks):
         pre = f"score_model.trunk.ipa_{b}"
+        nl = _tfmr_layers(P, b)
+        # sampling (ops.ln_linear_ok): LayerNorms run inside the launches of their GEMM consumers.  ipa_ln: linear_out and
+        # skip_embed write the two column ranges of one [R, 320] buffer and the first transformer layer's in_proj normalises
+        # the first 256 itself; the transition's LayerNorm: inside the edge transition's per-residue GEMM (blocks that have one)
+        fold1 = (not save) and nl >= 1 and node.is_cuda == z.is_cuda and ops.ln_linear_ok((node, 0, TD), (node, 0, TD), R, 3 * TD, TD)
+        fold6 = fold1 and b < num_blocks - 1 and et_folds_node_terms(cache, save)
+        cat = empty((R, TD), dev) if fold1 else None
         with rng(f"ipa_{b}.fwd"):
-            x1, sv_ipa = nw.ipa_fwd(P, pre, mv(node), z, quat, trans, mask.view(-1), B, N, cache, zb=zb)
+            x1, sv_ipa = nw.ipa_fwd(P, pre, mv(node), z, quat, trans, mask.view(-1), B, N, cache, zb=zb,
+                                    out_view=(cat, 0, TD) if fold1 else None)
         with rng(f"seq_tfmr_{b}.fwd"):
-            u, sv_ln = nw.ln_skip_fwd(P, b, x1, init_node, R)
-            u0 = u
+            pend_ln = None      # a LayerNorm whose launch is folded into its consumer's (nw.tfmr_layer_fwd)
+            if fold1:
+                tp = "score_model.trunk"
+                ops.linear(mv(init_node), mv(P[f"{tp}.skip_embed_{b}.weight"]), P[f"{tp}.skip_embed_{b}.bias"], (cat, CS, TD), R, 64, CS)
+                u = u0 = empty((R, TD), dev)             # written by the first layer's in_proj launch
+                pend_ln = (cat, P[f"{tp}.ipa_ln_{b}.weight"], P[f"{tp}.ipa_ln_{b}.bias"], None, CS, u0)
+                sv_ln = None
+            else:
+                u, sv_ln = nw.ln_skip_fwd(P, b, x1, init_node, R)
+                u0 = u
             sv_t = []
-            pend_ln = None      # sampling: a LayerNorm whose launch is folded into its consumer's (nw.tfmr_layer_fwd)
-            nl = _tfmr_layers(P, b)
             for l in range(nl):
                 # eval + no_grad fast path of nn.TransformerEncoder: padded rows of its output are zeroed (nested-tensor
                 # round trip) -- the row mask rides on the last layer's LayerNorm instead of a launch of its own
@@ -471,14 +496,24 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
                                                    x_ln=pend_ln, defer_out_ln=not save)
                 sv_t.append(s_)
         with rng(f"node_transition_{b}.fwd"):
-            n3, sv_pn = nw.post_node_fwd(P, b, u, u0, mask.view(-1), R, u2_ln=pend_ln)
+            n3, sv_pn = nw.post_node_fwd(P, b, u, u0, mask.view(-1), R, u2_ln=pend_ln, defer_ln=fold6)
             pend_ln = None
-            q2, t2, sv_bb = bb_update_fwd(P, b, n3, dmask.view(-1), quat, trans, R)
         sv_et = None
-        if b < num_blocks - 1:
+        if fold6:
+            n3_ln, sv_pn = sv_pn, None
+            n3 = n3_ln[5]
             with rng(f"edge_transition_{b}.fwd"):
-                z, sv_et, zb = edge_transition_fwd(P, b, n3, z, emask, B, N, save=save, cache=cache,
-                                                   zb_next=nw.ipa_w40(P, f"score_model.trunk.ipa_{b + 1}", cache))
+                z, sv_et, zb = edge_transition_fwd(P, b, None, z, emask, B, N, save=save, cache=cache,
+                                                   zb_next=nw.ipa_w40(P, f"score_model.trunk.ipa_{b + 1}", cache), n3_ln=n3_ln)
+            with rng(f"node_transition_{b}.fwd"):
+                q2, t2, sv_bb = bb_update_fwd(P, b, n3, dmask.view(-1), quat, trans, R)
+        else:
+            with rng(f"node_transition_{b}.fwd"):
+                q2, t2, sv_bb = bb_update_fwd(P, b, n3, dmask.view(-1), quat, trans, R)
+            if b < num_blocks - 1:
+                with rng(f"edge_transition_{b}.fwd"):
+                    z, sv_et, zb = edge_transition_fwd(P, b, n3, z, emask, B, N, save=save, cache=cache,
+                                                       zb_next=nw.ipa_w40(P, f"score_model.trunk.ipa_{b + 1}", cache))
         stages.append(dict(ipa=sv_ipa, ln=sv_ln, tfmr=sv_t, pn=sv_pn, bb=sv_bb, et=sv_et))
         node, quat, trans = n3, q2, t2
         if not save:

@@ -15,25 +15,28 @@ def rel(a, b):
     return float((a.double().cpu() - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-def _run(dev, M, N, K, seed=0, relu=False, resid=False, scale=False, ln_out=True, mean_shift=0.0):
+def _run(dev, M, N, K, seed=0, relu=False, resid=False, scale=False, ln_out=True, mean_shift=0.0, ln_cols=0):
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc)
     x = (rn(M, K) * 1.5 + mean_shift).to(dev)
     W, b = rn(N, K, sc=0.08).to(dev), rn(N, sc=0.3).to(dev)
-    gamma, beta = (1 + rn(K, sc=0.2)).to(dev), rn(K, sc=0.2).to(dev)
+    Kn = ln_cols or K
+    gamma, beta = (1 + rn(Kn, sc=0.2)).to(dev), rn(Kn, sc=0.2).to(dev)
     res = rn(M, N).to(dev) if resid else None
     rs = (torch.rand(M, generator=g) > 0.3).float().to(dev) if scale else None
     out = torch.full((M, N), float("nan"), device=dev)
     y = torch.full((M, K), float("nan"), device=dev) if ln_out else None
     assert ops.ln_linear_ok(mv(x), mv(W), M, N, K)
     ops.ln_linear(mv(x), gamma, beta, mv(W), b, mv(out), M, N, K, relu=relu, resid=None if res is None else mv(res),
-                  ln_rowscale=rs, ln_out=None if y is None else mv(y))
+                  ln_rowscale=rs, ln_out=None if y is None else mv(y), ln_cols=ln_cols)
     xd = x.double().cpu()
-    mean = xd.mean(-1, keepdim=True)
-    var = ((xd - mean) ** 2).mean(-1, keepdim=True)
-    yr = (xd - mean) / torch.sqrt(var + 1e-5) * gamma.double().cpu() + beta.double().cpu()
+    xn = xd[:, :Kn]
+    mean = xn.mean(-1, keepdim=True)
+    var = ((xn - mean) ** 2).mean(-1, keepdim=True)
+    yr = (xn - mean) / torch.sqrt(var + 1e-5) * gamma.double().cpu() + beta.double().cpu()
     if rs is not None:
         yr = yr * rs.double().cpu()[:, None]
+    yr = torch.cat([yr, xd[:, Kn:]], 1)            # (ln_cols: the columns behind it pass through)
     ref = yr @ W.double().cpu().T + b.double().cpu()
     if relu:
         ref = torch.relu(ref)
@@ -42,7 +45,7 @@ def _run(dev, M, N, K, seed=0, relu=False, resid=False, scale=False, ln_out=True
     if y is not None:
         assert rel(y, yr) < 5e-6, rel(y, yr)
     assert rel(out, ref) < 1e-5, rel(out, ref)
-    if K % 64:
+    if K % 64 or ln_cols:
         return                 # (fd_layernorm_fwd takes multiples of 64 only)
     # against the two launches it replaces
     y2, o2 = torch.empty(M, K, device=dev), torch.empty(M, N, device=dev)
@@ -56,6 +59,7 @@ def test_ln_gemm_emu(use_emu):
     _run("cpu", 33, 40, 256, seed=1, resid=True, scale=True)
     _run("cpu", 32, 32, 64, seed=2, ln_out=False)             # waves 2, 3 hold one group, ...
     _run("cpu", 8, 8, 8, seed=3)                              # ... or none
+    _run("cpu", 40, 72, 320, seed=4, ln_cols=256)             # [LayerNorm(x[:, :256]) | x[:, 256:]] (ipa_ln + skip concat)
 
 
 @pytest.mark.gpu
@@ -65,6 +69,7 @@ def test_ln_gemm_gpu(hip_lib):
     _run("cuda", 256, 256, 320, seed=2, resid=True)
     _run("cuda", 1000, 320, 320, seed=3, resid=True, relu=True, mean_shift=3.0)
     _run("cuda", 50, 72, 200, seed=4, ln_out=False)
+    _run("cuda", 128, 960, 320, seed=5, ln_cols=256)
 
 
 def _infer(dev, B, N, blocks, **kw):
