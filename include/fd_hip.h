@@ -170,6 +170,9 @@ typedef struct FdEdgeMlpDesc {
   float* ln_dbeta;          /* optional [128], accumulated */
   const float* dzb;         /* optional [rows,40]: adds dzb W40 to the upstream gradient (autograd of the next IPA block's linear_b /
                                down_z w.r.t. this transition's output; W40 = the four leading units of the image) */
+  unsigned* sched;          /* optional: two zero words of device scratch -- a launch with more 64-row tiles than blocks then hands the
+                               tiles out dynamically (one atomic per tile and block) and leaves the words zero again; the
+                               words of concurrent launches must differ */
 } FdEdgeMlpDesc;
 int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream);
 

@@ -206,8 +206,16 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
   const int ntiles = (int)((rows + EM_ROWS - 1) / EM_ROWS);
   const int G = (int)gridDim.x, first = (int)blockIdx.x;
   if (first >= ntiles) return;
+  // Tiles: block b starts with tile b; after that either the static stride (b + G, b + 2 G, ...) or -- d.sched, when a launch has
+  // more tiles than blocks -- the next tile nobody has taken (one atomic per tile and block).  With the static stride a block that
+  // becomes resident late (another stream's kernel still holds its CU's LDS when the launch starts) finishes its equal share late
+  // and the whole launch waits for it: in the training step the backward ran 1.5 ms alone and 1.9 ms behind a 0.3 ms grouped
+  // weight-gradient launch of the side stream.
+  unsigned* const sched = d.sched;
+  const bool dyn = sched != nullptr && ntiles > G;
+  __shared__ int s_tile;
   const int nmine = (ntiles - first + G - 1) / G;
-  const int total_stages = nmine * EM_NSTAGE;
+  const int total_stages = dyn ? 0x7fffffff : nmine * EM_NSTAGE;   // (dyn: the weight stream keeps one stage ahead to the end)
 
   // ---- weight stream: every wave copies an eighth (6 pieces) of each stage; stage s lives in buffer s & 1 ----
   const char* __restrict__ img_lane = static_cast<const char*>(d.img) + wave * (EM_STAGE / EM_WAVES) + lane * 16;
@@ -250,8 +258,11 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
     __syncthreads();
   }
 
-  for (int ti = 0; ti < nmine; ++ti) {
-    const long row = ((long)first + (long)ti * G) * EM_ROWS + wave * 16 + m;
+  int tile = first, nxt = 0;
+  for (int ti = 0;;) {
+    // (dyn) the tile after this one is taken now: the atomic's round trip runs under this tile's work
+    if (dyn && tid == 0) nxt = G + (int)atomicAdd(&sched[0], 1u);
+    const long row = (long)tile * EM_ROWS + wave * 16 + m;
     const bool rok = row < rows;
     const long rc = rok ? row : rows - 1;         // rows past the end are clamped on load, masked on store
     const long qi = rc / d.nres;                  // (b, i)
@@ -624,6 +635,16 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
               make_float4(acc3[nb][0], acc3[nb][1], acc3[nb][2], acc3[nb][3]);
     }
     EM_BODY_TO(BWD ? 7 : 8);
+    if (!dyn) {
+      if (++ti >= nmine) break;
+      tile = first + ti * G;
+    } else {
+      if (tid == 0) s_tile = nxt;
+      __syncthreads();
+      tile = s_tile;
+      __syncthreads();          // (thread 0 writes s_tile again only after every thread has read it)
+      if (tile >= ntiles) break;
+    }
   }
 #ifdef EM_PHASE_TIMING
   if (lane == 0) {
@@ -634,6 +655,16 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
   }
   if (tid == 0) __hip_atomic_fetch_add(&em_phase[10], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
+  if (dyn) {
+    fd::wait_vmem();             // the stage copied ahead for a tile that does not exist must land before this block's LDS is freed
+    if (tid == 0) {
+      // the last block out zeroes the two words for the next launch that is handed them
+      if (atomicAdd(&sched[1], 1u) == (unsigned)G - 1u) {
+        sched[0] = 0u;          // (the next launch that is handed these words is ordered behind this kernel by its stream)
+        sched[1] = 0u;
+      }
+    }
+  }
   if (LNB) {
     __syncthreads();
     if (tid < EM_C) {

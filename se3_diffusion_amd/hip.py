@@ -88,7 +88,7 @@ class FdEdgeMlpDesc(Structure):
         ("ld_pq", c_long), ("ld_pqf", c_long), ("zb_out", c_void_p), ("zb_bias", c_void_p),
         ("mask1", c_void_p), ("mask2", c_void_p), ("gmask1", c_void_p), ("gmask2", c_void_p),
         ("ln_y", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_gamma", c_void_p), ("ln_rowscale", c_void_p),
-        ("dy_out", c_void_p), ("ln_dgamma", c_void_p), ("ln_dbeta", c_void_p), ("dzb", c_void_p),
+        ("dy_out", c_void_p), ("ln_dgamma", c_void_p), ("ln_dbeta", c_void_p), ("dzb", c_void_p), ("sched", c_void_p),
     ]
 
 

@@ -389,6 +389,21 @@ def edge_mlp_pack_bwd(Wf, W2, W1, W40=None, out=None):
     return img
 
 
+_SCHED = {}
+
+
+def _edge_sched(like):
+    """Two zero words of device scratch for a launch's dynamic tile hand-out (FdEdgeMlpDesc.sched): a ring of 64 pairs per
+    device, zeroed once -- the kernel leaves its pair zero again, and launches that may run at the same time get different pairs."""
+    key = like.device
+    ent = _SCHED.get(key)
+    if ent is None:
+        ent = _SCHED[key] = [torch.zeros(128, dtype=torch.int32, device=like.device), 0]
+    buf, i = ent
+    ent[1] = (i + 1) % 64
+    return buf.data_ptr() + 8 * i
+
+
 def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, qf=None, gamma=None, beta=None,
              rowscale=None, gate1=None, gate2=None, save1=None, save2=None, y=None, mean=None, rstd=None,
              backward=False, blocks=0, ld_pq=0, ld_pqf=0, zb_out=None, zb_bias=None, mask1=None, mask2=None, gmask1=None,
@@ -406,6 +421,8 @@ def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, 
         if t is not None:
             tens.append(t)
     d.rows, d.nres, d.backward, d.eps, d.blocks = int(rows), int(nres), int(bool(backward)), 1e-5, int(blocks or opts.edge_blocks)
+    if opts.edge_dynamic_tiles and rows > 64 * (d.blocks or 512):
+        d.sched = _edge_sched(out)
     d.ld_pq, d.ld_pqf = int(ld_pq), int(ld_pqf)
     L = lib()
     stream = L._stream(tens)

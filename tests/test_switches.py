@@ -57,6 +57,7 @@ GROUPS = [
     (dict(fused_embed_bwd=False), 1e-4),
     (dict(zb_from_edge=False), 1e-4),
     (dict(packed_gates=False), 1e-4),
+    (dict(edge_dynamic_tiles=False), 1e-4),
     (dict(fused_ln_bwd=False), 1e-4),
     (dict(fused_ln_bwd=False, packed_gates=False), 1e-4),
     (dict(fused_edge=False, fused_embed=False), 2e-4),
@@ -99,4 +100,4 @@ def test_options_override_restores():
 @pytest.mark.gpu
 def test_switches_gpu(hip_lib):
     _compare("cuda", B=2, N=24, blocks=2)
-    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:3] + GROUPS[4:10])
+    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:3] + GROUPS[4:11])
