@@ -243,6 +243,7 @@ typedef struct FdEdgeEmbedBwdDesc {
   int blocks;             /* 0 = two persistent blocks per CU (512) */
   const unsigned* gmask2; /* optional [rows,4]: fd_edge_embed's mask2 -- replaces the read of h2 (h2 may then be null) */
   const unsigned* gmask1; /* optional [rows,4]: fd_edge_embed's mask1 -- replaces the read of h1 */
+  unsigned* sched;        /* optional: two zero words of device scratch for a dynamic tile hand-out (as FdEdgeMlpDesc.sched) */
 } FdEdgeEmbedBwdDesc;
 int fd_edge_embed_bwd(const FdEdgeEmbedBwdDesc* desc, void* stream);
 

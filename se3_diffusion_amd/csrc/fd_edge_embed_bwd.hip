@@ -56,8 +56,13 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_bwd_kernel(FdEdge
   const int ntiles = (int)((rows + EM_ROWS - 1) / EM_ROWS);
   const int G = (int)gridDim.x, first = (int)blockIdx.x;
   if (first >= ntiles) return;
+  // tiles: block b starts with tile b, then the static stride or (d.sched, more tiles than blocks) the next tile nobody has taken --
+  // as in fd_edge_mlp.hip: a block that becomes resident late no longer finishes an equal share late
+  unsigned* const sched = d.sched;
+  const bool dyn = sched != nullptr && ntiles > G;
+  __shared__ int s_tile;
   const int nmine = (ntiles - first + G - 1) / G;
-  const int total_stages = nmine * EB_NSTAGE;
+  const int total_stages = dyn ? 0x7fffffff : nmine * EB_NSTAGE;
 
   // ---- weight stream (as fd_edge_embed.hip) ----
   const char* __restrict__ img_lane = static_cast<const char*>(d.img) + wave * (EM_STAGE / EM_WAVES) + lane * 16;
@@ -89,8 +94,10 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_bwd_kernel(FdEdge
 #pragma unroll
     for (int e = 0; e < 4; ++e) dgam[nb][e] = dbet[nb][e] = 0.f;
 
-  for (int ti = 0; ti < nmine; ++ti) {
-    const long row = ((long)first + (long)ti * G) * EM_ROWS + wave * 16 + m;
+  int tile = first, nxt = 0;
+  for (int ti = 0;;) {
+    if (dyn && tid == 0) nxt = G + (int)atomicAdd(&sched[0], 1u);     // (the tile after this one)
+    const long row = (long)tile * EM_ROWS + wave * 16 + m;
     const bool rok = row < rows;
     const long rc = rok ? row : rows - 1;         // rows past the end are clamped on load, masked on store / in the sums
 
@@ -215,6 +222,23 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_bwd_kernel(FdEdge
                         h.w > 0.f ? a1[nb][3] : 0.f);
       }
       if (rok) *reinterpret_cast<float4*>(d.dh1 + row * EB_C + 16 * nb + 4 * g) = o;
+    }
+    if (!dyn) {
+      if (++ti >= nmine) break;
+      tile = first + ti * G;
+    } else {
+      if (tid == 0) s_tile = nxt;
+      __syncthreads();
+      tile = s_tile;
+      __syncthreads();          // (thread 0 writes s_tile again only after every thread has read it)
+      if (tile >= ntiles) break;
+    }
+  }
+  if (dyn) {
+    fd::wait_vmem();             // the stage copied ahead for a tile that does not exist lands before the ring is reused below
+    if (tid == 0 && atomicAdd(&sched[1], 1u) == (unsigned)G - 1u) {
+      sched[0] = 0u;             // the last block out zeroes the two words for the next launch that is handed them
+      sched[1] = 0u;
     }
   }
 

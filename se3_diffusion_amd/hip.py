@@ -114,6 +114,7 @@ class FdEdgeEmbedBwdDesc(Structure):
         ("dy", c_void_p), ("h3", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("gamma", c_void_p), ("rowscale", c_void_p),
         ("h2", c_void_p), ("h1", c_void_p), ("img", c_void_p), ("dh3", c_void_p), ("dh2", c_void_p), ("dh1", c_void_p),
         ("dgamma", c_void_p), ("dbeta", c_void_p), ("rows", c_long), ("blocks", c_int), ("gmask2", c_void_p), ("gmask1", c_void_p),
+        ("sched", c_void_p),
     ]
 
 

@@ -499,6 +499,8 @@ def edge_embed_bwd(dy, h3, mean, rstd, gamma, rowscale, h2, h1, img, dh3, dh2, d
         if t is not None:
             tens.append(t)
     d.rows, d.blocks = int(rows), int(blocks)
+    if opts.edge_dynamic_tiles and rows > 64 * (d.blocks or 512):
+        d.sched = _edge_sched(dh3)
     L = lib()
     L._check(L.cdll.fd_edge_embed_bwd(hip.ctypes.byref(d), L._stream(tens)), "fd_edge_embed_bwd")
 
