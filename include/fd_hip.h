@@ -170,9 +170,9 @@ typedef struct FdEdgeMlpDesc {
   float* ln_dbeta;          /* optional [128], accumulated */
   const float* dzb;         /* optional [rows,40]: adds dzb W40 to the upstream gradient (autograd of the next IPA block's linear_b /
                                down_z w.r.t. this transition's output; W40 = the four leading units of the image) */
-  unsigned* sched;          /* optional: two zero words of device scratch -- a launch with more 64-row tiles than blocks then hands the
-                               tiles out dynamically (one atomic per tile and block) and leaves the words zero again; the
-                               words of concurrent launches must differ */
+  unsigned* sched;          /* optional: one word of device scratch -- a launch whose blocks walk four or more 64-row tiles each then
+                               hands the tiles out dynamically (one atomic per tile and block); fd_edge_mlp zeroes the word on
+                               the launch's stream; the words of launches that may run at the same time must differ */
 } FdEdgeMlpDesc;
 int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream);
 
@@ -243,7 +243,7 @@ typedef struct FdEdgeEmbedBwdDesc {
   int blocks;             /* 0 = two persistent blocks per CU (512) */
   const unsigned* gmask2; /* optional [rows,4]: fd_edge_embed's mask2 -- replaces the read of h2 (h2 may then be null) */
   const unsigned* gmask1; /* optional [rows,4]: fd_edge_embed's mask1 -- replaces the read of h1 */
-  unsigned* sched;        /* optional: two zero words of device scratch for a dynamic tile hand-out (as FdEdgeMlpDesc.sched) */
+  unsigned* sched;        /* optional: one word of device scratch for a dynamic tile hand-out (as FdEdgeMlpDesc.sched) */
 } FdEdgeEmbedBwdDesc;
 int fd_edge_embed_bwd(const FdEdgeEmbedBwdDesc* desc, void* stream);
 

@@ -58,8 +58,8 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_bwd_kernel(FdEdge
   if (first >= ntiles) return;
   // tiles: block b starts with tile b, then the static stride or (d.sched, more tiles than blocks) the next tile nobody has taken --
   // as in fd_edge_mlp.hip: a block that becomes resident late no longer finishes an equal share late
-  unsigned* const sched = d.sched;
-  const bool dyn = sched != nullptr && ntiles > G;
+  unsigned* const sched = d.sched;      // (zeroed by the host entry in front of the launch)
+  const bool dyn = sched != nullptr;
   __shared__ int s_tile;
   const int nmine = (ntiles - first + G - 1) / G;
   const int total_stages = dyn ? 0x7fffffff : nmine * EB_NSTAGE;
@@ -234,13 +234,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_bwd_kernel(FdEdge
       if (tile >= ntiles) break;
     }
   }
-  if (dyn) {
-    fd::wait_vmem();             // the stage copied ahead for a tile that does not exist lands before the ring is reused below
-    if (tid == 0 && atomicAdd(&sched[1], 1u) == (unsigned)G - 1u) {
-      sched[0] = 0u;             // the last block out zeroes the two words for the next launch that is handed them
-      sched[1] = 0u;
-    }
-  }
+  if (dyn) fd::wait_vmem();     // the stage copied ahead for a tile that does not exist lands before the ring is reused below
 
   // ---- LayerNorm parameter gradients: over the 16 rows of the wave (lanes l & 15), over the waves (LDS), one atomic per
   // column and block ----
@@ -302,8 +296,15 @@ extern "C" int fd_edge_embed_bwd(const FdEdgeEmbedBwdDesc* desc, void* stream) {
   if (d.rows == 0) return FD_OK;
   const long ntiles = (d.rows + EM_ROWS - 1) / EM_ROWS;
   const int blocks = d.blocks > 0 ? d.blocks : 256 * EM_BLOCKS_PER_CU;   // MI355X: persistent blocks fill the 256 CUs
-  hipLaunchKernelGGL(edge_embed_bwd_kernel, dim3((unsigned)(ntiles < blocks ? ntiles : blocks)), dim3(64 * EM_WAVES), 0,
-                     (hipStream_t)stream, d);
+  const long grid = ntiles < blocks ? ntiles : blocks;
+  FdEdgeEmbedBwdDesc dd = d;
+  if (dd.sched != nullptr && ntiles >= 4 * grid) {       // (as fd_edge_mlp: zeroed on the launch's own stream)
+    FD_CHECK_ARG(hipMemsetAsync(dd.sched, 0, sizeof(unsigned), (hipStream_t)stream) == hipSuccess,
+                 "fd_edge_embed_bwd: zeroing the tile counter failed");
+  } else {
+    dd.sched = nullptr;
+  }
+  hipLaunchKernelGGL(edge_embed_bwd_kernel, dim3((unsigned)grid), dim3(64 * EM_WAVES), 0, (hipStream_t)stream, dd);
   FD_CHECK_LAUNCH("fd_edge_embed_bwd");
   return FD_OK;
 }

@@ -211,8 +211,8 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
   // becomes resident late (another stream's kernel still holds its CU's LDS when the launch starts) finishes its equal share late
   // and the whole launch waits for it: in the training step the backward ran 1.5 ms alone and 1.9 ms behind a 0.3 ms grouped
   // weight-gradient launch of the side stream.
-  unsigned* const sched = d.sched;
-  const bool dyn = sched != nullptr && ntiles > G;
+  unsigned* const sched = d.sched;      // (the host entry zeroes the word in front of every launch that uses it)
+  const bool dyn = sched != nullptr;
   __shared__ int s_tile;
   const int nmine = (ntiles - first + G - 1) / G;
   const int total_stages = dyn ? 0x7fffffff : nmine * EM_NSTAGE;   // (dyn: the weight stream keeps one stage ahead to the end)
@@ -655,16 +655,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
   }
   if (tid == 0) __hip_atomic_fetch_add(&em_phase[10], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-  if (dyn) {
-    fd::wait_vmem();             // the stage copied ahead for a tile that does not exist must land before this block's LDS is freed
-    if (tid == 0) {
-      // the last block out zeroes the two words for the next launch that is handed them
-      if (atomicAdd(&sched[1], 1u) == (unsigned)G - 1u) {
-        sched[0] = 0u;          // (the next launch that is handed these words is ordered behind this kernel by its stream)
-        sched[1] = 0u;
-      }
-    }
-  }
+  if (dyn) fd::wait_vmem();     // the stage copied ahead for a tile that does not exist must land before this block's LDS is freed
   if (LNB) {
     __syncthreads();
     if (tid < EM_C) {
@@ -755,21 +746,29 @@ extern "C" int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream) {
                "fd_edge_mlp: mask1 / mask2 (forward) and gmask1 / gmask2 (backward) come in pairs");
   const dim3 g3(grid), b3(64 * EM_WAVES);
   hipStream_t st = (hipStream_t)stream;
+  // dynamic tile hand-out: only for launches whose blocks walk several tiles each; the counter word is zeroed here, on the launch's
+  // own stream, so a launch never depends on how an earlier one left it
+  FdEdgeMlpDesc dd = d;
+  if (dd.sched != nullptr && ntiles >= 4L * grid) {
+    FD_CHECK_ARG(hipMemsetAsync(dd.sched, 0, sizeof(unsigned), st) == hipSuccess, "fd_edge_mlp: zeroing the tile counter failed");
+  } else {
+    dd.sched = nullptr;
+  }
   const bool zbv = d.zb_out != nullptr, mk = d.mask1 != nullptr;
   if (d.backward && d.ln_y != nullptr && d.dzb != nullptr)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false, true, true>), g3, b3, 0, st, d);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false, true, true>), g3, b3, 0, st, dd);
   else if (d.backward && d.ln_y != nullptr)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false, true, false>), g3, b3, 0, st, d);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false, true, false>), g3, b3, 0, st, dd);
   else if (d.backward)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false>), g3, b3, 0, st, d);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false>), g3, b3, 0, st, dd);
   else if (zbv && mk)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true, true>), g3, b3, 0, st, d);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true, true>), g3, b3, 0, st, dd);
   else if (zbv)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true, false>), g3, b3, 0, st, d);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true, false>), g3, b3, 0, st, dd);
   else if (mk)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, false, true>), g3, b3, 0, st, d);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, false, true>), g3, b3, 0, st, dd);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, false, false>), g3, b3, 0, st, d);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, false, false>), g3, b3, 0, st, dd);
   FD_CHECK_LAUNCH("fd_edge_mlp");
   return FD_OK;
 }

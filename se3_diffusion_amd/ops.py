@@ -393,8 +393,8 @@ _SCHED = {}
 
 
 def _edge_sched(like):
-    """Two zero words of device scratch for a launch's dynamic tile hand-out (FdEdgeMlpDesc.sched): a ring of 64 pairs per
-    device, zeroed once -- the kernel leaves its pair zero again, and launches that may run at the same time get different pairs."""
+    """One word of device scratch for a launch's dynamic tile hand-out (FdEdgeMlpDesc.sched; the entry point zeroes it on the
+    launch's stream): a ring of 64 per device, so that launches that may run at the same time get different words."""
     key = like.device
     ent = _SCHED.get(key)
     if ent is None:
@@ -421,7 +421,7 @@ def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, 
         if t is not None:
             tens.append(t)
     d.rows, d.nres, d.backward, d.eps, d.blocks = int(rows), int(nres), int(bool(backward)), 1e-5, int(blocks or opts.edge_blocks)
-    if opts.edge_dynamic_tiles and rows > 64 * (d.blocks or 512):
+    if opts.edge_dynamic_tiles and rows >= 4 * 64 * (d.blocks or 512):
         d.sched = _edge_sched(out)
     d.ld_pq, d.ld_pqf = int(ld_pq), int(ld_pqf)
     L = lib()
@@ -499,7 +499,7 @@ def edge_embed_bwd(dy, h3, mean, rstd, gamma, rowscale, h2, h1, img, dh3, dh2, d
         if t is not None:
             tens.append(t)
     d.rows, d.blocks = int(rows), int(blocks)
-    if opts.edge_dynamic_tiles and rows > 64 * (d.blocks or 512):
+    if opts.edge_dynamic_tiles and rows >= 4 * 64 * (d.blocks or 512):
         d.sched = _edge_sched(dh3)
     L = lib()
     L._check(L.cdll.fd_edge_embed_bwd(hip.ctypes.byref(d), L._stream(tens)), "fd_edge_embed_bwd")

@@ -60,6 +60,7 @@ def _run(dev, rows, seed=0, blocks=0, mask=True):
 
 def test_edge_embed_bwd_emu(use_emu):
     _run("cpu", rows=150, blocks=2)                  # persistent blocks walk two tiles, ragged last tile
+    _run("cpu", rows=300, seed=3, blocks=1)          # five tiles on one block: the dynamic tile hand-out
     _run("cpu", rows=64, seed=1, mask=False)
     _run("cpu", rows=5, seed=2, blocks=8)            # less than one wave's rows; idle blocks
 
