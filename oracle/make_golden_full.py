@@ -3,11 +3,13 @@ from the UNMODIFIED reference (model/score_network.py:170-215, experiments/train
 
     fwd_n128_b2   full depth (4 blocks), B=2 x N=128: outputs + gradient signatures of all 282 parameters
     fwd_n256_b1   full depth, B=1 x N=256: outputs + gradient signatures
-    fwd_n512_b1   full depth, B=1 x N=512: outputs (forward only, eval/no-grad and train mode)
+    fwd_n512_b1   full depth, B=1 x N=512: outputs + gradient signatures (BASELINE configs[3] trains at N up to 512)
     traj_n128     5 reverse-diffusion steps of Experiment.inference_fn's loop at N=128, full depth, injected noise
     traj_n256     BASELINE configs[2]'s length: 5 reverse steps at B=1 x N=256  } produced by calling the UNMODIFIED
     traj_n512_b2  BASELINE configs[4]'s length: 5 reverse steps at B=2 x N=512  } Experiment.inference_fn itself (a recording
                   wrapper around diffuser.reverse snapshots the numpy RNG state to learn the draws it is about to make)
+    traj_n128_t50 50 reverse steps (51 forwards) of the unmodified Experiment.inference_fn at B=1 x N=128: error growth of the
+                  device-resident / hipGraph-replayed loop over a tenth of the metric's 500-step trajectory
 
 Run in the build container only (needs /root/reference):  python oracle/make_golden_full.py
 The oracle (oracle/framediff_oracle.py) is pinned against the same runs (PINNING_REPORT_FULL.txt).
@@ -43,7 +45,7 @@ def main():
     cases = [
         dict(name="fwd_n128_b2", B=2, N=128, seed=31, n_pad=3, n_fixed=2, blocks=4, grad=True),
         dict(name="fwd_n256_b1", B=1, N=256, seed=32, n_pad=0, n_fixed=0, blocks=4, grad=True),
-        dict(name="fwd_n512_b1", B=1, N=512, seed=33, n_pad=0, n_fixed=0, blocks=4, grad=False),
+        dict(name="fwd_n512_b1", B=1, N=512, seed=33, n_pad=0, n_fixed=0, blocks=4, grad=True),
     ]
     only = os.environ.get("FD_GOLDEN_ONLY")
     for c in cases:
@@ -146,7 +148,8 @@ def main():
                             final_rigids=feats_t["rigids_t"].numpy(), final_psi=mo["psi"].numpy(), step_rigids=np.stack(per_step))
         print("trajectory golden (N=128) written", flush=True)
 
-    for name, Bt, Nt, num_t, seed in (("traj_n256", 1, 256, 5, 42), ("traj_n512_b2", 2, 512, 5, 43)):
+    for name, Bt, Nt, num_t, seed in (("traj_n256", 1, 256, 5, 42), ("traj_n512_b2", 2, 512, 5, 43),
+                                      ("traj_n128_t50", 1, 128, 50, 44)):
         if not only or name in only.split(","):
             t0 = time.time()
             traj_via_experiment(name, Bt, Nt, num_t, seed)

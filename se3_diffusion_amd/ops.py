@@ -6,6 +6,7 @@ torch is used for memory (torch.empty / views) and nothing else.
 from __future__ import annotations
 
 import math
+import threading
 
 import torch
 
@@ -219,15 +220,9 @@ GROUP_DW_MAX_ROWS = 16384          # residue rows (B*N <= 5e5 / N); pair-row gra
 def queue_dw(dy, x, dW, M, N, K, db=None):
     """Queue dW[N,K] += dy[M,N]^T @ x[M,K] (db[N] += column sums of dy) for the next flush_dw().  Returns False when the
     product does not qualify (option off, exact-fp32 mode, operands not float4-addressable): the caller launches it itself."""
-    if not opts.grouped_node_dw or M > GROUP_DW_MAX_ROWS or M < 1 or lib().exact_f32:
+    if not queue_dw_ok(dy, x, dW, M, N, K):
         return False
-    dt, do, dl = dy
-    xt, xo, xl = x
-    wt, wo, wl = dW
-    if (N % 4) or (K % 4) or (dl % 4) or (xl % 4) or (dt.data_ptr() + 4 * do) % 16 or (xt.data_ptr() + 4 * xo) % 16:
-        return False
-    if wl < K or dl < N or xl < K:
-        return False
+    dt, xt, wt = dy[0], x[0], dW[0]
     q = _DWQ
     if q["rows"] is not None and q["rows"] != M:
         flush_dw()
@@ -266,6 +261,25 @@ def group_dw(items, rows, blocks=0):
                      (len(items), 128, int(rows), 1, 0, 0, 0, 1)))
         return
     L._check(L.cdll.fd_group_dw(hip.ctypes.byref(d), stream), "fd_group_dw")
+
+
+def reset_dw_queue():
+    """Drop whatever an interrupted backward pass left queued (an exception between queue_dw() and the next flush_dw()): a stale
+    item would otherwise be launched by the NEXT step's first flush and add into that step's gradient buffers."""
+    q = _DWQ
+    q["items"], q["tensors"], q["rows"] = [], [], None
+
+
+def queue_dw_ok(dy, x, dW, M, N, K):
+    """Would queue_dw accept this product?  (callers that queue several products as a unit check all of them first)"""
+    if not opts.grouped_node_dw or M > GROUP_DW_MAX_ROWS or M < 1 or lib().exact_f32:
+        return False
+    dt, do, dl = dy
+    xt, xo, xl = x
+    wt, wo, wl = dW
+    if (N % 4) or (K % 4) or (dl % 4) or (xl % 4) or (dt.data_ptr() + 4 * do) % 16 or (xt.data_ptr() + 4 * xo) % 16:
+        return False
+    return not (wl < K or dl < N or xl < K)
 
 
 def flush_dw(blocks=0):
@@ -390,18 +404,24 @@ def edge_mlp_pack_bwd(Wf, W2, W1, W40=None, out=None):
 
 
 _SCHED = {}
+_SCHED_LOCK = threading.Lock()
+# launches that took the dynamic tile hand-out since the process started (tests assert that the benchmarked step uses it)
+STATS = {"edge_dynamic_launches": 0}
 
 
-def _edge_sched(like):
+def _edge_sched(like, stream):
     """One word of device scratch for a launch's dynamic tile hand-out (FdEdgeMlpDesc.sched; the entry point zeroes it on the
-    launch's stream): a ring of 64 per device, so that launches that may run at the same time get different words."""
-    key = like.device
-    ent = _SCHED.get(key)
-    if ent is None:
-        ent = _SCHED[key] = [torch.zeros(128, dtype=torch.int32, device=like.device), 0]
-    buf, i = ent
-    ent[1] = (i + 1) % 64
-    return buf.data_ptr() + 8 * i
+    launch's stream).  One word per (device, stream): two launches on one stream are ordered, so the second launch's zeroing
+    memset runs after the first has ended; launches on different streams (two models, a replayed graph beside eager work)
+    never share a word.  Captured graphs keep the word of their capture stream (replays of ONE graph are ordered by the
+    stream they are replayed on; replaying two graphs captured on the same stream concurrently is not supported)."""
+    key = (like.device, int(stream or 0))
+    with _SCHED_LOCK:
+        buf = _SCHED.get(key)
+        if buf is None:
+            buf = _SCHED[key] = torch.zeros(4, dtype=torch.int32, device=like.device)
+        STATS["edge_dynamic_launches"] += 1
+    return buf.data_ptr()
 
 
 def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, qf=None, gamma=None, beta=None,
@@ -421,11 +441,11 @@ def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, 
         if t is not None:
             tens.append(t)
     d.rows, d.nres, d.backward, d.eps, d.blocks = int(rows), int(nres), int(bool(backward)), 1e-5, int(blocks or opts.edge_blocks)
-    if opts.edge_dynamic_tiles and rows >= 4 * 64 * (d.blocks or 512):
-        d.sched = _edge_sched(out)
     d.ld_pq, d.ld_pqf = int(ld_pq), int(ld_pqf)
     L = lib()
     stream = L._stream(tens)
+    if opts.edge_dynamic_tiles and rows >= 4 * 64 * (d.blocks or 512):
+        d.sched = _edge_sched(out, stream)
     prof = L.gemm_profile
     if prof is not None and L.is_device:
         # same record layout as FdLib.gemm (tile code 7 = the fused edge-transition kernel); algorithmic flops of the
@@ -499,10 +519,11 @@ def edge_embed_bwd(dy, h3, mean, rstd, gamma, rowscale, h2, h1, img, dh3, dh2, d
         if t is not None:
             tens.append(t)
     d.rows, d.blocks = int(rows), int(blocks)
-    if opts.edge_dynamic_tiles and rows >= 4 * 64 * (d.blocks or 512):
-        d.sched = _edge_sched(dh3)
     L = lib()
-    L._check(L.cdll.fd_edge_embed_bwd(hip.ctypes.byref(d), L._stream(tens)), "fd_edge_embed_bwd")
+    stream = L._stream(tens)
+    if opts.edge_dynamic_tiles and rows >= 4 * 64 * (d.blocks or 512):
+        d.sched = _edge_sched(dh3, stream)
+    L._check(L.cdll.fd_edge_embed_bwd(hip.ctypes.byref(d), stream), "fd_edge_embed_bwd")
 
 
 # ---------------------------------------------------------------------------

@@ -221,8 +221,12 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3, dzb_next=None):
         ops.linear_dw(mv(dPf), mv(e), (gWf, CZ, EH), R, CZ, CE)
         ops.linear_dw(mv(dQf), mv(e), (gWf, CZ + CE, EH), R, CZ, CE)
         ops.bias_grad(mv(dQf), G[f"{pre}.final_layer.bias"], R, CZ)
-    if not (ops.queue_dw(mv(dPf), mv(e), (gWf, CZ, EH), R, CZ, CE)
-            and ops.queue_dw(mv(dQf), mv(e), (gWf, CZ + CE, EH), R, CZ, CE, db=G[f"{pre}.final_layer.bias"])):
+    # (both products or neither: a half-accepted pair followed by the fallback would add the accepted product twice)
+    if (ops.queue_dw_ok(mv(dPf), mv(e), (gWf, CZ, EH), R, CZ, CE)
+            and ops.queue_dw_ok(mv(dQf), mv(e), (gWf, CZ + CE, EH), R, CZ, CE)):
+        ops.queue_dw(mv(dPf), mv(e), (gWf, CZ, EH), R, CZ, CE)
+        ops.queue_dw(mv(dQf), mv(e), (gWf, CZ + CE, EH), R, CZ, CE, db=G[f"{pre}.final_layer.bias"])
+    else:
         ops.side(_grads_f, (dPf, dQf, e), R)
     de = empty((R, CE), dev)
     ops.linear_dx(mv(dPf), (Wf, CZ, EH), mv(de), R, CZ, CE)
@@ -266,8 +270,11 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3, dzb_next=None):
         ops.linear_dw(mv(dP1), mv(e), (gW1, CZ, EH), R, EH, CE)
         ops.linear_dw(mv(dQ1), mv(e), (gW1, CZ + CE, EH), R, EH, CE)
         ops.bias_grad(mv(dQ1), G[f"{pre}.trunk.0.bias"], R, EH)
-    if not (ops.queue_dw(mv(dP1), mv(e), (gW1, CZ, EH), R, EH, CE)
-            and ops.queue_dw(mv(dQ1), mv(e), (gW1, CZ + CE, EH), R, EH, CE, db=G[f"{pre}.trunk.0.bias"])):
+    if (ops.queue_dw_ok(mv(dP1), mv(e), (gW1, CZ, EH), R, EH, CE)
+            and ops.queue_dw_ok(mv(dQ1), mv(e), (gW1, CZ + CE, EH), R, EH, CE)):
+        ops.queue_dw(mv(dP1), mv(e), (gW1, CZ, EH), R, EH, CE)
+        ops.queue_dw(mv(dQ1), mv(e), (gW1, CZ + CE, EH), R, EH, CE, db=G[f"{pre}.trunk.0.bias"])
+    else:
         ops.side(_grads_1, (dP1, dQ1, e), R)
     ops.linear_dx(mv(dP1), (W1, CZ, EH), mv(de), R, EH, CE, beta=True)
     ops.linear_dx(mv(dQ1), (W1, CZ + CE, EH), mv(de), R, EH, CE, beta=True)
@@ -540,8 +547,13 @@ def backward(P, G, sv, d_out, on_done=None):
         raise NotImplementedError("backward is defined for the training-mode (additive) transformer mask")
     # every zero-initialised accumulator of the pass from one memset (per block: dproj [R,6816], the node-term sums of the
     # edge transition [R,2*(128+384)], du0, ds, dframe, ...: ~R * 8,700 floats)
-    with ops.zero_arena(R * (nb * 8800 + 1024) + 65536 if opts.zero_arena else 0, dev):
-        _backward(P, G, sv, d_out, notify)
+    ops.reset_dw_queue()        # nothing an interrupted earlier pass queued may leak into this one's gradients
+    try:
+        with ops.zero_arena(R * (nb * 8800 + 1024) + 65536 if opts.zero_arena else 0, dev):
+            _backward(P, G, sv, d_out, notify)
+    except BaseException:
+        ops.reset_dw_queue()
+        raise
 
 
 def _backward(P, G, sv, d_out, notify):

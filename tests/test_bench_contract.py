@@ -1,5 +1,5 @@
 """bench.py's output contract (one JSON line with the driver's fields + `roofline` + `cpu_baseline`) on a small configuration,
-and a rehearsal of its multi-rank path: two ranks launched by torch.distributed.run on ONE GPU (FD_DIST_BACKEND=gloo,
+and a rehearsal of its multi-rank path: `python bench.py --gpus 2` starting its own two ranks on ONE GPU (FD_DIST_BACKEND=gloo,
 FD_FORCE_DEVICE=0 -- RCCL refuses two ranks on a device), i.e. the per-rank data, parameter broadcast, flat all-reduce,
 barrier-bracketed timing and max-over-ranks code that `--gpus N` runs on an 8-GPU node."""
 import json
@@ -44,6 +44,21 @@ def test_bench_line_single(hip_lib):
 
 
 def test_bench_two_ranks_on_one_gpu(hip_lib):
+    """plain `python bench.py --gpus 2`: bench.py starts its two ranks itself (spawn_ranks -> torch.distributed.run); gloo and a
+    forced device because RCCL refuses two ranks on one GPU -- on an 8-GPU node the same command runs over RCCL."""
+    env = dict(os.environ, FD_BENCH_PRIME="1", FD_DIST_BACKEND="gloo", FD_FORCE_DEVICE="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = _line(r.stdout)
+    _check(d, 2)
+    c = d["config"]
+    assert c["ranks"] == 2 and c["collective_backend"] == "gloo" and c["rccl_ranks"] == 0 and len(c["ms_per_step_by_rank"]) == 2
+
+
+def test_bench_under_torchrun(hip_lib):
+    """the driver's own launch form for N > 1 (torch.distributed.run around bench.py --gpus N) still works and is not re-spawned"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

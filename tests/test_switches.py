@@ -87,6 +87,34 @@ def test_switches_two_blocks_emu(use_emu):
     _compare("cpu", B=1, N=8, blocks=2, groups=[GROUPS[7], GROUPS[8], GROUPS[9]])
 
 
+def _dynamic_vs_static(dev, B, N, blocks):
+    """the dynamic tile hand-out of the fused edge kernels inside a full step: with two persistent blocks per launch (edge_blocks=2)
+    every fused edge / embedder-backward launch of these sizes has >= 4 tiles per block and takes the atomic-counter path; the
+    same step with the static stride must give the same gradients (the default-size comparison was vacuous)."""
+    from se3_diffusion_amd import ops
+    n0 = ops.STATS["edge_dynamic_launches"]
+    l1, g1 = _step(dev, B, N, blocks, edge_blocks=2)
+    assert ops.STATS["edge_dynamic_launches"] > n0, "the dynamic path was not taken"
+    n1 = ops.STATS["edge_dynamic_launches"]
+    l0, g0 = _step(dev, B, N, blocks, edge_blocks=2, edge_dynamic_tiles=False)
+    assert ops.STATS["edge_dynamic_launches"] == n1
+    assert abs(l0 - l1) <= 2e-6 * abs(l0)
+    for n in g0:
+        if n.endswith("linear_b.bias"):
+            continue
+        err = float((g1[n] - g0[n]).abs().max() / (g0[n].abs().max() + 1e-3))
+        assert err < 1e-4, (n, err)
+
+
+def test_dynamic_tiles_emu(use_emu):
+    _dynamic_vs_static("cpu", B=2, N=16, blocks=2)
+
+
+@pytest.mark.gpu
+def test_dynamic_tiles_gpu(hip_lib):
+    _dynamic_vs_static("cuda", B=2, N=32, blocks=2)
+
+
 def test_options_override_restores():
     was = options.opts.fused_edge
     with options.override(fused_edge=not was):
