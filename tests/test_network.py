@@ -30,8 +30,18 @@ def relerr(a, b, floor=1e-12):
     return float((a - b).abs().max() / (b.abs().max() + floor))
 
 
+# Per-output bounds = <= 10 x the worst value any GPU parity case achieved in round 4 (profiles/r04_parity_errors.md: 35 cases,
+# N = 12 ... 512, B up to 30, three GEMM modes): trans_score 2.9e-6, atom37 / atom14 7.3e-6, rigids 6.1e-7, rot_score 7.6e-5 (the
+# B=30 step; 1e-6 typical), psi 1.4e-4 in ONE case whose torsion pre-activation is nearly the zero vector (B=3 x N=37; 1e-6 ... 1e-5
+# everywhere else) -- psi keeps the 2e-4 it had.  The same errors appear with every GEMM a bitwise fp32 chain (exact_f32 mode): they
+# are the fp32 oracle's own summation order, not the split-bf16 arithmetic.
+TOL_OUT_KEY = {"trans_score": 3e-5, "atom37": 7e-5, "atom14": 7e-5, "rigids": 1e-5, "rot_score": 8e-4, "psi": 2e-4}
+
+
 def check_out(key, got, ref, tol, floor=1e-12, errs=None):
-    """max |got - ref| / max |ref| < tol, with the achieved value recorded (parity_log) and returned"""
+    """max |got - ref| / max |ref| < tol (the tighter of the caller's bound and TOL_OUT_KEY's), with the achieved value recorded
+    (parity_log) and returned"""
+    tol = min(tol, TOL_OUT_KEY.get(key, tol))
     e = relerr(got, ref, floor)
     parity_log.out(key, e)
     if errs is not None:
@@ -65,6 +75,8 @@ def grad_mismatch(g, g_ref, tol=2e-3, floor=2e-5, kink_tol=1e-2, kink_units=2, n
     r2 = g_ref.detach().double().cpu()
     scale = float(r2.abs().max())
     err = (g2 - r2).abs()
+    if name is not None:
+        tol = min(tol, TOL_GRAD_FAMILY.get(parity_log.family(name), tol))
     over = err > tol * scale + floor
     n_over = int(over.sum())
     if n_over == 0:
@@ -100,8 +112,13 @@ def quat_align(a, b):
     return torch.cat([a[..., :4] * s, a[..., 4:]], -1)
 
 
-# the bounds of the fp32 parity tests (DESIGN.md "Numerics"); tests/parity_log.py records what every case achieves
-TOL_OUT, TOL_ROT, TOL_GRAD, ABS_GRAD, TOL_GRAD_L2 = 2e-4, 1e-3, 2e-3, 2e-5, None
+# the bounds of the fp32 parity tests (DESIGN.md "Numerics"); tests/parity_log.py records what every case achieves.
+# Gradients (max |g - g_ref| / max |g_ref| per tensor): measured worst per parameter family 1.8e-5 (bb_update) ... 4.8e-4 (most
+# families, at the B=30 benchmarked step -- a sum over 30 x 128^2 pair rows in fp32 on both sides) ... 1.2e-3 (edge_transition
+# trunk.0.weight at N=512, where the oracle itself is 5.5e-4 from the reference): TOL_GRAD = 2e-3 is 1.7 - 4 x those, per-family
+# bounds below are tighter where the code achieves more.  TOL_GRAD_L2: relative L2 error of a tensor (worst measured 5.1e-4).
+TOL_OUT, TOL_ROT, TOL_GRAD, ABS_GRAD, TOL_GRAD_L2 = 2e-4, 8e-4, 2e-3, 2e-5, 2e-3
+TOL_GRAD_FAMILY = {"bb_update": 2e-4, "torsion_pred": 1.2e-3}
 
 
 def run_case(dev, B, N, blocks, seed, n_pad=0, n_fixed=0, check_grad=True, tol_out=TOL_OUT, tol_grad=TOL_GRAD, rot_floor=1e-12,

@@ -14,8 +14,9 @@ Every case runs three times: with the shipped GEMM selection, with the persisten
 M >= 65536 weight-gradient tiles 4/6 engage by themselves) and with FD_GEMM_EXACT_F32 (every GEMM a bitwise fp32
 fmaf chain; the fused split-bf16 edge-transition kernel is then replaced by the unfused fp32 launch sequence).
 
-Tolerances (fp32, the table in DESIGN.md "Numerics"): outputs 2e-4 of the tensor's max magnitude (rot_score 1e-3),
-parameter gradients 2e-3 of the tensor's max magnitude + 2e-5 absolute (analytically-zero gradients); a ReLU-fed Linear may
+Tolerances (fp32, the table in DESIGN.md "Numerics"; written in tests/test_network.py next to the measured values they are <= 10 x
+of): outputs per key 1e-5 ... 8e-4 of the tensor's max magnitude, parameter gradients 2e-3 of the tensor's max magnitude (2e-4 /
+1.2e-3 for two families) + 2e-5 absolute (analytically-zero gradients) and 2e-3 relative L2 per tensor; a ReLU-fed Linear may
 show at most two flipped hidden units (rows of its weight / entries of its bias) within 1e-2, counted and bounded per case
 (test_network.grad_mismatch / check_kinks).
 """
@@ -39,7 +40,8 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 OUT_KEYS = ["rot_score", "trans_score", "rigids", "atom37", "psi"]
 MODES = ("shipped", "persistent", "exact_f32")
 TOL_LOSS = 1e-4
-TOL_TRAJ50 = (5e-3, 5e-2, 1e-2)     # rotation matrices, translations (Angstrom), psi after 50 chained steps
+# 50 chained steps: measured 1.4e-5 (rotation matrices), 1.2e-4 A (translations), 1e-6 (psi), eager and graph-replayed alike
+TOL_TRAJ50 = (1.5e-4, 1.5e-3, 1e-4)
 TOL_GSIG = 2e-3       # gradient signatures (sum, norm) of the reference's large tensors
 
 
@@ -292,7 +294,8 @@ def test_reference_golden_n512(hip_lib):
     _golden_full(hip_lib, "fwd_n512_b1", "shipped")
 
 
-def _trajectory(fixture, use_graph, tol_rot=1e-3, tol_trans=1e-2, tol_psi=2e-3):
+# 5-step trajectories: measured worst 4.2e-5 (rotation matrices), 9e-4 A (translations, B=2 x N=512), 1e-5 (psi)
+def _trajectory(fixture, use_graph, tol_rot=4e-4, tol_trans=9e-3, tol_psi=1e-4):
     from se3_diffusion_amd import sampler, train_step as ts
     from se3_diffusion_amd.data import se3_diffuser, utils as du
     from se3_diffusion_amd.model.score_network import ScoreNetwork
