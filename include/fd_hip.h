@@ -148,7 +148,7 @@ typedef struct FdEdgeMlpDesc {
   int nres;
   int backward;
   float eps;
-  int blocks;            /* 0 = one persistent block per CU (256) */
+  int blocks;            /* 0 = persistent blocks that fill the 256 CUs (512 of shape 4, 256 of shape 8) */
   long ld_pq;            /* row stride of p1 / q1 (0 = 384) */
   long ld_pqf;           /* row stride of pf / qf (0 = 128) */
   float* zb_out;         /* forward, optional: [rows,40] (see above) */
@@ -173,7 +173,10 @@ typedef struct FdEdgeMlpDesc {
   unsigned* sched;          /* optional: one word of device scratch -- a launch whose blocks walk four or more 64-row tiles each then
                                hands the tiles out dynamically (one atomic per tile and block); fd_edge_mlp zeroes the word on
                                the launch's stream; the words of launches that may run at the same time must differ */
+  int shape;                /* 0 = by size (8 from FD_EDGE_MLP_W8_MIN_ROWS rows up), 4 = 4 waves x 64-row tiles on two blocks per CU,
+                               8 = 8 waves x 128-row tiles on one block per CU (same results bit for bit) */
 } FdEdgeMlpDesc;
+#define FD_EDGE_MLP_W8_MIN_ROWS 131072L
 int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream);
 
 /* ---- edge embedder, fused (model/score_network.py:97-101,129-153 Embedder edge path, data/utils.py:570-580) ----

@@ -16,9 +16,13 @@
 constexpr int EM_ROWS = 16 * EM_WAVES;     // rows per block tile
 constexpr int EM_PIECE = 1024;             // one fragment: 64 lanes x 16 B
 constexpr int EM_UNIT = 12 * EM_PIECE;     // 4 n-blocks x 3 planes
-constexpr int EM_UPS = EM_WAVES / 2;       // units per stage
-constexpr int EM_STAGE = EM_UPS * EM_UNIT; // 48 KB (8 waves) / 24 KB (4 waves)
+#ifndef EM_UPS
+#define EM_UPS (EM_WAVES / 2)              // units per stage (a stage = one barrier interval of the weight stream)
+#endif
+constexpr int EM_STAGE = EM_UPS * EM_UNIT; // 24 KB with two units
 constexpr int EM_BLOCKS_PER_CU = 8 / EM_WAVES;
+constexpr int EM_PPW = 12 * EM_UPS / EM_WAVES;   // 1 KB LDS-DMA pieces of a stage per wave: 6 (4 waves x 2 units) or 3 (8 waves x 2 units)
+static_assert(EM_PPW * EM_WAVES == 12 * EM_UPS && (EM_PPW == 6 || EM_PPW == 3), "a stage must split into 3 or 6 whole pieces per wave");
 
 __device__ __forceinline__ void em_split8(const float (&x)[8], uint4& s0, uint4& s1, uint4& s2) {
   unsigned t0[4], t1[4], t2[4];
@@ -71,3 +75,25 @@ __device__ __forceinline__ void em16_mma_half(f32x4& a0, f32x4& a1, const Em16Ha
   }
 }
 
+// Order of a half-unit's instructions in the stage loops (the fragment reads of half-unit i + 1 are in flight while half-unit i is
+// multiplied).  Default (round 4): one scheduling region per half-unit in which the six ds_read_b128 ride between its first six
+// MFMAs -- a wave's own MFMA stream has no read-issue gap and the compiler keeps the fragments' live ranges short (0 - 9 spilled
+// VGPRs instead of 12 - 34 in fd_edge_mlp.hip): -3 ... -8 % per launch (profiles/r04_edge_variants_*.log).  -DEM_NO_INTERLEAVE: the
+// round-3 order -- the six reads in a block in front of the twelve MFMAs, a sched_barrier between them.
+#ifndef EM_NO_INTERLEAVE
+#define EM_PIN_TOP() fd::sched_pin()
+#define EM_PIN_MID()
+// (the six reads ride behind the FIRST six MFMAs -- one each --, so the last one has six MFMAs = ~100 cycles to return before the
+// next half-unit needs it; spread over all twelve, the next half-unit opened with an lgkmcnt(0) stall)
+#define EM_GROUPS(has_read)                                                                     \
+  if (has_read) {                                                                               \
+    fd::sched_group<0x008, 1>(); fd::sched_group<0x100, 1>(); fd::sched_group<0x008, 1>(); fd::sched_group<0x100, 1>(); \
+    fd::sched_group<0x008, 1>(); fd::sched_group<0x100, 1>(); fd::sched_group<0x008, 1>(); fd::sched_group<0x100, 1>(); \
+    fd::sched_group<0x008, 1>(); fd::sched_group<0x100, 1>(); fd::sched_group<0x008, 1>(); fd::sched_group<0x100, 1>(); \
+    fd::sched_group<0x008, 6>();                                                                \
+  }
+#else
+#define EM_PIN_TOP()
+#define EM_PIN_MID() fd::sched_pin()
+#define EM_GROUPS(has_read)
+#endif

@@ -164,12 +164,14 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_kernel(FdEdgeEmbe
 #pragma clang loop unroll(full)
       for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
         const int r = EM_UPS * sg + (hh >> 1), g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
+        EM_PIN_TOP();
         if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-        fd::sched_pin();
+        EM_PIN_MID();
         if (g2 == 0 && (hh & 1) == 0) {
           if ((r >> 1) == 0) em_split8(x0, b[0], b[1], b[2]); else em_split8(x1, b[0], b[1], b[2]);
         }
         em16_mma_half(acc1[a], acc1[a + 1], H[hh & 1], b);
+        EM_GROUPS(hh + 1 < 2 * EM_UPS);
         if (hh == 1) stage_prefetch();
       }
     }
@@ -203,10 +205,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_kernel(FdEdgeEmbe
 #pragma clang loop unroll(full)
       for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
         const int r = EM_UPS * sg + (hh >> 1), ks = r >> 1, g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
+        EM_PIN_TOP();
         if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-        fd::sched_pin();
+        EM_PIN_MID();
         if (g2 == 0 && (hh & 1) == 0) em16_split2(acc1[2 * ks], acc1[2 * ks + 1], b[0], b[1], b[2]);
         em16_mma_half(acc2[a], acc2[a + 1], H[hh & 1], b);
+        EM_GROUPS(hh + 1 < 2 * EM_UPS);
         if (hh == 1) stage_prefetch();
       }
     }
@@ -230,10 +234,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_kernel(FdEdgeEmbe
 #pragma clang loop unroll(full)
       for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
         const int r = EM_UPS * sg + (hh >> 1), ks = r >> 1, g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
+        EM_PIN_TOP();
         if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-        fd::sched_pin();
+        EM_PIN_MID();
         if (g2 == 0 && (hh & 1) == 0) em16_split2(acc2[2 * ks], acc2[2 * ks + 1], b[0], b[1], b[2]);
         em16_mma_half(acc3[a], acc3[a + 1], H[hh & 1], b);
+        EM_GROUPS(hh + 1 < 2 * EM_UPS);
         if (hh == 1) stage_prefetch();
       }
     }
@@ -297,10 +303,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_kernel(FdEdgeEmbe
 #pragma clang loop unroll(full)
         for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
           const int ks = EM_UPS * sg + (hh >> 1), a = 2 * (hh & 1);
+          EM_PIN_TOP();
           if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-          fd::sched_pin();
+          EM_PIN_MID();
           if ((hh & 1) == 0) em16_split2(acc3[2 * ks], acc3[2 * ks + 1], b[0], b[1], b[2]);
           em16_mma_half(acc4[a], acc4[a + 1], H[hh & 1], b);
+          EM_GROUPS(hh + 1 < 2 * EM_UPS);
           if (hh == 1) stage_prefetch();
         }
       }

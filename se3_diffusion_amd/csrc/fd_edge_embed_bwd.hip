@@ -167,10 +167,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_bwd_kernel(FdEdge
 #pragma clang loop unroll(full)
       for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
         const int r = EM_UPS * sg + (hh >> 1), ks = r >> 1, g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
+        EM_PIN_TOP();
         if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-        fd::sched_pin();
+        EM_PIN_MID();
         if (g2 == 0 && (hh & 1) == 0) em16_split2(d3[2 * ks], d3[2 * ks + 1], b[0], b[1], b[2]);
         em16_mma_half(a2[a], a2[a + 1], H[hh & 1], b);
+        EM_GROUPS(hh + 1 < 2 * EM_UPS);
         if (hh == 1) stage_prefetch();
       }
     }
@@ -203,10 +205,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_bwd_kernel(FdEdge
 #pragma clang loop unroll(full)
       for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
         const int r = EM_UPS * sg + (hh >> 1), ks = r >> 1, g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
+        EM_PIN_TOP();
         if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-        fd::sched_pin();
+        EM_PIN_MID();
         if (g2 == 0 && (hh & 1) == 0) em16_split2(a2[2 * ks], a2[2 * ks + 1], b[0], b[1], b[2]);
         em16_mma_half(a1[a], a1[a + 1], H[hh & 1], b);
+        EM_GROUPS(hh + 1 < 2 * EM_UPS);
         if (hh == 1) stage_prefetch();
       }
     }

@@ -33,8 +33,23 @@
 //     8 units Wfz, 24 units Wf                           (layer 3, K = 128 + 384)
 // Algorithmic HBM bytes per pair row: 512 read + 512 written (PMC: 1.1 KB) (+ h1, h2, y saved for the backward in
 // training).
+// Two shapes of the same kernel are built (round 4):
+//   fd_edge_mlp.hip itself      4 waves x 64-row tiles, two blocks per CU, 24 KB stages (two units), ring of two: launches with
+//                               few tiles per CU (single backbones)
+//   fd_edge_mlp_w8.hip          8 waves x 128-row tiles, ONE block per CU, 48 KB stages (four units), ring of two: half the barriers
+//                               per MFMA and one weight stream per CU instead of two (half the L2 -> LDS traffic): -5 ... -8 % per
+//                               launch from 131,072 pair rows up (profiles/r04_edge_variants_*.log)
+// (that file defines EM_SHAPE_W8 + the shape macros and includes this one; the pack kernels and the C entry points live here only)
 #include "fd_common.h"
 #include "../../include/fd_hip.h"
+
+#ifdef EM_SHAPE_W8
+#define EM_LAUNCH fd_edge_mlp_launch_w8
+#else
+#define EM_LAUNCH fd_edge_mlp_launch_w4
+#endif
+int fd_edge_mlp_launch_w4(const FdEdgeMlpDesc& d, hipStream_t st);
+int fd_edge_mlp_launch_w8(const FdEdgeMlpDesc& d, hipStream_t st);
 
 namespace {
 
@@ -44,11 +59,17 @@ constexpr int EM_UNITS = 128;              // units per tile
 constexpr int EM_ZB_UNITS = 4;             // + the next IPA block's [linear_b ; down_z] (40 <- 128: 4 k-steps x one n-group)
 constexpr int EM_ZB = 40;
 #ifndef EM_RING
-// LDS stages of the weight stream.  3 (the copy runs two stages ahead behind a counted vmcnt wait) makes the kernel 2-3 %
-// faster on its own (1.47 vs 1.51 ms forward with saves) but costs 144 KB of LDS per CU, and the training step then loses
-// the overlap with the gradient side stream: 29.0 vs 26.0 ms per step on one box.  2 is shipped.
+// LDS stages of the weight stream and how many stages ahead of its use a stage's copy is issued (EM_AHEAD <= EM_RING - 1: the
+// slot a copy lands in was last read one barrier ago at the latest).  Round 2: ring 3 / ahead 2 with two 4-wave blocks per CU
+// made the kernel 2-3 % faster on its own but cost 144 KB of LDS per CU, and the training step lost its overlap with the
+// gradient side stream (29.0 vs 26.0 ms).  Round 4 (-DEM_WAVES=8: ONE 8-wave block per CU, one weight stream for 128 rows, half the
+// L2 -> LDS traffic): the ring can be four or five 24 KB stages deep.
 #define EM_RING 2
 #endif
+#ifndef EM_AHEAD
+#define EM_AHEAD (EM_RING - 1)
+#endif
+static_assert(EM_AHEAD >= 1 && EM_AHEAD <= 3 && EM_AHEAD <= EM_RING - 1, "copy distance: 1..3 stages, at most ring - 1");
 constexpr int EM_H = 384, EM_C = 128;
 
 // Probe build only (tools/probes/edge_phases.py compiles this file with -DEM_PHASE_TIMING into its own library): wave-level
@@ -71,6 +92,7 @@ __device__ unsigned long long em_phase[12];
 #define EM_BODY_TO(i)
 #endif
 
+#ifndef EM_SHAPE_W8
 struct EmMat {
   const float* p;
   long rs, cs;
@@ -165,6 +187,8 @@ __global__ __launch_bounds__(256) void edge_mlp_pack_zbw_kernel(const float* __r
   *reinterpret_cast<uint4*>(dst + 2 * EM_PIECE) = s2;
 }
 
+#endif  // !EM_SHAPE_W8
+
 // ZB (forward only): a fourth chained layer on the kernel's own output -- zb = [linear_b ; down_z] z' + b40 of the next
 // trunk block's IPA -- so that block needs no pass over z' [P,128] for it (fd_gemm: 119 us per block at B=30 x N=128, 252 MB
 // read); +3 % of the chain's MFMAs, 160 B more written per pair row
@@ -224,20 +248,28 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
   auto issue_stage = [&]() __attribute__((always_inline)) {
     const char* src = img_lane + (long)(issued % EM_NSTAGE) * EM_STAGE;
     char* dst = lds_wave + (issued % EM_RING) * EM_STAGE;
-    fd::glds16x4(src, dst);
-    fd::glds16x2(src + 4096, dst + 4096);
+    if (EM_PPW == 6) {
+      fd::glds16x4(src, dst);
+      fd::glds16x2(src + 4096, dst + 4096);
+    } else {
+      fd::glds16x3(src, dst);
+    }
     ++issued;
   };
   // begin the next stage: its copy (issued one stage ago) has landed and is visible to the block; every wave is done
   // with the previous stage, whose buffer takes the copy after next.  Returns the stage's LDS address + 16 * lane.
   auto stage_begin = [&]() __attribute__((always_inline)) -> const char* {
-    // EM_RING == 3: the copy of the stage AFTER this one (6 LDS-DMA instructions per wave, issued during the previous
-    // stage) may stay in flight across the barrier -- vmcnt retires in issue order, so "at most 6 outstanding" means this
-    // stage's copy, issued before them, has landed (any other memory operation issued since only makes the wait stricter)
-    // (no younger copy in flight -- the last stage of the launch: wait for everything)
+    // EM_AHEAD > 1: the copies of the stages AFTER this one (EM_PPW LDS-DMA instructions per wave and stage, issued during the
+    // previous stages) may stay in flight across the barrier; no younger copy in flight -- the last stage of the launch: wait for
+    // everything
     EM_TICK_TO(tb_);
-    if (EM_RING == 3 && issued > consumed + 1)
-      fd::wait_vmem_keep6();
+    // (vmcnt retires in issue order: "at most y x EM_PPW outstanding" = this stage's copy, issued before the y younger stages'
+    // copies, has landed; any other memory operation issued since only makes the wait stricter)
+    const int younger = issued - consumed - 1;
+    if (EM_AHEAD >= 3 && younger >= 2)
+      fd::wait_vmem_keep<2 * EM_PPW>();
+    else if (EM_AHEAD >= 2 && younger >= 1)
+      fd::wait_vmem_keep<EM_PPW>();
     else
       fd::wait_vmem();
     __syncthreads();
@@ -252,7 +284,9 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
     if (issued < total_stages) issue_stage();
   };
   issue_stage();
-  if (EM_RING == 3 && total_stages > 1) issue_stage();
+#pragma unroll
+  for (int a = 1; a < EM_AHEAD; ++a)
+    if (a < total_stages) issue_stage();
   if (LNB) {
     if (tid < 2 * EM_C) lnacc[tid] = 0.f;           // (ordered before its first use by the first stage barrier / the one below)
     __syncthreads();
@@ -316,10 +350,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
 #pragma clang loop unroll(full)
           for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
             const int r = EM_UPS * sg + (hh >> 1), g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
+            EM_PIN_TOP();
             if (hh + 1 < 2 * EM_UPS) em16_read_half(Hz[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-            fd::sched_pin();
+            EM_PIN_MID();
             if (g2 == 0 && (hh & 1) == 0) em_split8(kz[r >> 1], bz[0], bz[1], bz[2]);
             em16_mma_half(X[a], X[a + 1], Hz[hh & 1], bz);
+            EM_GROUPS(hh + 1 < 2 * EM_UPS);
             if (hh == 1) stage_prefetch();
           }
         }
@@ -414,10 +450,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
 #pragma clang loop unroll(full)
         for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
           const int r = EM_UPS * sg + (hh >> 1), g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
+          EM_PIN_TOP();
           if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-          fd::sched_pin();
+          EM_PIN_MID();
           if (g2 == 0 && (hh & 1) == 0) em_split8(xr[r >> 1], b[0], b[1], b[2]);
           em16_mma_half(acc1[a], acc1[a + 1], H[hh & 1], b);
+          EM_GROUPS(hh + 1 < 2 * EM_UPS);
           if (hh == 1) stage_prefetch();
         }
       }
@@ -466,10 +504,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
 #pragma clang loop unroll(full)
         for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
           const int u2 = EM_UPS * sg + (hh >> 1), ks = u2 / 6, g6 = u2 % 6, a = 4 * g6 + 2 * (hh & 1);
+          EM_PIN_TOP();
           if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-          fd::sched_pin();
+          EM_PIN_MID();
           if (g6 == 0 && (hh & 1) == 0) em16_split2(acc1[2 * ks], acc1[2 * ks + 1], b[0], b[1], b[2]);
           em16_mma_half(acc2[a], acc2[a + 1], H[hh & 1], b);
+          EM_GROUPS(hh + 1 < 2 * EM_UPS);
           if (hh == 1) stage_prefetch();
         }
       }
@@ -522,10 +562,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
 #pragma clang loop unroll(full)
       for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
         const int r = EM_UPS * sg + (hh >> 1), g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
+        EM_PIN_TOP();
         if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-        fd::sched_pin();
+        EM_PIN_MID();
         if (g2 == 0 && (hh & 1) == 0) em_split8(xr[r >> 1], b[0], b[1], b[2]);
         em16_mma_half(acc3[a], acc3[a + 1], H[hh & 1], b);
+        EM_GROUPS(hh + 1 < 2 * EM_UPS);
         if (hh == 1) stage_prefetch();
       }
     }
@@ -536,10 +578,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
 #pragma clang loop unroll(full)
       for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
         const int v = EM_UPS * sg + (hh >> 1), ks = v >> 1, g2 = v & 1, a = 4 * g2 + 2 * (hh & 1);
+        EM_PIN_TOP();
         if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-        fd::sched_pin();
+        EM_PIN_MID();
         if (g2 == 0 && (hh & 1) == 0) em16_split2(acc2[2 * ks], acc2[2 * ks + 1], b[0], b[1], b[2]);
         em16_mma_half(acc3[a], acc3[a + 1], H[hh & 1], b);
+        EM_GROUPS(hh + 1 < 2 * EM_UPS);
         if (hh == 1) stage_prefetch();
       }
     }
@@ -613,10 +657,12 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
 #pragma clang loop unroll(full)
           for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
             const int ks = EM_UPS * sg + (hh >> 1), a = 2 * (hh & 1);
+            EM_PIN_TOP();
             if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-            fd::sched_pin();
+            EM_PIN_MID();
             if ((hh & 1) == 0) em16_split2(acc3[2 * ks], acc3[2 * ks + 1], b[0], b[1], b[2]);
             em16_mma_half(acc4[a], acc4[a + 1], H[hh & 1], b);
+            EM_GROUPS(hh + 1 < 2 * EM_UPS);
             if (hh == 1) stage_prefetch();
           }
         }
@@ -679,6 +725,40 @@ extern "C" int fd_edge_mlp_phases(unsigned long long* host12, int reset) {
 }
 #endif
 
+// the launch of THIS translation unit's shape (tile = 16 * EM_WAVES rows, 256 * EM_BLOCKS_PER_CU persistent blocks)
+int EM_LAUNCH(const FdEdgeMlpDesc& d, hipStream_t st) {
+  const long ntiles = (d.rows + EM_ROWS - 1) / EM_ROWS;
+  const int blocks = d.blocks > 0 ? d.blocks : 256 * EM_BLOCKS_PER_CU;   // MI355X: persistent blocks fill the 256 CUs
+  const int grid = (int)(ntiles < blocks ? ntiles : blocks);
+  const dim3 g3(grid), b3(64 * EM_WAVES);
+  // dynamic tile hand-out: only for launches whose blocks walk several tiles each; the counter word is zeroed here, on the launch's
+  // own stream, so a launch never depends on how an earlier one left it
+  FdEdgeMlpDesc dd = d;
+  if (dd.sched != nullptr && ntiles >= 4L * grid) {
+    FD_CHECK_ARG(hipMemsetAsync(dd.sched, 0, sizeof(unsigned), st) == hipSuccess, "fd_edge_mlp: zeroing the tile counter failed");
+  } else {
+    dd.sched = nullptr;
+  }
+  const bool zbv = d.zb_out != nullptr, mk = d.mask1 != nullptr;
+  if (d.backward && d.ln_y != nullptr && d.dzb != nullptr)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false, true, true>), g3, b3, 0, st, dd);
+  else if (d.backward && d.ln_y != nullptr)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false, true, false>), g3, b3, 0, st, dd);
+  else if (d.backward)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false>), g3, b3, 0, st, dd);
+  else if (zbv && mk)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true, true>), g3, b3, 0, st, dd);
+  else if (zbv)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true, false>), g3, b3, 0, st, dd);
+  else if (mk)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, false, true>), g3, b3, 0, st, dd);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, false, false>), g3, b3, 0, st, dd);
+  FD_CHECK_LAUNCH("fd_edge_mlp");
+  return FD_OK;
+}
+
+#ifndef EM_SHAPE_W8
 extern "C" int fd_edge_mlp_pack(const float* A1, long rs1, long cs1, const float* A2, long rs2, long cs2,
                                 const float* A3, long rs3, long cs3, const float* A4, long rs4, long cs4, void* img,
                                 void* stream) {
@@ -737,38 +817,15 @@ extern "C" int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream) {
                         d.gamma, d.beta, d.y, d.ln_y, d.ln_gamma, d.dy_out, d.dzb};
   for (const void* p : ptrs) FD_CHECK_ARG(fd_aligned16(p), "fd_edge_mlp: operands must be 16-byte aligned");
   if (d.rows == 0) return FD_OK;
-  const long ntiles = (d.rows + EM_ROWS - 1) / EM_ROWS;
-  const int blocks = d.blocks > 0 ? d.blocks : 256 * EM_BLOCKS_PER_CU;   // MI355X: persistent blocks fill the 256 CUs
-  const int grid = (int)(ntiles < blocks ? ntiles : blocks);
   FD_CHECK_ARG(d.zb_out == nullptr || (!d.backward && fd_aligned16(d.zb_out) && fd_aligned16(d.zb_bias)),
                "fd_edge_mlp: zb_out is a forward output (16-byte aligned; the image must carry the fd_edge_mlp_pack_zb units)");
   FD_CHECK_ARG((d.mask1 == nullptr) == (d.mask2 == nullptr) && (d.gmask1 == nullptr) == (d.gmask2 == nullptr),
                "fd_edge_mlp: mask1 / mask2 (forward) and gmask1 / gmask2 (backward) come in pairs");
-  const dim3 g3(grid), b3(64 * EM_WAVES);
+  FD_CHECK_ARG(d.shape == 0 || d.shape == 4 || d.shape == 8, "fd_edge_mlp: shape is 0 (by size), 4 or 8 (waves per block)");
+  // shape by size: the one-block-per-CU shape needs >= 4 of its 128-row tiles per CU to amortise its longer tile (measured:
+  // 16,384 rows 0.088 vs 0.063 ms, 458,752 rows 1.21 / 1.42 / 1.33 vs 1.23 / 1.66 / 1.47 ms fwd / fwd + saves / bwd)
+  const int shape = d.shape != 0 ? d.shape : (d.rows >= FD_EDGE_MLP_W8_MIN_ROWS ? 8 : 4);
   hipStream_t st = (hipStream_t)stream;
-  // dynamic tile hand-out: only for launches whose blocks walk several tiles each; the counter word is zeroed here, on the launch's
-  // own stream, so a launch never depends on how an earlier one left it
-  FdEdgeMlpDesc dd = d;
-  if (dd.sched != nullptr && ntiles >= 4L * grid) {
-    FD_CHECK_ARG(hipMemsetAsync(dd.sched, 0, sizeof(unsigned), st) == hipSuccess, "fd_edge_mlp: zeroing the tile counter failed");
-  } else {
-    dd.sched = nullptr;
-  }
-  const bool zbv = d.zb_out != nullptr, mk = d.mask1 != nullptr;
-  if (d.backward && d.ln_y != nullptr && d.dzb != nullptr)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false, true, true>), g3, b3, 0, st, dd);
-  else if (d.backward && d.ln_y != nullptr)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false, true, false>), g3, b3, 0, st, dd);
-  else if (d.backward)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false>), g3, b3, 0, st, dd);
-  else if (zbv && mk)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true, true>), g3, b3, 0, st, dd);
-  else if (zbv)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true, false>), g3, b3, 0, st, dd);
-  else if (mk)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, false, true>), g3, b3, 0, st, dd);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, false, false>), g3, b3, 0, st, dd);
-  FD_CHECK_LAUNCH("fd_edge_mlp");
-  return FD_OK;
+  return shape == 8 ? fd_edge_mlp_launch_w8(d, st) : fd_edge_mlp_launch_w4(d, st);
 }
+#endif  // !EM_SHAPE_W8

@@ -84,6 +84,21 @@ __device__ __forceinline__ void glds16x4(const void* g_lane, void* lds_wave_base
       : "v"(g_lane), "s"(dst)
       : "memory");
 }
+__device__ __forceinline__ void glds16x3(const void* g_lane, void* lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(lds_wave_base));
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g_lane), "s"(dst)
+      : "memory");
+}
 __device__ __forceinline__ void glds16x2(const void* g_lane, void* lds_wave_base) {
   unsigned keep;
   const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(lds_wave_base));
@@ -121,6 +136,11 @@ __device__ __forceinline__ void wait_vmem_keep() { asm volatile("s_waitcnt vmcnt
 
 // the instruction scheduler moves nothing across this point (pins a software-pipelined order)
 __device__ __forceinline__ void sched_pin() { __builtin_amdgcn_sched_barrier(0); }
+
+// one group of an instruction-scheduling pipeline (llvm.amdgcn.sched.group.barrier): the next SIZE instructions of class MASK
+// (0x008 MFMA, 0x100 LDS read, 0x002 VALU, 0x020 VMEM read) in program order of the groups declared in this scheduling region
+template <int MASK, int SIZE>
+__device__ __forceinline__ void sched_group() { __builtin_amdgcn_sched_group_barrier(MASK, SIZE, 0); }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }

@@ -89,9 +89,11 @@ class FdEdgeMlpDesc(Structure):
         ("mask1", c_void_p), ("mask2", c_void_p), ("gmask1", c_void_p), ("gmask2", c_void_p),
         ("ln_y", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_gamma", c_void_p), ("ln_rowscale", c_void_p),
         ("dy_out", c_void_p), ("ln_dgamma", c_void_p), ("ln_dbeta", c_void_p), ("dzb", c_void_p), ("sched", c_void_p),
+        ("shape", c_int),
     ]
 
 
+EDGE_MLP_W8_MIN_ROWS = 131072
 EDGE_MLP_IMAGE_BYTES = 132 * 12288
 
 

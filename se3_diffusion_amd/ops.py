@@ -442,9 +442,12 @@ def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, 
             tens.append(t)
     d.rows, d.nres, d.backward, d.eps, d.blocks = int(rows), int(nres), int(bool(backward)), 1e-5, int(blocks or opts.edge_blocks)
     d.ld_pq, d.ld_pqf = int(ld_pq), int(ld_pqf)
+    d.shape = int(opts.edge_shape)
     L = lib()
     stream = L._stream(tens)
-    if opts.edge_dynamic_tiles and rows >= 4 * 64 * (d.blocks or 512):
+    # tiles of the shape the entry point will pick: 128 rows on 256 blocks (8 waves, >= EDGE_MLP_W8_MIN_ROWS rows) or 64 rows on 512
+    w8 = d.shape == 8 or (d.shape == 0 and rows >= hip.EDGE_MLP_W8_MIN_ROWS)
+    if opts.edge_dynamic_tiles and rows >= 4 * (128 if w8 else 64) * (d.blocks or (256 if w8 else 512)):
         d.sched = _edge_sched(out, stream)
     prof = L.gemm_profile
     if prof is not None and L.is_device:

@@ -40,7 +40,8 @@ class Options:
     fused_embed_bwd: bool = True      # FD_EMBED_BWD_FUSED: the edge embedder's dX chain in one launch (fd_edge_embed_bwd)
     grouped_pair_dw: bool = True      # FD_PAIR_DW: the edge transition's pair-row weight gradients in one grouped launch
     pair_dw_blocks: int = 160         # FD_PAIR_DW_BLOCKS: blocks of fd_pair_dw when it runs beside the main stream (0 = 256)
-    edge_blocks: int = 0              # FD_EDGE_BLOCKS: persistent blocks of the fused edge kernels (0 = 512)
+    edge_blocks: int = 0              # FD_EDGE_BLOCKS: persistent blocks of the fused edge kernels (0 = fill the CUs: 512 / 256)
+    edge_shape: int = 0               # FD_EDGE_SHAPE: 0 = by size, 4 = 4-wave blocks (two per CU), 8 = 8-wave blocks (one per CU)
     edge_dynamic_tiles: bool = True   # FD_EDGE_DYN_TILES: a fused edge launch with more tiles than blocks hands them out dynamically
     packed_gates: bool = True         # FD_PACKED_GATES: the fused edge backward gates on packed sign bits instead of reading h1 / h2
     fused_ln_bwd: bool = True         # FD_EDGE_LN_BWD: the edge transition's LayerNorm backward (and the IPA term dz += dzb W40 of
@@ -69,7 +70,7 @@ class Options:
             fused_edge=_flag("FD_EDGE_FUSED", True), fused_embed=_flag("FD_EMBED_FUSED", True),
             fused_embed_bwd=_flag("FD_EMBED_BWD_FUSED", True),
             grouped_pair_dw=_flag("FD_PAIR_DW", True), pair_dw_blocks=_int("FD_PAIR_DW_BLOCKS", 160),
-            edge_blocks=_int("FD_EDGE_BLOCKS", 0), zb_from_edge=_flag("FD_ZB_FUSED", True),
+            edge_blocks=_int("FD_EDGE_BLOCKS", 0), edge_shape=_int("FD_EDGE_SHAPE", 0), zb_from_edge=_flag("FD_ZB_FUSED", True),
             fused_ln_bwd=_flag("FD_EDGE_LN_BWD", True), edge_dynamic_tiles=_flag("FD_EDGE_DYN_TILES", True), packed_gates=_flag("FD_PACKED_GATES", True),
             fold_node_terms=_flag("FD_FOLD_NODE_TERMS", True),
             fused_ipa_attn=_flag("FD_IPA_ATTN_FUSED", True),

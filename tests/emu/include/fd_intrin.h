@@ -145,10 +145,16 @@ static inline void glds16x2(const void* g_lane, void* lds_wave_base) {
   for (int k = 0; k < 2; ++k)
     memcpy(static_cast<char*>(lds_wave_base) + 1024 * k + 16 * hipemu::g_cur->lane, static_cast<const char*>(g_lane) + 1024 * k, 16);
 }
+static inline void glds16x3(const void* g_lane, void* lds_wave_base) {
+  for (int k = 0; k < 3; ++k)
+    memcpy(static_cast<char*>(lds_wave_base) + 1024 * k + 16 * hipemu::g_cur->lane, static_cast<const char*>(g_lane) + 1024 * k, 16);
+}
 static inline void glds16x4(const void* g_lane, void* lds_wave_base) {
   for (int k = 0; k < 4; ++k)
     memcpy(static_cast<char*>(lds_wave_base) + 1024 * k + 16 * hipemu::g_cur->lane, static_cast<const char*>(g_lane) + 1024 * k, 16);
 }
+template <int MASK, int SIZE>
+static inline void sched_group() {}
 static inline void wait_vmem() {}
 static inline void wait_vmem_keep6() {}
 template <int N>

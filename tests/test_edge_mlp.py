@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from se3_diffusion_amd import ops
+from se3_diffusion_amd import ops, options
 
 
 def _case(dev, B, N, seed):
@@ -129,9 +129,39 @@ def _run(dev, B, N, seed=0, blocks=0):
         assert torch.equal(dzg, dzf)
 
 
+def _same_in_both_shapes(dev, B, N, seed, blocks):
+    """the two shapes of the kernel (4 waves x 64-row tiles on two blocks per CU / 8 waves x 128-row tiles on one) run the same
+    arithmetic in the same order per pair row: forward outputs, saves, packed masks and the zb layer bit for bit"""
+    t = _case(dev, B, N, seed)
+    P = B * N * N
+    gz = torch.Generator().manual_seed(seed + 100)
+    W40, b40 = (torch.randn(40, 128, generator=gz) * 0.1).to(dev), torch.randn(40, generator=gz).to(dev)
+    img = ops.edge_mlp_pack(t["W1"], t["W2"], t["Wf"], W40=W40)
+    res = []
+    for shape in (4, 8):
+        e = lambda *s: torch.full(s, float("nan"), device=dev)
+        o = dict(out=e(P, 128), h1=e(P, 384), h2=e(P, 384), y=e(P, 128), mean=e(P), rstd=e(P), zb=e(P, 40),
+                 m1=torch.zeros(P, 12, dtype=torch.int32, device=dev), m2=torch.zeros(P, 12, dtype=torch.int32, device=dev))
+        with options.override(edge_shape=shape):
+            ops.edge_mlp(t["z"], img, o["out"], P, N, p1=t["P1"], q1=t["Q1"], bias2=t["b2"], pf=t["Pf"], qf=t["Qf"],
+                         gamma=t["gamma"], beta=t["beta"], rowscale=t["emask"], save1=o["h1"], save2=o["h2"], y=o["y"],
+                         mean=o["mean"], rstd=o["rstd"], blocks=blocks, zb_out=o["zb"], zb_bias=b40, mask1=o["m1"], mask2=o["m2"])
+        res.append(o)
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+
+
 def test_edge_mlp_emu(use_emu):
     _run("cpu", B=1, N=12)            # 144 rows: one full tile + a ragged one
     _run("cpu", B=1, N=17, seed=4, blocks=1)     # 5 tiles on 1 block (>= 4 per block): the dynamic tile hand-out
+
+
+def test_edge_mlp_w8_emu(use_emu):
+    """the one-block-per-CU shape (csrc/fd_edge_mlp_w8.hip): every check of the default shape, static and dynamic tile order"""
+    with options.override(edge_shape=8):
+        _run("cpu", B=1, N=13)                      # 169 rows: one full 128-row tile + a ragged one
+        _run("cpu", B=1, N=23, seed=5, blocks=1)    # 529 rows: 5 tiles on 1 block: the dynamic hand-out
+    _same_in_both_shapes("cpu", B=1, N=14, seed=6, blocks=0)
 
 
 @pytest.mark.gpu
@@ -140,3 +170,14 @@ def test_edge_mlp_gpu(hip_lib):
     _run("cuda", B=2, N=50, seed=1)
     _run("cuda", B=3, N=128, seed=2)               # 384 tiles: persistent blocks walk several tiles
     _run("cuda", B=1, N=67, seed=3, blocks=5)      # few blocks, many tiles each, ragged tail
+
+
+@pytest.mark.gpu
+def test_edge_mlp_w8_gpu(hip_lib):
+    with options.override(edge_shape=8):
+        _run("cuda", B=1, N=12)
+        _run("cuda", B=2, N=50, seed=1)
+        _run("cuda", B=1, N=67, seed=3, blocks=5)
+    _run("cuda", B=9, N=128, seed=2)               # 147,456 rows: the shape the entry point picks by size (1,152 tiles on 256 blocks)
+    _same_in_both_shapes("cuda", B=3, N=128, seed=7, blocks=0)
+    _same_in_both_shapes("cuda", B=1, N=67, seed=8, blocks=3)

@@ -58,6 +58,7 @@ GROUPS = [
     (dict(zb_from_edge=False), 1e-4),
     (dict(packed_gates=False), 1e-4),
     (dict(edge_dynamic_tiles=False), 1e-4),
+    (dict(edge_shape=8), 1e-4),               # (default at these sizes: the 4-wave shape)
     (dict(fused_ln_bwd=False), 1e-4),
     (dict(fused_ln_bwd=False, packed_gates=False), 1e-4),
     (dict(fused_edge=False, fused_embed=False), 2e-4),
@@ -84,7 +85,7 @@ def test_switches_emu(use_emu):
 
 def test_switches_two_blocks_emu(use_emu):
     # with an edge transition between the blocks: the fused LayerNorm-backward / dzb W40 prologue against the separate kernels
-    _compare("cpu", B=1, N=8, blocks=2, groups=[GROUPS[7], GROUPS[8], GROUPS[9]])
+    _compare("cpu", B=1, N=8, blocks=2, groups=[GROUPS[7], GROUPS[8], GROUPS[9], GROUPS[10]])
 
 
 def _dynamic_vs_static(dev, B, N, blocks):
@@ -128,4 +129,4 @@ def test_options_override_restores():
 @pytest.mark.gpu
 def test_switches_gpu(hip_lib):
     _compare("cuda", B=2, N=24, blocks=2)
-    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:3] + GROUPS[4:11])
+    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:3] + GROUPS[4:12])
