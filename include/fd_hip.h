@@ -176,7 +176,7 @@ typedef struct FdEdgeMlpDesc {
   int shape;                /* 0 = by size (8 from FD_EDGE_MLP_W8_MIN_ROWS rows up), 4 = 4 waves x 64-row tiles on two blocks per CU,
                                8 = 8 waves x 128-row tiles on one block per CU (same results bit for bit) */
 } FdEdgeMlpDesc;
-#define FD_EDGE_MLP_W8_MIN_ROWS 131072L
+#define FD_EDGE_MLP_W8_MIN_ROWS 65536L
 int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream);
 
 /* ---- edge embedder, fused (model/score_network.py:97-101,129-153 Embedder edge path, data/utils.py:570-580) ----

@@ -26,6 +26,18 @@ def _sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def _hip_includes(src):
+    """newest mtime of the .hip files a source includes (fd_edge_mlp_w8.hip instantiates fd_edge_mlp.hip's kernel)"""
+    import re
+    m = 0.0
+    with open(src) as f:
+        for inc in re.findall(r'#include "([^"]+\.hip)"', f.read()):
+            q = os.path.join(os.path.dirname(src), inc)
+            if os.path.exists(q):
+                m = max(m, os.path.getmtime(q))
+    return m
+
+
 def _headers_mtime():
     m = 0.0
     for d in (CSRC, os.path.join(CSRC, "gfx950"), os.path.join(ROOT, "include")):
@@ -44,7 +56,7 @@ def build(verbose=True, force=False):
     for src in _sources():
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hm):
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hm, _hip_includes(src)):
             jobs.append((src, obj))
 
     def cc(job):

@@ -38,7 +38,7 @@
 //                               few tiles per CU (single backbones)
 //   fd_edge_mlp_w8.hip          8 waves x 128-row tiles, ONE block per CU, 48 KB stages (four units), ring of two: half the barriers
 //                               per MFMA and one weight stream per CU instead of two (half the L2 -> LDS traffic): -5 ... -8 % per
-//                               launch from 131,072 pair rows up (profiles/r04_edge_variants_*.log)
+//                               launch from 65,536 pair rows up (profiles/r04_edge_variants_*.log)
 // (that file defines EM_SHAPE_W8 + the shape macros and includes this one; the pack kernels and the C entry points live here only)
 #include "fd_common.h"
 #include "../../include/fd_hip.h"
@@ -436,6 +436,32 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
       acc2[nb][0] = a.x; acc2[nb][1] = a.y; acc2[nb][2] = a.z; acc2[nb][3] = a.w;
     }
 
+    // -DEM_PQ_STEP (measured in round 4, NOT the default): the per-residue terms P1_i / Q1_j of epilogue 1 two 16-blocks (one
+    // k-step of layer 2) at a time -- requested one step ahead into 16 registers, consumed behind a stage boundary whose vmcnt wait
+    // has already retired them -- instead of sixteen loads issued and waited for between layer 1 and layer 2 (6 % of a forward
+    // launch, profiles/r03_edge_phases.txt).  The 16 registers cost 44 - 64 spilled VGPRs and the launch is no faster (B=30 x N=128:
+    // 1.20-1.33 / 1.55-1.61 ms against 1.23 / 1.59; B=8 x N=512 with saves 6.30 against 5.97 ms, profiles/r04_edge_variants_round3_*).
+#ifdef EM_PQ_STEP
+    constexpr bool PQ_STEP = !BWD;
+#else
+    constexpr bool PQ_STEP = false;
+#endif
+    float4 pq[4];        // P (blocks 2 ks, 2 ks + 1), Q (the same blocks)
+    auto pq_load = [&](int cn, int kn) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int col = 128 * cn + 16 * (2 * kn + i) + 4 * g;
+#ifdef EM_ABLATE_PQ
+        pq[i] = make_float4(0.1f, 0.2f, -0.1f, 0.f);
+        pq[2 + i] = make_float4(0.f, 0.1f, 0.f, -0.2f);
+#else
+        pq[i] = *reinterpret_cast<const float4*>(d.p1 + qi * ld_pq + col);
+        pq[2 + i] = *reinterpret_cast<const float4*>(d.q1 + qj * ld_pq + col);
+#endif
+      }
+    };
+    if (PQ_STEP) pq_load(0, 0);
+
     for (int c = 0; c < 3; ++c) {
       // ---- layer 1, chunk c: 128 hidden units x K = 128: units (k-step r >> 1, n-group r & 1) ----
       f32x4 acc1[8];
@@ -460,10 +486,11 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
         }
       }
       // epilogue 1: forward  h1 = relu(acc + P1_i + Q1_j);  backward  d2 = acc gated by h2 > 0
+      // (-DEM_PQ_STEP: the forward's, in four pieces behind the first four stage boundaries of layer 2 instead)
       EM_BODY_TO(2);
       unsigned bits1 = 0u;
 #pragma unroll
-      for (int nb = 0; nb < 8; ++nb) {
+      for (int nb = 0; nb < (PQ_STEP ? 0 : 8); ++nb) {
         const int col = 128 * c + 16 * nb + 4 * g;
         float v[4];
 #pragma unroll
@@ -494,12 +521,36 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
         if (d.save1 != nullptr && rok)
           *reinterpret_cast<float4*>(d.save1 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
       }
-      if (!BWD && MASK && rok) d.mask1[row * 12 + 4 * c + g] = bits1;
+      if (!PQ_STEP && !BWD && MASK && rok) d.mask1[row * 12 + 4 * c + g] = bits1;
       EM_BODY_TO(3);
       // ---- layer 2, k in chunk c: units (k-step u2 / 6, n-group u2 % 6) ----
 #pragma clang loop unroll(full)
       for (int sg = 0; sg < 24 / EM_UPS; ++sg) {
         const char* st = stage_begin();
+        if (PQ_STEP && (EM_UPS * sg) % 4 == 0 && (EM_UPS * sg) / 4 < 4) {
+          // Epilogue 1 of the two 16-blocks that k-step ks = u2 / 4 of layer 2 consumes (k-step ks starts at unit 6 ks >= 4 ks),
+          // HERE: right behind a stage boundary, whose vmcnt wait has already retired the per-residue terms requested one step
+          // ago -- no wait of its own; then the request for the next step's terms (the next chunk's first step after the last).
+          const int ks = (EM_UPS * sg) / 4;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int nb = 2 * ks + i, col = 128 * c + 16 * nb + 4 * g;
+            float v[4];
+            v[0] = acc1[nb][0] + (pq[i].x + pq[2 + i].x); v[1] = acc1[nb][1] + (pq[i].y + pq[2 + i].y);
+            v[2] = acc1[nb][2] + (pq[i].z + pq[2 + i].z); v[3] = acc1[nb][3] + (pq[i].w + pq[2 + i].w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (MASK) bits1 |= (v[e] > 0.f ? 1u : 0u) << (4 * nb + e);
+              v[e] = v[e] > 0.f ? v[e] : 0.f;
+              acc1[nb][e] = v[e];
+            }
+            if (d.save1 != nullptr && rok)
+              *reinterpret_cast<float4*>(d.save1 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+          if (MASK && ks == 3 && rok) d.mask1[row * 12 + 4 * c + g] = bits1;
+          const int cn = ks < 3 ? c : c + 1, kn = ks < 3 ? ks + 1 : 0;
+          if (cn < 3) pq_load(cn, kn);
+        }
         em16_read_half(H[0], st);
 #pragma clang loop unroll(full)
         for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
@@ -822,8 +873,9 @@ extern "C" int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream) {
   FD_CHECK_ARG((d.mask1 == nullptr) == (d.mask2 == nullptr) && (d.gmask1 == nullptr) == (d.gmask2 == nullptr),
                "fd_edge_mlp: mask1 / mask2 (forward) and gmask1 / gmask2 (backward) come in pairs");
   FD_CHECK_ARG(d.shape == 0 || d.shape == 4 || d.shape == 8, "fd_edge_mlp: shape is 0 (by size), 4 or 8 (waves per block)");
-  // shape by size: the one-block-per-CU shape needs >= 4 of its 128-row tiles per CU to amortise its longer tile (measured:
-  // 16,384 rows 0.088 vs 0.063 ms, 458,752 rows 1.21 / 1.42 / 1.33 vs 1.23 / 1.66 / 1.47 ms fwd / fwd + saves / bwd)
+  // shape by size: the one-block-per-CU shape from two of its 128-row tiles per CU up (measured fwd / fwd + saves / bwd: 16,384 rows
+  // 0.088 vs 0.063 ms; 65,536 rows 0.171-0.179 / 0.216-0.240 / 0.196-0.213 vs 0.190-0.193 / 0.225-0.253 / 0.210-0.231 ms; 458,752 rows
+  // 1.21 / 1.42 / 1.33 vs 1.23 / 1.66 / 1.47 ms; profiles/r04_edge_variants_*)
   const int shape = d.shape != 0 ? d.shape : (d.rows >= FD_EDGE_MLP_W8_MIN_ROWS ? 8 : 4);
   hipStream_t st = (hipStream_t)stream;
   return shape == 8 ? fd_edge_mlp_launch_w8(d, st) : fd_edge_mlp_launch_w4(d, st);

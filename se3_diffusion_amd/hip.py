@@ -93,7 +93,7 @@ class FdEdgeMlpDesc(Structure):
     ]
 
 
-EDGE_MLP_W8_MIN_ROWS = 131072
+EDGE_MLP_W8_MIN_ROWS = 65536
 EDGE_MLP_IMAGE_BYTES = 132 * 12288
 
 

@@ -16,6 +16,18 @@ FLAGS = ["-O1", "-g0", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-strict-
          "-Wno-unused-result", "-Wno-attributes", "-Wno-unknown-pragmas"]
 
 
+def _hip_includes(src):
+    """newest mtime of the .hip files a source includes (fd_edge_mlp_w8.hip instantiates fd_edge_mlp.hip's kernel)"""
+    import re
+    m = 0.0
+    with open(src) as f:
+        for inc in re.findall(r'#include "([^"]+\.hip)"', f.read()):
+            q = os.path.join(os.path.dirname(src), inc)
+            if os.path.exists(q):
+                m = max(m, os.path.getmtime(q))
+    return m
+
+
 def build(verbose=True, force=False):
     os.makedirs(OUT, exist_ok=True)
     hm = 0.0
@@ -29,7 +41,7 @@ def build(verbose=True, force=False):
     for s in srcs:
         o = os.path.join(OUT, os.path.basename(s).rsplit(".", 1)[0] + ".o")
         objs.append(o)
-        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hm):
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hm, _hip_includes(s) if s.endswith(".hip") else 0.0):
             jobs.append((s, o))
 
     def cc(job):

@@ -19,13 +19,9 @@ from se3_diffusion_amd import build, hip  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 # tag -> extra flags ("" = the product library itself)
 VARIANTS = {
-    "shipped (4 waves x 2 blocks, ring 2)": None,
-    "w4_il": ["-DEM_INTERLEAVE"],
-    "w8_u4_r2a1": ["-DEM_WAVES=8", "-DEM_UPS=4", "-DEM_RING=2", "-DEM_AHEAD=1"],
-    "w8_u4_r2a1_il": ["-DEM_WAVES=8", "-DEM_UPS=4", "-DEM_RING=2", "-DEM_AHEAD=1", "-DEM_INTERLEAVE"],
-    "w8_u4_r3a2": ["-DEM_WAVES=8", "-DEM_UPS=4", "-DEM_RING=3", "-DEM_AHEAD=2"],
-    "w8_u4_r3a2_il": ["-DEM_WAVES=8", "-DEM_UPS=4", "-DEM_RING=3", "-DEM_AHEAD=2", "-DEM_INTERLEAVE"],
-    "w8_u2_r5a3_il": ["-DEM_WAVES=8", "-DEM_UPS=2", "-DEM_RING=5", "-DEM_AHEAD=3", "-DEM_INTERLEAVE"],
+    "shipped": None,
+    "pq_lump": ["-DEM_PQ_LUMP"],
+    "no_interleave": ["-DEM_NO_INTERLEAVE", "-DEM_PQ_LUMP"],
     "shipped again": [],
 }
 if os.environ.get("EDGE_VARIANTS_EXTRA"):          # "tag:-DX=1,-DY=2;tag2:..."
@@ -40,22 +36,28 @@ def lib_path(tag):
 
 def build_all():
     build.build(verbose=False)
-    src = os.path.join(build.CSRC, "fd_edge_mlp.hip")
-    others = [os.path.join(build.OBJ, f) for f in sorted(os.listdir(build.OBJ)) if f.endswith(".o") and f != "fd_edge_mlp.o"]
+    # both shapes of the kernel (fd_edge_mlp.hip = 4 waves, fd_edge_mlp_w8.hip = 8 waves) are recompiled under the variant's flags
+    names = ("fd_edge_mlp", "fd_edge_mlp_w8")
+    others = [os.path.join(build.OBJ, f) for f in sorted(os.listdir(build.OBJ)) if f.endswith(".o") and f[:-2] not in names]
     for tag, flags in VARIANTS.items():
         if not flags:
             continue
-        obj = os.path.join(HERE, f"fd_edge_mlp_ev_{tag}.o")
-        r = subprocess.run([build.HIPCC, *build.FLAGS, *flags, "-c", src, "-o", obj, "-Rpass-analysis=kernel-resource-usage"],
-                           capture_output=True, text=True)
-        if r.returncode:
-            print(tag, "FAILED to compile:\n", r.stderr[-1500:])
-            continue
-        spills = [l.split("VGPRs Spill:")[1].split()[0] for l in r.stderr.splitlines() if "VGPRs Spill:" in l]
-        lds = [l.split("LDS Size [bytes/block]:")[1].split()[0] for l in r.stderr.splitlines() if "LDS Size" in l]
-        subprocess.check_call([build.HIPCC, f"--offload-arch={build.ARCH}", "-shared", "-fPIC", obj, *others, "-o", lib_path(tag)])
-        os.remove(obj)
-        print(f"{tag}: built; VGPR spills per kernel variant {spills[3:]}, LDS {sorted(set(lds[3:]))}")
+        objs, report = [], []
+        for n in names:
+            obj = os.path.join(HERE, f"{n}_ev_{tag}.o")
+            r = subprocess.run([build.HIPCC, *build.FLAGS, *flags, "-c", os.path.join(build.CSRC, n + ".hip"), "-o", obj,
+                                "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+            if r.returncode:
+                print(tag, n, "FAILED to compile:\n", r.stderr[-1500:])
+                break
+            spills = [l.split("VGPRs Spill:")[1].split()[0] for l in r.stderr.splitlines() if "VGPRs Spill:" in l]
+            report.append(f"{n} spills {spills[-7:]}")
+            objs.append(obj)
+        else:
+            subprocess.check_call([build.HIPCC, f"--offload-arch={build.ARCH}", "-shared", "-fPIC", *objs, *others, "-o", lib_path(tag)])
+            print(f"{tag}: built; " + "; ".join(report))
+        for o in objs:
+            os.remove(o)
 
 
 def main():
@@ -82,6 +84,7 @@ def main():
     dg, db = torch.zeros(128, device=dev), torch.zeros(128, device=dev)
     up = rn(P, 128)
     sched = torch.zeros(4, dtype=torch.int32, device=dev)
+    shape = int(os.environ.get("FD_EDGE_SHAPE", "0"))
 
     def desc(**kw):
         d = hip.FdEdgeMlpDesc()
@@ -89,6 +92,7 @@ def main():
             setattr(d, k, v.data_ptr() if torch.is_tensor(v) else v)
         d.rows, d.nres, d.eps = P, N, 1e-5
         d.sched = sched.data_ptr()
+        d.shape = shape
         return d
 
     cases = {
