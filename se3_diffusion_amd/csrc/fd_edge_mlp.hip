@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256) void edge_mlp_pack_zbw_kernel(const float* __r
 // register layout; the backward image then holds its two x-consuming regions in chained k order (fd_edge_mlp_pack x_chained).
 // ZBW (with LNB): and the upstream gradient first gets the IPA pair-projection term  dz += dzb W40  of the block behind this
 // transition (autograd of linear_b / down_z w.r.t. z, ipa_pytorch.py:380-386,455) as a K = 40 product on four leading units.
-template <bool BWD, bool ZB = false, bool MASK = false, bool LNB = false, bool ZBW = false>
+// SV: save1 and save2 are both given (training) and leave the wave two 16-blocks at a time where the next layer splits them
+template <bool BWD, bool ZB = false, bool MASK = false, bool LNB = false, bool ZBW = false, bool SV = false>
 __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpDesc d) {
   constexpr int EM_NSTAGE = (EM_UNITS + (ZB ? EM_ZB_UNITS : 0) + (ZBW ? EM_ZB_UNITS : 0)) / EM_UPS;
   __shared__ __attribute__((aligned(16))) char lds[EM_RING * EM_STAGE];
@@ -446,6 +447,9 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
 #else
     constexpr bool PQ_STEP = false;
 #endif
+    // SV: the training saves (h1 / h2 forward, d2 / d1 backward) leave the wave two 16-blocks at a time where the next layer splits
+    // them (otherwise, and in rounds 2-3 always: 8 / 24 stores back to back in epilogues 1 / 2 behind run-time null checks)
+    constexpr bool STORE_SPREAD = SV;
     float4 pq[4];        // P (blocks 2 ks, 2 ks + 1), Q (the same blocks)
     auto pq_load = [&](int cn, int kn) __attribute__((always_inline)) {
 #pragma unroll
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc1[nb][e] = v[e];
-        if (d.save1 != nullptr && rok)
+        if (!STORE_SPREAD && d.save1 != nullptr && rok)
           *reinterpret_cast<float4*>(d.save1 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
       }
       if (!PQ_STEP && !BWD && MASK && rok) d.mask1[row * 12 + 4 * c + g] = bits1;
@@ -558,7 +562,17 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
           EM_PIN_TOP();
           if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
           EM_PIN_MID();
-          if (g6 == 0 && (hh & 1) == 0) em16_split2(acc1[2 * ks], acc1[2 * ks + 1], b[0], b[1], b[2]);
+          if (g6 == 0 && (hh & 1) == 0) {
+            em16_split2(acc1[2 * ks], acc1[2 * ks + 1], b[0], b[1], b[2]);
+            if (STORE_SPREAD && !PQ_STEP && rok) {
+              // the save of h1 / d2: the two 16-blocks this k-step consumes, HERE (two stores per six units of MFMAs) instead
+              // of eight back to back in the epilogue
+#pragma unroll
+              for (int i = 0; i < 2; ++i)
+                *reinterpret_cast<float4*>(d.save1 + row * EM_H + 128 * c + 16 * (2 * ks + i) + 4 * g) =
+                    make_float4(acc1[2 * ks + i][0], acc1[2 * ks + i][1], acc1[2 * ks + i][2], acc1[2 * ks + i][3]);
+            }
+          }
           em16_mma_half(acc2[a], acc2[a + 1], H[hh & 1], b);
           EM_GROUPS(hh + 1 < 2 * EM_UPS);
           if (hh == 1) stage_prefetch();
@@ -591,7 +605,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc2[nb][e] = v[e];
-      if (d.save2 != nullptr && rok)
+      if (!STORE_SPREAD && d.save2 != nullptr && rok)
         *reinterpret_cast<float4*>(d.save2 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
       if (!BWD && MASK && (nb & 7) == 7) {
         if (rok) d.mask2[row * 12 + 4 * (nb >> 3) + g] = bits2;
@@ -632,7 +646,15 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
         EM_PIN_TOP();
         if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
         EM_PIN_MID();
-        if (g2 == 0 && (hh & 1) == 0) em16_split2(acc2[2 * ks], acc2[2 * ks + 1], b[0], b[1], b[2]);
+        if (g2 == 0 && (hh & 1) == 0) {
+          em16_split2(acc2[2 * ks], acc2[2 * ks + 1], b[0], b[1], b[2]);
+          if (STORE_SPREAD && rok) {      // the save of h2 / d1, two blocks per k-step of layer 3
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              *reinterpret_cast<float4*>(d.save2 + row * EM_H + 16 * (2 * ks + i) + 4 * g) =
+                  make_float4(acc2[2 * ks + i][0], acc2[2 * ks + i][1], acc2[2 * ks + i][2], acc2[2 * ks + i][3]);
+          }
+        }
         em16_mma_half(acc3[a], acc3[a + 1], H[hh & 1], b);
         EM_GROUPS(hh + 1 < 2 * EM_UPS);
         if (hh == 1) stage_prefetch();
@@ -791,20 +813,28 @@ int EM_LAUNCH(const FdEdgeMlpDesc& d, hipStream_t st) {
     dd.sched = nullptr;
   }
   const bool zbv = d.zb_out != nullptr, mk = d.mask1 != nullptr;
-  if (d.backward && d.ln_y != nullptr && d.dzb != nullptr)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false, true, true>), g3, b3, 0, st, dd);
-  else if (d.backward && d.ln_y != nullptr)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false, true, false>), g3, b3, 0, st, dd);
-  else if (d.backward)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<true, false, false>), g3, b3, 0, st, dd);
-  else if (zbv && mk)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true, true>), g3, b3, 0, st, dd);
-  else if (zbv)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, true, false>), g3, b3, 0, st, dd);
-  else if (mk)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, false, true>), g3, b3, 0, st, dd);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<false, false, false>), g3, b3, 0, st, dd);
+#ifdef EM_STORE_LUMP
+  const bool sv = false;
+#else
+  const bool sv = d.save1 != nullptr && d.save2 != nullptr;
+#endif
+#define EM_GO(...) hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<__VA_ARGS__>), g3, b3, 0, st, dd)
+  if (d.backward && d.ln_y != nullptr && d.dzb != nullptr) {
+    if (sv) EM_GO(true, false, false, true, true, true); else EM_GO(true, false, false, true, true, false);
+  } else if (d.backward && d.ln_y != nullptr) {
+    if (sv) EM_GO(true, false, false, true, false, true); else EM_GO(true, false, false, true, false, false);
+  } else if (d.backward) {
+    if (sv) EM_GO(true, false, false, false, false, true); else EM_GO(true, false, false, false, false, false);
+  } else if (zbv && mk) {
+    if (sv) EM_GO(false, true, true, false, false, true); else EM_GO(false, true, true, false, false, false);
+  } else if (zbv) {
+    EM_GO(false, true, false);
+  } else if (mk) {
+    if (sv) EM_GO(false, false, true, false, false, true); else EM_GO(false, false, true, false, false, false);
+  } else {
+    EM_GO(false, false, false);
+  }
+#undef EM_GO
   FD_CHECK_LAUNCH("fd_edge_mlp");
   return FD_OK;
 }

@@ -20,9 +20,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # tag -> extra flags ("" = the product library itself)
 VARIANTS = {
     "shipped": None,
-    "pq_lump": ["-DEM_PQ_LUMP"],
-    "no_interleave": ["-DEM_NO_INTERLEAVE", "-DEM_PQ_LUMP"],
+    "store_lump": ["-DEM_STORE_LUMP"],
     "shipped again": [],
+    "store_lump again": ["-DEM_STORE_LUMP"],
 }
 if os.environ.get("EDGE_VARIANTS_EXTRA"):          # "tag:-DX=1,-DY=2;tag2:..."
     for item in os.environ["EDGE_VARIANTS_EXTRA"].split(";"):
