@@ -582,11 +582,22 @@ def main():
         for i in range(a.warmup, a.warmup + a.steps):
             step(i)
     barrier()
+    # the interpreter's cyclic garbage collector stays out of the timed region (as timeit does): the host runs ~13 ms per step
+    # ahead of the GPU, and a full collection over the step's tensor graph in the middle of the K steps can eat that lead.  One HIP
+    # event per step (recorded behind the optimiser launch, read after the region) gives the per-step spread as a diagnostic.
+    import gc
+    gc.collect()
+    gc.disable()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    marks[0].record()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     if os.environ.get("FD_BENCH_ENQUEUE"):
         # host-side cost of a step: time inside step() with the GPU running asynchronously behind it.  If it is close to
         # ms_per_step the launch stream, not the GPU, bounds the step.
@@ -677,6 +688,9 @@ def main():
                    "ranks": world, "collective_backend": (torch.distributed.get_backend() if world > 1 else None),
                    "rccl_ranks": world if (world > 1 and torch.distributed.get_backend() == "nccl") else 0,
                    "ms_per_step_by_rank": per_rank_ms,
+                   "step_ms_spread": {"min": round(per_step[0], 3), "median": round(per_step[len(per_step) // 2], 3),
+                                      "max": round(per_step[-1], 3),
+                                      "note": "HIP events between consecutive optimiser launches of the timed steps (rank 0)"},
                    "scaling_curve": "not measured by this line (one N per invocation; the driver composes 1/2/4/8)",
                    "ms_per_step_exact_f32_gemms": None if exact_ms is None else round(exact_ms, 3),
                    "self_conditioning_50pct": None if sc_ms is None else {
