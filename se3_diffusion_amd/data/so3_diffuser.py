@@ -47,6 +47,31 @@ def _series(omega, eps, L=1000):
     return f, df
 
 
+def _series_torch(omega, eps, L=1000):
+    """(f, f') as _series, in torch float64 and differentiable w.r.t. omega (host tensors: the reference's torch_score is
+    differentiable on the CPU too, data/so3_diffuser.py:274-305).  The sines / cosines of (l + 1/2) omega come from the same
+    rotation recurrence; every step is an out-of-place torch op, so autograd sees the whole series."""
+    omega = omega.to(torch.float64)
+    eps = torch.as_tensor(eps, dtype=torch.float64)
+    omega, eps = torch.broadcast_tensors(omega, eps)
+    lo, dlo = torch.sin(omega / 2), 0.5 * torch.cos(omega / 2)
+    so, co = torch.sin(omega), torch.cos(omega)
+    s, c = lo, 2 * dlo
+    q = torch.exp(-eps ** 2)
+    w, r = torch.ones_like(q), q
+    f, df = torch.zeros_like(q), torch.zeros_like(q)
+    for l in range(L):
+        cw = (2 * l + 1) * w
+        f = f + cw * s / lo
+        df = df + cw * (lo * (l + 0.5) * c - s * dlo) / lo ** 2
+        w = w * r
+        r = r * q
+        if not bool(torch.any(w)):
+            break
+        s, c = s * co + c * so, c * co - s * so
+    return f, df
+
+
 def igso3_expansion(omega, eps, L=1000, use_torch=False):
     """Truncated IGSO(3) power series (eps = sqrt(2) * eps_leach); omega 1-D or 2-D."""
     if use_torch:
@@ -196,12 +221,26 @@ class SO3Diffuser:
         return scal[..., None] * vec / (omega[..., None] + eps)
 
     def torch_score(self, vec: torch.Tensor, t: torch.Tensor, eps: float = 1e-6):
-        """[B, N, 3] rotation vectors, t [B] -> float64 score.  GPU tensors: fp64 HIP series, differentiable."""
+        """[B, N, 3] rotation vectors, t [B] -> float64 score.  GPU tensors: fp64 HIP series, differentiable; host tensors:
+        numpy series, or torch float64 (differentiable) when `vec` requires a gradient."""
         if vec.is_cuda:
             from .. import score_ops
             return score_ops.rotvec_score(vec, t, self)
         if vec.requires_grad:
-            raise NotImplementedError("differentiable torch_score runs on the GPU (fd_heads kernels)")
+            # host tensors that carry a gradient: the same arithmetic in torch float64 (autograd through the series; with
+            # use_cached_score the tabulated magnitude is piecewise constant in omega, as in the reference's bucketize + gather)
+            tt = np.atleast_1d(du.move_to_np(t)).astype(np.float64)
+            omega = torch.linalg.norm(vec.to(torch.float64), dim=-1) + eps
+            sg = torch.as_tensor(self.discrete_sigma[self.t_to_idx(tt)], dtype=torch.float64)
+            sg = sg.reshape(sg.shape + (1,) * (omega.dim() - 1))
+            if self.use_cached_score:
+                rows = torch.as_tensor(self._score_norms[self.t_to_idx(tt)], dtype=torch.float64)
+                idx = torch.bucketize(omega.detach(), torch.as_tensor(self.discrete_omega[:-1], dtype=torch.float64))
+                scal = torch.gather(rows, 1, idx.reshape(rows.shape[0], -1)).reshape(omega.shape)
+            else:
+                f, df = _series_torch(omega, sg)
+                scal = df / (f + 1e-4)
+            return scal[..., None] * vec.to(torch.float64) / (omega[..., None] + eps)
         tt = np.atleast_1d(du.move_to_np(t)).astype(np.float64)
         v = du.move_to_np(vec)
         omega = np.linalg.norm(v, axis=-1) + eps

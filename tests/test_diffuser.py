@@ -58,6 +58,27 @@ def test_schedules_and_tables(diff):
         r3.b_t(np.array(-0.1))
 
 
+def test_torch_score_host_differentiable(diff):
+    """SO3Diffuser.torch_score on host tensors that require a gradient (reference data/so3_diffuser.py:274-305 is differentiable
+    on the CPU): value == the numpy path, gradient == central differences of the numpy path (float64)"""
+    so3 = diff._so3_diffuser
+    g = torch.Generator().manual_seed(5)
+    v = (torch.randn(2, 6, 3, generator=g, dtype=torch.float64) * 0.6).requires_grad_(True)
+    t = torch.tensor([0.3, 0.8])
+    sc = so3.torch_score(v, t)
+    ref = so3.torch_score(v.detach(), t)
+    assert sc.dtype == torch.float64 and float((sc.detach() - ref).abs().max()) < 1e-10 * float(ref.abs().max())
+    w = torch.randn(2, 6, 3, generator=g, dtype=torch.float64)
+    (sc * w).sum().backward()
+    h = 1e-6
+    for (b, n, k) in ((0, 0, 0), (1, 3, 2), (0, 5, 1)):
+        vp, vm = v.detach().clone(), v.detach().clone()
+        vp[b, n, k] += h
+        vm[b, n, k] -= h
+        fd_ = float(((so3.torch_score(vp, t) - so3.torch_score(vm, t)) * w).sum()) / (2 * h)
+        assert abs(float(v.grad[b, n, k]) - fd_) < 1e-5 * (abs(fd_) + 1.0), (b, n, k, float(v.grad[b, n, k]), fd_)
+
+
 def test_torch_score_host(diff):
     so3 = diff._so3_diffuser
     sc = so3.torch_score(torch.tensor(G["ts_vec"]), torch.tensor(G["ts"], dtype=torch.float32)).numpy()
