@@ -136,12 +136,18 @@ def cpu_baseline(n_res, blocks, sample_b, budget_s=40.0, reps=3, force_kind=None
         tried.append((th, round(med, 2), len(dts)))
         if best is None or med < best[1]:
             best = (th, med)
-        if time.time() - t_start + med > budget_s:
+        # the sweep ends when the budget is spent or when more threads are clearly slower: past the peak every doubling is slower
+        # still, and ALL logical CPUs cost minutes per step on the 256-CPU GPU box (measured once per round and written down
+        # instead of re-measured by every default run: 230 s per step in round 3, 228.7 s in round 4, profiles/r04_bench_train.json)
+        if time.time() - t_start + med > budget_s or med > 1.5 * best[1]:
             break
     th, dt = best
     skipped = [t for t in sweep if t not in [x[0] for x in tried]]
     return dict(value=round(sample_b * n_res / dt, 2), unit="residues/s", cores=th, kind=kind,
                 logical_cpus=ncpu, thread_settings_not_reached=skipped,
+                all_logical_cpus_note="every logical CPU of the 2 x EPYC 9575F box (256 threads) measured 228.7 s per step in round 4 "
+                                      "(profiles/r04_bench_train.json) against 1.5 s at 16 threads: the sweep stops once more threads "
+                                      "are > 1.5 x slower than the best",
                 port_vs_reference=_port_vs_reference(),
                 sample=f"fwd + DSM loss + bwd, B={sample_b} x N={n_res}, {blocks} blocks, "
                        f"{'unmodified reference' if kind == 'reference' else 'torch-CPU fp32 oracle (port)'}; best median over threads "
