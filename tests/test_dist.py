@@ -319,3 +319,62 @@ def test_score_network_data_parallel_gpu(hip_lib, overlap):
         if err > 1e-4 * float(g.abs().max()) + 1e-6:             # fp32 round-off of two summation orders (split-K atomics)
             bad.append((n, err, float(g.abs().max())))
     assert not bad, bad[:8]
+
+
+_RCCL_ONE_RANK = r'''
+import json, os, sys, time
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)          # "nccl" IS RCCL on ROCm
+from se3_diffusion_amd import ops, train_step as ts
+from se3_diffusion_amd.model.score_network import ScoreNetwork
+from se3_diffusion_amd.optim import FlatAdam
+model = ScoreNetwork(ts.base_model_conf(1), diffuser=None).cuda()
+opt = FlatAdam(model.parameters(), lr=1e-4, adjacent=model.flat_layout_groups())
+g = torch.Generator(device="cuda").manual_seed(0)
+opt.flat_g.normal_(generator=g)
+ref = opt.flat_g.clone()
+# the step's collective: ONE all-reduce over the flat fp32 gradient buffer (the full-depth model's is 69.8 MB), in place
+full = torch.randn(17_446_190, device="cuda", generator=g)
+full_ref = full.clone()
+dist.all_reduce(full, op=dist.ReduceOp.SUM)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(5):
+    dist.all_reduce(full, op=dist.ReduceOp.SUM)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / 5 * 1e3
+# the overlapped form's device branch: async all-reduce of a SLICE issued from the gradient side stream
+st = torch.cuda.Stream()
+st.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(st):
+    h = dist.all_reduce(opt.flat_g[1000:500000], op=dist.ReduceOp.SUM, async_op=True)
+h.wait()
+torch.cuda.current_stream().wait_stream(st)
+for t in list(model.parameters())[:8]:
+    dist.broadcast(t.data, src=0)
+dist.barrier()
+torch.cuda.synchronize()
+ok = bool(torch.equal(opt.flat_g, ref) and torch.equal(full, full_ref))
+print(json.dumps({"ok": ok, "backend": dist.get_backend(), "allreduce_70MB_ms": round(ms, 3),
+                  "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())}))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_gpu(hip_lib):
+    """RCCL itself (not gloo) under the step's collectives, as far as one GPU goes: a 1-rank `nccl` process group runs the flat
+    69.8 MB gradient all-reduce in place, an asynchronous all-reduce of a slice issued from a side stream (the overlapped
+    form's device branch), the parameter broadcast and a barrier; values must come back unchanged.  (RCCL refuses two ranks on
+    one device, so the 2-rank tests above use gloo; the N-GPU run is the driver's.)"""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, ROOT, str(_free_port())], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print("[rccl one rank]", d)
+    assert d["ok"] and d["backend"] == "nccl"
