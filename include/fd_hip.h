@@ -381,6 +381,20 @@ int fd_ipa_attn_bwd(const float* A, float* dA, const float* zb, const float* dfe
                     const float* kp_soa, const float* head_w, float* dzb, float* dqp, float* dkp, float* dhead_w,
                     float* hw_part, int B, int N, void* stream);
 
+/* IPA attention of a block of the trunk in ONE launch (model/ipa_pytorch.py:380-457: logits :380-417, softmax :422,
+ * o :424-428, o_pt + norm :432-449, o_pair :455-457) -- replaces  fd_gemm (q k^T) -> fd_ipa_attn_fwd -> fd_gemm (a v) ->
+ * fd_gemm (a v_pts) -> fd_ipa_opt_fwd.  A block owns 16 query rows and heads_per_block heads (one wave each); keys walk in
+ * tiles of 16 with a running maximum / denominator; the zb rows of the tile stream through LDS by LDS-DMA; q k^T, a v, a v_pts
+ * and o_pair ride the exact-fp32 MFMA; the logits / probabilities never reach HBM.
+ *   proj [R, 6816] (fd_ipa_points_fwd's input: q | kv | raw points), zb [B N N, 40], qp / kp [R, 8, 24] and vp [R, 8, 36]
+ *   (global-frame points from fd_ipa_points_fwd), head_w [8], mask [R], quat [R, 4], trans [R, 3] ->
+ *   feats [R, 2688] = [o 2048 | o_pt x,y,z 288 | |o_pt| 96 | o_pair 256]  (every column written).
+ * A (may be null): [B, 8, N, N] receives the probabilities (training: the backward kernels read them).
+ * heads_per_block: 8, 4, 2, or 0 = chosen from the number of query tiles.  All tensor arguments 16-byte aligned. */
+int fd_ipa_flash_fwd(const float* proj, const float* zb, const float* qp, const float* kp, const float* vp,
+                     const float* head_w, const float* mask, const float* quat, const float* trans, float* feats,
+                     float* A, int B, int N, int heads_per_block, void* stream);
+
 /* dz[p, 0:128] (+)= dzb[p, 0:40] W40[0:40, 0:128] over the pair rows (autograd of linear_b / down_z w.r.t. z,
  * ipa_pytorch.py:380-386,455-457): streaming kernel, W40 resident in registers */
 int fd_ipa_dz_acc(const float* dzb, const float* W40, float* dz, long rows, int accumulate, void* stream);

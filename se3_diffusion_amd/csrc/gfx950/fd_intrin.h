@@ -68,6 +68,23 @@ __device__ __forceinline__ void sched_fence() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)p;
 }
+// ONE LDS-DMA piece (16 bytes per lane, lane-private source address, wave-uniform destination + 16 lane) as inline asm:
+// like glds16x4 the compiler does not see the copy (no vmcnt(0) in front of the next ds_read, nothing at __syncthreads());
+// the caller waits with wait_vmem() before the barrier that publishes it.  The vmcnt counter retires in issue order, so
+// the compiler's own waits for loads issued AFTER this copy also cover it -- stricter than needed, never too weak.
+__device__ __forceinline__ void glds16a(const void* g_lane, void* lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(lds_wave_base));
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g_lane), "s"(dst)
+      : "memory");
+}
 __device__ __forceinline__ void glds16x4(const void* g_lane, void* lds_wave_base) {
   unsigned keep;
   const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(lds_wave_base));
@@ -141,6 +158,10 @@ __device__ __forceinline__ void sched_pin() { __builtin_amdgcn_sched_barrier(0);
 // (0x008 MFMA, 0x100 LDS read, 0x002 VALU, 0x020 VMEM read) in program order of the groups declared in this scheduling region
 template <int MASK, int SIZE>
 __device__ __forceinline__ void sched_group() { __builtin_amdgcn_sched_group_barrier(MASK, SIZE, 0); }
+
+// a value the caller knows to be the same in every lane of the wave, as a scalar (v_readfirstlane): what is derived from it
+// (per-head pointers, loop bounds) stays in SGPRs
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }

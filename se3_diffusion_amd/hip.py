@@ -198,6 +198,7 @@ _SIGS = {
     "fd_ipa_points_bwd": "pppppppliiiis",
     "fd_ipa_softmax_fwd": "ppppppiis",
     "fd_ipa_attn_fwd": "ppppppppiis",
+    "fd_ipa_flash_fwd": "ppppppppppp" + "iiis",
     "fd_seq_attn_fwd": "ppppfiis",
     "fd_ipa_attn_bwd": "pppppppppppppiis",
     "fd_ipa_softmax_bwd": "ppppppppppiis",

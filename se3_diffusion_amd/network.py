@@ -274,7 +274,7 @@ def ipa_w40(P, pre, cache=None):
     return W40, b40
 
 
-def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None, out_view=None):
+def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None, out_view=None, save=True):
     """x1 = s + mask * IPA(s, z, T).  s: matrix view [R,256].  zb: [P,40] = W40 z + b40 when the kernel that produced z
     already formed it (the previous block's fused edge transition)."""
     dev = z
@@ -298,32 +298,42 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None, out_view
         ops.linear(s, mv(P[f"{pre}.linear_q_points.weight"]), P[f"{pre}.linear_q_points.bias"], (proj, 6144, LDP), R, 192, CS)
         ops.linear(s, mv(P[f"{pre}.linear_kv_points.weight"]), P[f"{pre}.linear_kv_points.bias"], (proj, 6336, LDP), R, 480, CS)
     qp = empty((R, H, PQ * 3), dev); kp = empty((R, H, PQ * 3), dev); vp = empty((R, H, PV * 3), dev)
-    # (the copy serves fd_ipa_attn_fwd/bwd only: the unfused softmax kernels and the fused pair pass read kp)
-    kpT = empty((B, H, PQ * 3, N), dev) if opts.fused_ipa_attn else None
+    train = bool(save)             # a backward pass will read the probabilities A (and the [B, 8, 24, N] key-point copy)
+    flash = (opts.flash_ipa and B * ((N + 15) // 16) >= opts.flash_ipa_min_tiles and N <= 1024
+             and (lib().is_device or opts.flash_ipa_min_tiles <= 0))
+    # (the copy serves fd_ipa_attn_fwd/bwd only: the unfused softmax kernels, the fused pair pass and the flash kernel read kp)
+    kpT = empty((B, H, PQ * 3, N), dev) if opts.fused_ipa_attn and (train or not flash) else None
     lib().call("fd_ipa_points_fwd", proj, quat, trans, qp, kp, vp, kpT, N, R, H, C, PQ, PV)
     W40, b40 = ipa_w40(P, pre, cache)
-    A = empty((B, H, N, N), dev)
     L = lib()
-    L.gemm(proj, proj, A, N, N, C, (LDP, 1), (1, LDP), N, b_off=2048, batch=B * H, bdiv=H,
-           a_bs=(N * LDP, C), b_bs=(N * LDP, 2 * C), c_bs=(H * N * N, N * N), alpha=math.sqrt(1.0 / (3 * C)))
     feats = empty((R, LDF), dev)
     if zb is None:
         zb = empty((Pn, ZB), dev)
         ops.linear(mv(z), mv(W40), b40, mv(zb), Pn, ZB, CZ)
     fused_attn = opts.fused_ipa_attn
-    if fused_attn:
-        # logits + softmax (A in place) + o_pair (the pair part of feats) of every query row in one launch
-        L.call("fd_ipa_attn_fwd", A, zb, qp, kp, kpT, P[f"{pre}.head_weights"], mask, feats, B, N)
+    if flash:
+        # one launch: q k^T, logits, softmax, a v, a v_pts, o_pt (+ norm), o_pair; the probabilities are written out only for
+        # the backward pass (training)
+        A = empty((B, H, N, N), dev) if train else None
+        L.call("fd_ipa_flash_fwd", proj, zb, qp, kp, vp, P[f"{pre}.head_weights"], mask, quat, trans, feats, A, B, N,
+               opts.flash_ipa_hpb)
     else:
-        L.call("fd_ipa_softmax_fwd", A, zb, qp, kp, P[f"{pre}.head_weights"], mask, B, N)
-    L.gemm(A, proj, feats, N, C, N, (N, 1), (LDP, 1), LDF, b_off=2048 + C, batch=B * H, bdiv=H,
-           a_bs=(H * N * N, N * N), b_bs=(N * LDP, 2 * C), c_bs=(N * LDF, C))
-    optg = empty((R, H, PV * 3), dev)
-    L.gemm(A, vp, optg, N, PV * 3, N, (N, 1), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
-           a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
-    L.call("fd_ipa_opt_fwd", optg, quat, trans, feats, R)
-    if not fused_attn:
-        L.call("fd_ipa_opair_fwd", A, zb, feats, B, N)
+        A = empty((B, H, N, N), dev)
+        L.gemm(proj, proj, A, N, N, C, (LDP, 1), (1, LDP), N, b_off=2048, batch=B * H, bdiv=H,
+               a_bs=(N * LDP, C), b_bs=(N * LDP, 2 * C), c_bs=(H * N * N, N * N), alpha=math.sqrt(1.0 / (3 * C)))
+        if fused_attn:
+            # logits + softmax (A in place) + o_pair (the pair part of feats) of every query row in one launch
+            L.call("fd_ipa_attn_fwd", A, zb, qp, kp, kpT, P[f"{pre}.head_weights"], mask, feats, B, N)
+        else:
+            L.call("fd_ipa_softmax_fwd", A, zb, qp, kp, P[f"{pre}.head_weights"], mask, B, N)
+        L.gemm(A, proj, feats, N, C, N, (N, 1), (LDP, 1), LDF, b_off=2048 + C, batch=B * H, bdiv=H,
+               a_bs=(H * N * N, N * N), b_bs=(N * LDP, 2 * C), c_bs=(N * LDF, C))
+        optg = empty((R, H, PV * 3), dev)
+        L.gemm(A, vp, optg, N, PV * 3, N, (N, 1), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
+               a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
+        L.call("fd_ipa_opt_fwd", optg, quat, trans, feats, R)
+        if not fused_attn:
+            L.call("fd_ipa_opair_fwd", A, zb, feats, B, N)
     # out_view (a matrix view, sampling): x1 goes straight into the [R, 320] buffer whose columns 256.. take skip_embed -- the
     # operand of the first transformer layer's in_proj, which then normalises the first 256 columns itself (trunk.forward)
     x1 = empty((R, CS), dev) if out_view is None else out_view[0]

@@ -50,6 +50,11 @@ class Options:
     fold_node_terms: bool = True      # FD_FOLD_NODE_TERMS: sampling -- per-residue terms of an edge transition as one GEMM
     # -- IPA
     fused_ipa_attn: bool = True       # FD_IPA_ATTN_FUSED: logits + softmax + o_pair of a query row in one launch
+    flash_ipa: bool = True            # FD_IPA_FLASH: q k^T, logits, softmax, a v, a v_pts, o_pt and o_pair of a block in ONE launch
+                                      # (fd_ipa_flash_fwd: the probabilities never reach HBM in inference) ...
+    flash_ipa_min_tiles: int = 96     # FD_IPA_FLASH_MIN_TILES: ... from this many 16-row query tiles (B * ceil(N / 16)) up: a lone
+                                      # backbone has too few tiles to fill the CUs and keeps the launch sequence
+    flash_ipa_hpb: int = 0            # FD_IPA_FLASH_HPB: heads per block of that kernel (0 = by size, 8 / 4 / 2)
     proj_merge: bool = True           # FD_PROJ_MERGE: IPA's four projections of s as one GEMM over back-to-back weights
     # -- node level
     fused_seq_attn: bool = True       # FD_SEQ_ATTN_FUSED: sequence-transformer attention in one launch ...
@@ -74,6 +79,8 @@ class Options:
             fused_ln_bwd=_flag("FD_EDGE_LN_BWD", True), edge_dynamic_tiles=_flag("FD_EDGE_DYN_TILES", True), packed_gates=_flag("FD_PACKED_GATES", True),
             fold_node_terms=_flag("FD_FOLD_NODE_TERMS", True),
             fused_ipa_attn=_flag("FD_IPA_ATTN_FUSED", True),
+            flash_ipa=_flag("FD_IPA_FLASH", True), flash_ipa_min_tiles=_int("FD_IPA_FLASH_MIN_TILES", 96),
+            flash_ipa_hpb=_int("FD_IPA_FLASH_HPB", 0),
             proj_merge=_flag("FD_PROJ_MERGE", True),
             fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),
             grouped_node_dw=_flag("FD_NODE_DW", True), node_dw_blocks=_int("FD_NODE_DW_BLOCKS", 0),

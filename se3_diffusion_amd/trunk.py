@@ -482,7 +482,7 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
         cat = empty((R, TD), dev) if fold1 else None
         with rng(f"ipa_{b}.fwd"):
             x1, sv_ipa = nw.ipa_fwd(P, pre, mv(node), z, quat, trans, mask.view(-1), B, N, cache, zb=zb,
-                                    out_view=(cat, 0, TD) if fold1 else None)
+                                    out_view=(cat, 0, TD) if fold1 else None, save=save)
         with rng(f"seq_tfmr_{b}.fwd"):
             pend_ln = None      # a LayerNorm whose launch is folded into its consumer's (nw.tfmr_layer_fwd)
             if fold1:

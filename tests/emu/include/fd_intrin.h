@@ -141,6 +141,9 @@ static inline uint2 lds_read_tr16(const void* p) {
   return out;
 }
 
+static inline void glds16a(const void* g_lane, void* lds_wave_base) {
+  memcpy(static_cast<char*>(lds_wave_base) + 16 * hipemu::g_cur->lane, g_lane, 16);
+}
 static inline void glds16x2(const void* g_lane, void* lds_wave_base) {
   for (int k = 0; k < 2; ++k)
     memcpy(static_cast<char*>(lds_wave_base) + 1024 * k + 16 * hipemu::g_cur->lane, static_cast<const char*>(g_lane) + 1024 * k, 16);
@@ -168,6 +171,7 @@ static inline void sched_fence() {}
 static inline void sched_pin() {}
 
 
+static inline int uniform(int v) { return v; }
 static inline int lane_id() { return hipemu::g_cur->lane; }
 static inline int wave_id() { return hipemu::g_cur->wave; }
 

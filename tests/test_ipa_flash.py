@@ -1,0 +1,152 @@
+"""fd_ipa_flash_fwd -- IPA attention of a trunk block in one launch (model/ipa_pytorch.py:380-457: logits, softmax, o, o_pt,
+|o_pt|, o_pair) -- against (1) the launch sequence it replaces (q k^T GEMM -> fd_ipa_attn_fwd -> a v / a v_pts GEMMs ->
+fd_ipa_opt_fwd, themselves oracle-tested) and (2) a float64 restatement of the reference's arithmetic on the same inputs.
+Tolerances are relative to each output group's maximum and <= 10 x what the kernel achieves (recorded by parity_log)."""
+import math
+
+import pytest
+import torch
+
+import parity_log
+from se3_diffusion_amd import ops
+
+H, C, PQ, PV, ZB, CZ4 = 8, 256, 8, 12, 40, 32
+LDP, LDF = 6816, 2688
+F_PT, F_NORM, F_PAIR = 2048, 2336, 2432
+
+
+def _inputs(dev, B, N, seed, spread=1.0, masked=True):
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    R = B * N
+    proj = rn(R, LDP)
+    quat = rn(R, 4)
+    quat = quat / quat.norm(dim=-1, keepdim=True)
+    # translations in the diffuser's units (0.1 A): N(0, 1) per axis at t = 1 for every N; a folded 512-residue chain has a
+    # radius of gyration of ~2.4 (1.4 per axis).  Drawn independently per residue here -- no chain locality, which is the worst
+    # case for the tile-centred point term of the kernel (neighbours in sequence are not neighbours in space)
+    trans = rn(R, 3, sc=spread)
+    zb = rn(R * N, ZB)
+    hw = rn(H)
+    mask = ((torch.rand(R, generator=g) > 0.1).float() if masked else torch.ones(R)).to(dev)
+    return proj, quat, trans, zb, hw, mask
+
+
+def _points(L, proj, quat, trans, B, N):
+    R = B * N
+    qp = torch.empty(R, H, PQ * 3, device=proj.device); kp = torch.empty_like(qp)
+    vp = torch.empty(R, H, PV * 3, device=proj.device)
+    kpT = torch.empty(B, H, PQ * 3, N, device=proj.device)
+    L.call("fd_ipa_points_fwd", proj, quat, trans, qp, kp, vp, kpT, N, R, H, C, PQ, PV)
+    return qp, kp, vp, kpT
+
+
+def _sequence(L, proj, quat, trans, zb, hw, mask, qp, kp, vp, kpT, B, N):
+    """network.ipa_fwd's launches (the path the flash kernel replaces)."""
+    R = B * N
+    dev = proj.device
+    A = torch.empty(B, H, N, N, device=dev)
+    L.gemm(proj, proj, A, N, N, C, (LDP, 1), (1, LDP), N, b_off=2048, batch=B * H, bdiv=H,
+           a_bs=(N * LDP, C), b_bs=(N * LDP, 2 * C), c_bs=(H * N * N, N * N), alpha=math.sqrt(1.0 / (3 * C)))
+    feats = torch.zeros(R, LDF, device=dev)
+    L.call("fd_ipa_attn_fwd", A, zb, qp, kp, kpT, hw, mask, feats, B, N)
+    L.gemm(A, proj, feats, N, C, N, (N, 1), (LDP, 1), LDF, b_off=2048 + C, batch=B * H, bdiv=H,
+           a_bs=(H * N * N, N * N), b_bs=(N * LDP, 2 * C), c_bs=(N * LDF, C))
+    optg = torch.empty(R, H, PV * 3, device=dev)
+    L.gemm(A, vp, optg, N, PV * 3, N, (N, 1), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
+           a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
+    L.call("fd_ipa_opt_fwd", optg, quat, trans, feats, R)
+    return feats, A
+
+
+def _quat_to_rot(q):
+    a, b, c, d = q.unbind(-1)
+    return torch.stack([a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c),
+                        2 * (b * c + a * d), a * a - b * b + c * c - d * d, 2 * (c * d - a * b),
+                        2 * (b * d - a * c), 2 * (c * d + a * b), a * a - b * b - c * c + d * d], -1).view(*q.shape[:-1], 3, 3)
+
+
+def _float64(proj, quat, trans, zb, hw, mask, B, N):
+    """ipa_pytorch.py:351-457 in float64 on the raw projections (points rotated here, not taken from the kernel)."""
+    P = proj.double().cpu().view(B, N, LDP)
+    Rm = _quat_to_rot(quat.double().cpu()).view(B, N, 3, 3)
+    t = trans.double().cpu().view(B, N, 3)
+    q = P[..., :2048].view(B, N, H, C)
+    kv = P[..., 2048:6144].view(B, N, H, 2 * C)
+    k, v = kv[..., :C], kv[..., C:]
+    qpr = P[..., 6144:6336].view(B, N, 3, H * PQ).permute(0, 1, 3, 2)              # [B,N,64,3] raw
+    kvpr = P[..., 6336:6816].view(B, N, 3, H * (PQ + PV)).permute(0, 1, 3, 2)      # [B,N,160,3]
+    glob = lambda x: torch.einsum("bnac,bnpc->bnpa", Rm, x) + t[:, :, None, :]
+    qpg = glob(qpr).view(B, N, H, PQ, 3)
+    kvpg = glob(kvpr).view(B, N, H, PQ + PV, 3)
+    kpg, vpg = kvpg[..., :PQ, :], kvpg[..., PQ:, :]
+    zbd = zb.double().cpu().view(B, N, N, ZB)
+    m = mask.double().cpu().view(B, N)
+    gamma = torch.nn.functional.softplus(hw.double().cpu()) * math.sqrt(1.0 / (3.0 * (PQ * 9.0 / 2.0)))
+    a = torch.einsum("bihc,bjhc->bhij", q, k) * math.sqrt(1.0 / (3 * C))
+    a = a + math.sqrt(1.0 / 3) * zbd[..., :H].permute(0, 3, 1, 2)
+    d2 = ((qpg[:, :, None] - kpg[:, None]) ** 2).sum((-1, -2))                     # [B,i,j,H]
+    a = a - 0.5 * (d2 * gamma).permute(0, 3, 1, 2)
+    a = a + 1e5 * (m[:, None, :, None] * m[:, None, None, :] - 1)
+    a = torch.softmax(a, -1)
+    o = torch.einsum("bhij,bjhc->bihc", a, v).reshape(B * N, H * C)
+    og = torch.einsum("bhij,bjhpx->bihpx", a, vpg)
+    ol = torch.einsum("bnca,bnhpc->bnhpa", Rm, og - t[:, :, None, None, :])        # R^T (o - t)
+    nrm = torch.sqrt((ol ** 2).sum(-1) + 1e-8)
+    opair = torch.einsum("bhij,bijc->bihc", a, zbd[..., H:]).reshape(B * N, H * CZ4)
+    ol = ol.reshape(B * N, H * PV, 3)
+    feats = torch.cat([o, ol[..., 0], ol[..., 1], ol[..., 2], nrm.reshape(B * N, H * PV), opair], -1)
+    return feats, a
+
+
+GROUPS = (("o", 0, F_PT), ("o_pt", F_PT, F_NORM), ("norm", F_NORM, F_PAIR), ("o_pair", F_PAIR, LDF))
+
+
+def _run(dev, B, N, seed, hpb=0, spread=1.0, want_A=True, tol=2e-5, tol_seq=2e-5, log=None):
+    L = ops.lib()
+    proj, quat, trans, zb, hw, mask = _inputs(dev, B, N, seed, spread)
+    qp, kp, vp, kpT = _points(L, proj, quat, trans, B, N)
+    f_seq, A_seq = _sequence(L, proj, quat, trans, zb, hw, mask, qp, kp, vp, kpT, B, N)
+    feats = torch.full((B * N, LDF), float("nan"), device=dev)          # (every column must be written)
+    A = torch.full((B, H, N, N), float("nan"), device=dev) if want_A else None
+    L.call("fd_ipa_flash_fwd", proj, zb, qp, kp, vp, hw, mask, quat, trans, feats, A, B, N, hpb)
+    assert bool(torch.isfinite(feats).all())
+    f64, a64 = _float64(proj, quat, trans, zb, hw, mask, B, N)
+    rows = (mask.cpu() > 0)                                               # rows of masked residues: see test_ipa_attn.py
+    out = {}
+    for name, lo, hi in GROUPS:
+        ref = f64[rows][:, lo:hi]
+        sc = float(ref.abs().max())
+        e64 = float((feats.cpu().double()[rows][:, lo:hi] - ref).abs().max()) / sc
+        eseq = float((feats.cpu()[rows][:, lo:hi] - f_seq.cpu()[rows][:, lo:hi]).abs().max()) / sc
+        s64 = float((f_seq.cpu().double()[rows][:, lo:hi] - ref).abs().max()) / sc      # what the sequence itself achieves
+        out[name] = (e64, eseq, s64)
+        if log is not None:
+            parity_log.out(f"flash.{name}", e64)
+        assert e64 < tol, (name, e64, s64)
+        assert eseq < tol_seq, (name, eseq)
+    if want_A:
+        assert bool(torch.isfinite(A).all())
+        rr = rows.view(B, 1, N, 1)
+        ea = float(((A.cpu().double() - a64) * rr).abs().max())
+        es = float(((A.cpu() - A_seq.cpu()) * rr).abs().max())
+        if log is not None:
+            parity_log.out("flash.A", ea)
+        assert ea < tol and es < tol_seq, (ea, es)
+    return out
+
+
+def test_ipa_flash_fwd_emu(use_emu):
+    _run("cpu", 1, 12, 0, hpb=8)          # one ragged tile
+    _run("cpu", 2, 37, 1, hpb=4)          # three tiles, ragged rows and keys, two head groups
+    _run("cpu", 1, 33, 2, hpb=2)
+    _run("cpu", 1, 20, 3, hpb=0, want_A=False)
+
+
+@pytest.mark.gpu
+def test_ipa_flash_fwd_gpu(hip_lib):
+    with parity_log.case("ipa_flash_fwd") as log:
+        for (B, N, seed, hpb, spread) in ((2, 128, 0, 8, 1.0), (1, 128, 1, 2, 1.0), (1, 128, 2, 4, 1.0), (3, 100, 3, 8, 1.0),
+                                          (1, 256, 4, 0, 1.2), (1, 257, 5, 8, 1.2), (2, 400, 6, 0, 1.5), (1, 512, 7, 8, 1.5),
+                                          (1, 600, 8, 8, 1.5)):
+            _run("cuda", B, N, seed, hpb=hpb, spread=spread, log=log)

@@ -1,7 +1,7 @@
 """Alternative launch sequences of the same arithmetic give the same training step.  Every field of options.opts that selects
 between a fused kernel and the launches it replaces is flipped here (read at call time: no re-import): IPA's four
 projections of s as ONE GEMM over back-to-back weights (proj_merge; optim.FlatAdam lays them out so), the sequence-
-transformer attention in one launch (fused_seq_attn), the per-row IPA attention kernel (fused_ipa_attn), the fused edge
+transformer attention in one launch (fused_seq_attn), the per-row IPA attention kernel (fused_ipa_attn), IPA attention as one launch (flash_ipa), the fused edge
 transition + grouped weight gradients (fused_edge, grouped_pair_dw), the grouped node-level weight gradients
 (grouped_node_dw), the fused edge embedder (fused_embed), the zero arena,
 split-K dX, and the gradient side stream -- model/ipa_pytorch.py:340-374,584-593.
@@ -24,7 +24,8 @@ from se3_diffusion_amd.optim import FlatAdam  # noqa: E402
 
 
 def _step(dev, B, N, blocks, **kw):
-    with options.override(seq_attn_min_rows=0, **kw):            # (0: the fused sequence attention at any size)
+    # (0: the fused sequence attention and the one-launch IPA attention at any size)
+    with options.override(seq_attn_min_rows=0, flash_ipa_min_tiles=0, **kw):
         conf = dict(fo.CONF, num_blocks=blocks)
         m = ScoreNetwork(ts.base_model_conf(blocks), diffuser=None)
         m.load_state_dict(fo.synth_params(seed=11, conf=conf), strict=True)
@@ -51,6 +52,8 @@ def _step(dev, B, N, blocks, **kw):
 GROUPS = [
     (dict(proj_merge=False, fused_seq_attn=False), 1e-4),
     (dict(fused_ipa_attn=False), 1e-4),
+    (dict(flash_ipa=False), 1e-4),            # fd_ipa_flash_fwd (probabilities written for the backward) vs the launch sequence
+    (dict(flash_ipa_hpb=2), 1e-4),            # (its 2-heads-per-block shape against the default pick)
     (dict(zero_arena=False, dx_splitk=False, grad_stream=False), 1e-4),
     (dict(grouped_pair_dw=False), 1e-4),
     (dict(grouped_node_dw=False), 1e-4),
@@ -85,7 +88,7 @@ def test_switches_emu(use_emu):
 
 def test_switches_two_blocks_emu(use_emu):
     # with an edge transition between the blocks: the fused LayerNorm-backward / dzb W40 prologue against the separate kernels
-    _compare("cpu", B=1, N=8, blocks=2, groups=[GROUPS[7], GROUPS[8], GROUPS[9], GROUPS[10]])
+    _compare("cpu", B=1, N=8, blocks=2, groups=[GROUPS[2], GROUPS[9], GROUPS[10], GROUPS[11], GROUPS[12]])
 
 
 def _dynamic_vs_static(dev, B, N, blocks):
@@ -129,4 +132,4 @@ def test_options_override_restores():
 @pytest.mark.gpu
 def test_switches_gpu(hip_lib):
     _compare("cuda", B=2, N=24, blocks=2)
-    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:3] + GROUPS[4:12])
+    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:5] + GROUPS[6:14])

@@ -1,0 +1,114 @@
+"""fd_ipa_flash_fwd against the launch sequence it replaces (q k^T GEMM -> fd_ipa_attn_fwd -> a v / a v_pts GEMMs ->
+fd_ipa_opt_fwd) at the shapes of the benchmark configs: us per IPA block, HIP events over back-to-back replays.
+    python tools/bench_ipa_flash.py [B N [hpb ...]]      (GPU box)"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_ipa_flash as T  # noqa: E402  (input builder + the replaced sequence: test infrastructure, timing only)
+from se3_diffusion_amd import ops  # noqa: E402
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def case(B, N, hpbs, spread=1.0):
+    L = ops.lib()
+    dev = "cuda"
+    proj, quat, trans, zb, hw, mask = T._inputs(dev, B, N, 0, spread, masked=False)
+    qp, kp, vp, kpT = T._points(L, proj, quat, trans, B, N)
+    t_seq = timeit(lambda: T._sequence(L, proj, quat, trans, zb, hw, mask, qp, kp, vp, kpT, B, N))
+    f_seq, A_seq = T._sequence(L, proj, quat, trans, zb, hw, mask, qp, kp, vp, kpT, B, N)
+    line = [f"B={B:3d} N={N:4d}: sequence (5 launches) {t_seq:8.1f} us"]
+    feats = torch.empty(B * N, T.LDF, device=dev)
+    A = torch.empty(B, T.H, N, N, device=dev)
+    for hpb in hpbs:
+        t = timeit(lambda: L.call("fd_ipa_flash_fwd", proj, zb, qp, kp, vp, hw, mask, quat, trans, feats, None, B, N, hpb))
+        tA = timeit(lambda: L.call("fd_ipa_flash_fwd", proj, zb, qp, kp, vp, hw, mask, quat, trans, feats, A, B, N, hpb))
+        err = float((feats - f_seq).abs().max() / f_seq.abs().max())
+        errA = float((A - A_seq).abs().max())
+        line.append(f"flash hpb={hpb}: {t:8.1f} us (with A {tA:8.1f}) maxdiff {err:.1e} / A {errA:.1e}")
+    print(" | ".join(line), flush=True)
+
+
+# compile-time variants of the kernel (prefetch distances, scheduling pins): second copies of the library with
+# fd_ipa_flash.hip recompiled under -D flags, built in the build container (`--build`) so that they travel with gpurun
+VARIANTS = {"kpf2": ["-DFL_KPF=2"], "kpf6": ["-DFL_KPF=6"], "abl_nodma": ["-DFL_ABL_NODMA"], "abl_nokv": ["-DFL_ABL_NOKV"],
+            "abl_nopair": ["-DFL_ABL_NOPAIR"], "abl_nosm": ["-DFL_ABL_NOSM"],
+            "abl_all": ["-DFL_ABL_NODMA", "-DFL_ABL_NOKV", "-DFL_ABL_NOPAIR", "-DFL_ABL_NOSM"]}
+PROBES = os.path.join(ROOT, "tools", "probes")
+
+
+def build_variants():
+    import subprocess
+    from se3_diffusion_amd import build
+    build.build(verbose=False)
+    others = [os.path.join(build.OBJ, f) for f in sorted(os.listdir(build.OBJ)) if f.endswith(".o") and f != "fd_ipa_flash.o"]
+    for tag, flags in VARIANTS.items():
+        obj = os.path.join(PROBES, f"fd_ipa_flash_{tag}.o")
+        r = subprocess.run([build.HIPCC, *build.FLAGS, *flags, "-c", os.path.join(build.CSRC, "fd_ipa_flash.hip"), "-o", obj,
+                            "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        spills = [l.split("VGPRs Spill:")[1].split()[0] for l in r.stderr.splitlines() if "VGPRs Spill:" in l]
+        subprocess.check_call([build.HIPCC, f"--offload-arch={build.ARCH}", "-shared", "-fPIC", obj, *others, "-o",
+                               os.path.join(PROBES, f"libfd_flash_{tag}.so")])
+        os.remove(obj)
+        print(f"{tag}: built, spilled VGPRs per kernel {spills}")
+
+
+def variants(B, N, hpb, spread=1.0):
+    from se3_diffusion_amd import hip
+    dev = "cuda"
+    L0 = ops.lib()
+    proj, quat, trans, zb, hw, mask = T._inputs(dev, B, N, 0, spread, masked=False)
+    qp, kp, vp, kpT = T._points(L0, proj, quat, trans, B, N)
+    feats = torch.empty(B * N, T.LDF, device=dev)
+    f0 = torch.empty_like(feats)
+    L0.call("fd_ipa_flash_fwd", proj, zb, qp, kp, vp, hw, mask, quat, trans, f0, None, B, N, hpb)
+    line = [f"B={B:3d} N={N:4d} hpb={hpb}"]
+    for tag in ["shipped"] + sorted(VARIANTS):
+        path = hip.LIB_PATH if tag == "shipped" else os.path.join(PROBES, f"libfd_flash_{tag}.so")
+        if not os.path.exists(path):
+            continue
+        L = hip.FdLib(path)
+        t = timeit(lambda: L.call("fd_ipa_flash_fwd", proj, zb, qp, kp, vp, hw, mask, quat, trans, feats, None, B, N, hpb))
+        line.append(f"{tag} {t:7.1f} us{'' if torch.equal(feats, f0) else ' (DIFFERS)'}")
+    print(" | ".join(line), flush=True)
+
+
+def main():
+    if "--build" in sys.argv:
+        build_variants()
+        return
+    if "--variants" in sys.argv:
+        variants(30, 128, 8)
+        variants(8, 512, 8, spread=3.0)
+        variants(7, 256, 4, spread=2.0)
+        return
+    if len(sys.argv) > 2:
+        case(int(sys.argv[1]), int(sys.argv[2]), [int(x) for x in sys.argv[3:]] or [0])
+        return
+    case(30, 128, [8, 4])
+    case(8, 512, [8], spread=3.0)
+    case(7, 256, [8, 4], spread=2.0)
+    case(1, 128, [2, 4, 8])
+    case(1, 256, [2, 4, 8], spread=2.0)
+    case(1, 512, [4, 8], spread=3.0)
+
+
+if __name__ == "__main__":
+    main()
