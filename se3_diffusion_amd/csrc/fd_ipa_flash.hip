@@ -62,6 +62,11 @@ constexpr int STAGE_INSTR = (STAGE_PIECES + 63) / 64;   // 45 wave-wide copies p
 #else
 #define FL_DMA(src, dst) fd::glds16a(src, dst)
 #endif
+#ifdef FL_ABL_NOBAR
+#define FL_SYNC()
+#else
+#define FL_SYNC() __syncthreads()
+#endif
 #ifndef FL_KPF
 #define FL_KPF 4    // K chunks (one 16-byte load per lane each) requested ahead of their MFMAs (probe: -DFL_KPF=..)
 #endif
@@ -197,7 +202,11 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
   // requested before the o_pair phase of this one.
   constexpr int KPF = HPB == 8 ? FL_KPF : 16, VPF = HPB == 8 ? FL_VPF : 10;     // (HPB < 8: one wave per SIMD, 512 registers)
   float4 kf[C / 16];
+#ifdef FL_ABL_KVB0
+  const float* __restrict__ kbase = a.proj + KV_OFF + h * 2 * C;                 // (probe: every backbone reads backbone 0's K / V)
+#else
   const float* __restrict__ kbase = a.proj + rb * LDP + KV_OFF + h * 2 * C;      // (wave-uniform; lane offsets are 32-bit)
+#endif
   const float* __restrict__ vpb = a.vp + (rb * H + h) * (PV * 3);
   {
     const float* kr = kbase + (unsigned)(imin(n, N - 1) * LDP + 4 * kk);
@@ -205,10 +214,8 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
     for (int cc = 0; cc < KPF; ++cc) kf[cc] = ldkv(kr + 16 * cc);
   }
 
-#pragma unroll 1
-  for (int t = 0; t < nti; ++t) {
-    fd::wait_vmem();
-    __syncthreads();           // stage t of the image has landed; every wave is done with tile t - 1 (its stage, Es, Fs)
+  // the copy of the next key tile's zb image (its stage was last read in the o_pair phase of tile t - 1)
+  auto next_stage = [&](int t) {
     if (t + 1 < nti) {
 #pragma unroll
       for (int k = 0; k < NI; ++k) {
@@ -217,6 +224,16 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
           FL_DMA(zb_b + umin(poff[k] + (unsigned)(t + 1) * (TI * ZB), plim), slab + ((t + 1) & 1) * STAGE_BYTES + inst * 1024);
       }
     }
+  };
+#define FL_NEXT_STAGE() next_stage(t)
+
+#pragma unroll 1
+  for (int t = 0; t < nti; ++t) {
+    fd::wait_vmem();
+    FL_SYNC();                 // stage t of the image has landed; every wave is done with tile t - 1 (its stage, Es, Fs)
+#ifndef FL_DMA_MID
+    FL_NEXT_STAGE();
+#endif
     const float* __restrict__ sl = reinterpret_cast<const float*>(slab + (t & 1) * STAGE_BYTES);
     const int j0 = TI * t;
     // ---- S^T = K Q^T (two accumulator chains) and the point term
@@ -233,6 +250,11 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
           if (kk < 2) { v = ld4(kpr + 16); qb = ld4(qpr + 16); }
         }
         if (cc + KPF < C / 16) { kf[cc + KPF] = ldkv(kr + 16 * (cc + KPF)); kf[cc + KPF + 1] = ldkv(kr + 16 * (cc + KPF + 1)); }
+#ifdef FL_DMA_MID
+        // (probe: the image copy behind the tile's LAST K request instead of at the top of the tile -- measured SLOWER,
+        //  122 against 109 us at B=30 x N=128, 464 against 398 at B=8 x N=512: profiles/r04_ipa_flash_variants.log)
+        if (cc + KPF == C / 16 - 2 || (KPF >= C / 16 && cc == 0)) FL_NEXT_STAGE();
+#endif
         FL_PIN();
         const float4 k0 = kf[cc], k1 = kf[cc + 1];
         s0 = fd::mfma_16x16x4(k0.x, Qf[cc].x, s0);
@@ -348,7 +370,7 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
       for (int cc = 0; cc < KPF; ++cc) kf[cc] = ldkv(kr + 16 * cc);
     }
 #ifndef FL_ABL_NOPAIR
-    __syncthreads();           // Es, Fs of this tile are visible
+    FL_SYNC();                 // Es, Fs of this tile are visible
     // ---- o_pair of the wave's rows: [16 (heads, HPB used) x 16 keys] x [16 keys x 32]
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
