@@ -395,6 +395,24 @@ int fd_ipa_flash_fwd(const float* proj, const float* zb, const float* qp, const 
                      const float* head_w, const float* mask, const float* quat, const float* trans, float* feats,
                      float* A, int B, int N, int heads_per_block, void* stream);
 
+/* Query side of the IPA attention backward in ONE launch (autograd of model/ipa_pytorch.py:380-457 with the probabilities A
+ * saved by the forward) -- replaces  fd_gemm (dA = dO V^T) -> fd_gemm (dA += dOpt vpts^T) -> fd_ipa_attn_bwd's per-row kernel;
+ * dA never exists.  dL = A (dP - D) with dP = dO.v + dOpt.vpts + dout.zd on the exact-fp32 MFMA, D from the forward's outputs
+ * (dO.o + dout.opair + ptdot) ->
+ *   dL [B, 8, N, N] (written once: the dQ / dK GEMMs and the key-point gradient that follow read it),
+ *   dzb [B N N, 40] = [sqrt(1/3) dL | sum_h A dout], dqp [R, 8, 24], dkp [R, 8, 24] (fd_ipa_kpts_bwd on dL), dhead_w [8] (+=;
+ *   hw_part [R, 8] is scratch).
+ * proj [R, 6816], A [B, 8, N, N], zb [B N N, 40], dfeats / feats [R, 2688], doptg [R, 8, 36] and ptdot [R, 8] from
+ * fd_ipa_opt_bwd_dot, qp / kp [R, 8, 24], vp [R, 8, 36] (global frame), head_w [8], trans [R, 3].  16-byte aligned tensors. */
+int fd_ipa_flash_bwd(const float* proj, const float* A, const float* zb, const float* dfeats, const float* feats,
+                     const float* doptg, const float* ptdot, const float* qp, const float* kp, const float* vp,
+                     const float* head_w, const float* trans, float* dL, float* dzb, float* dqp, float* dkp,
+                     float* dhead_w, float* hw_part, int B, int N, void* stream);
+/* fd_ipa_opt_bwd that also returns ptdot [R, 8] = sum_p d(o_pt, global frame) . (o_pt, global frame) per head (the o_pt term
+ * of the softmax backward's row constant; model/ipa_pytorch.py:432-449) */
+int fd_ipa_opt_bwd_dot(const float* dfeats, const float* feats, const float* quat, const float* trans, float* doptg,
+                       float* dframe, float* ptdot, long R, void* stream);
+
 /* dz[p, 0:128] (+)= dzb[p, 0:40] W40[0:40, 0:128] over the pair rows (autograd of linear_b / down_z w.r.t. z,
  * ipa_pytorch.py:380-386,455-457): streaming kernel, W40 resident in registers */
 int fd_ipa_dz_acc(const float* dzb, const float* W40, float* dz, long rows, int accumulate, void* stream);

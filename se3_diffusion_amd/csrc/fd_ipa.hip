@@ -431,11 +431,15 @@ __global__ __launch_bounds__(256) void ipa_opt_fwd_kernel(const float* __restric
 }
 
 // block per residue (128 threads, 96 active)
+// ptdot (may be null; needs trans): [R, 8] = sum_p d(o_pt global) . (o_pt global) per head -- the o_pt term of the softmax
+// backward's row constant sum_j a_ij dP_ij (fd_ipa_flash_bwd takes it from here instead of a pass over the keys)
 __global__ __launch_bounds__(128) void ipa_opt_bwd_kernel(const float* __restrict__ dfeats,
                                                           const float* __restrict__ feats,
                                                           const float* __restrict__ quat,
-                                                          float* __restrict__ doptg, float* __restrict__ dframe) {
+                                                          float* __restrict__ doptg, float* __restrict__ dframe,
+                                                          const float* __restrict__ trans, float* __restrict__ ptdot) {
   __shared__ float red[2][12];
+  __shared__ float dots[H * PV];
   const long r = blockIdx.x;
   const int hp = (int)threadIdx.x;
   const Rot R = quat_to_rot(quat + r * 4);
@@ -460,6 +464,10 @@ __global__ __launch_bounds__(128) void ipa_opt_bwd_kernel(const float* __restric
     const float uz = R.r[6] * lx + R.r[7] * ly + R.r[8] * lz;
     float* dg = doptg + (r * H * PV + hp) * 3;
     dg[0] = dux; dg[1] = duy; dg[2] = duz;
+    if (ptdot != nullptr) {
+      const float* t = trans + r * 3;
+      dots[hp] = dux * (ux + t[0]) + duy * (uy + t[1]) + duz * (uz + t[2]);
+    }
     acc[0] = ux * dlx; acc[1] = ux * dly; acc[2] = ux * dlz;
     acc[3] = uy * dlx; acc[4] = uy * dly; acc[5] = uy * dlz;
     acc[6] = uz * dlx; acc[7] = uz * dly; acc[8] = uz * dlz;
@@ -473,6 +481,12 @@ __global__ __launch_bounds__(128) void ipa_opt_bwd_kernel(const float* __restric
     for (int k = 0; k < 12; ++k) red[wave][k] = acc[k];
   __syncthreads();
   if (hp < 12) dframe[r * 12 + hp] += red[0][hp] + red[1][hp];
+  if (ptdot != nullptr && hp < H) {
+    float d = 0.f;
+#pragma unroll
+    for (int p = 0; p < PV; ++p) d += dots[hp * PV + p];
+    ptdot[r * H + hp] = d;
+  }
 }
 
 // ---------------------------------------------------------------- o_pair
@@ -730,8 +744,18 @@ extern "C" int fd_ipa_opt_bwd(const float* dfeats, const float* feats, const flo
                               float* dframe, long R_, void* stream) {
   if (R_ == 0) return FD_OK;
   hipLaunchKernelGGL(ipa_opt_bwd_kernel, dim3((unsigned)R_), dim3(128), 0, (hipStream_t)stream, dfeats, feats, quat,
-                     doptg, dframe);
+                     doptg, dframe, (const float*)nullptr, (float*)nullptr);
   FD_CHECK_LAUNCH("fd_ipa_opt_bwd");
+  return FD_OK;
+}
+
+extern "C" int fd_ipa_opt_bwd_dot(const float* dfeats, const float* feats, const float* quat, const float* trans,
+                                  float* doptg, float* dframe, float* ptdot, long R_, void* stream) {
+  FD_CHECK_ARG(trans != nullptr && ptdot != nullptr, "fd_ipa_opt_bwd_dot: trans and ptdot are required");
+  if (R_ == 0) return FD_OK;
+  hipLaunchKernelGGL(ipa_opt_bwd_kernel, dim3((unsigned)R_), dim3(128), 0, (hipStream_t)stream, dfeats, feats, quat,
+                     doptg, dframe, trans, ptdot);
+  FD_CHECK_LAUNCH("fd_ipa_opt_bwd_dot");
   return FD_OK;
 }
 

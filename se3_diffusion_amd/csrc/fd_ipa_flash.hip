@@ -458,6 +458,346 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward, query side (reference: autograd of ipa_pytorch.py:380-457).  With the probabilities A saved by the forward,
+//   dP_ij^h = dO_i . v_j + dOpt_i . vpts_j + dout_i^h . zd_ij          (gradient w.r.t. a_ij^h of o, o_pt (global frame), o_pair)
+//   dL_ij^h = A_ij^h (dP_ij^h - D_i^h),   D_i^h = sum_j A dP = dO_i . o_i + dOpt_i . opt_i + dout_i^h . opair_i^h
+// (D from the forward's own outputs: no second pass over the keys), and from dL
+//   dzb[i, j, h] = sqrt(1/3) dL,  dzb[i, j, 8 + c] = sum_h A_ij^h dout_i^h[c],  dqp_i = gamma sum_j dL_ij (k'_j - q'_i),
+//   d gamma_h (per-row partial) = -1/2 sum_j dL_ij |q'_i - k'_j|^2
+// in ONE launch with the forward kernel's skeleton (16 query rows x HPB heads per block, key tiles of 16, the tile's zb rows
+// through the LDS image) -- it replaces the dA GEMM (dO V^T), the dA += GEMM (dOpt vpts^T) and fd_ipa_attn_bwd's per-row
+// kernel; dA never exists, dL is written once (for the dK GEMM, fd_ipa_kpts_bwd and dQ GEMM that follow).
+// Per key tile and wave: dP^T = V dO^T (64 MFMAs, dO^T resident as B operand) + vpts dOpt^T (12) + the o_pair term as a
+// per-row product [heads x 32] x [32 x 16 keys] of the wave's own two rows (16, results handed to the head waves through
+// LDS); sum_j dL k'_j with |k'_j|^2 riding as a 25th row (16); dzb's o_pair columns as [16 keys x heads] x [heads x 32] per
+// row (8, probabilities of all heads through LDS).  The per-tile exchange buffers are double-buffered so that a tile needs
+// two block barriers.
+struct FlashBwdArgs {
+  const float *proj, *A, *zb, *dfeats, *feats, *doptg, *ptdot, *qp, *kp, *vp, *head_w, *trans;
+  float *dL, *dzb, *dqp, *hw_part;
+  int B, N;
+};
+
+template <int HPB>
+__global__ __launch_bounds__(HPB * 64) void ipa_flash_bwd_kernel(FlashBwdArgs a) {
+  constexpr int NI = (STAGE_INSTR + HPB - 1) / HPB;
+  constexpr int STAGE_BYTES = HPB * NI * 1024;
+  constexpr int RPW = TI / HPB;
+  constexpr int NG = H / HPB;
+  static_assert(HPB == H, "dzb's o_pair columns sum over all heads: one block owns them");
+  __shared__ __attribute__((aligned(16))) char slab[2 * STAGE_BYTES];
+  __shared__ __attribute__((aligned(16))) float Es[2][HPB][TI][16];     // probabilities of the key tile [head][i][key]
+  __shared__ __attribute__((aligned(16))) float Xs[2][HPB][TI][16];     // o_pair part of dP [head][i][key]
+  __shared__ __attribute__((aligned(16))) float Ys[2][HPB][TI][16];     // sqrt(1/3) dL [head][i][key]
+
+  const int N = a.N;
+  const int nti = (N + TI - 1) / TI;
+  const int lid = fd_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+  const int g = lid % NG, it = (lid / NG) % nti, b = lid / (NG * nti);
+  const int lane = fd::lane_id();
+  const int wave = fd::uniform(fd::wave_id());
+  const int n = lane & 15, kk = lane >> 4;
+  const int h = g * HPB + wave;
+  const int i0 = it * TI;
+  const long rb = (long)b * N;
+  const long rg = rb + imin(i0 + n, N - 1);
+  const bool row_ok = i0 + n < N;
+  const bool vec = (N & 3) == 0;                             // rows of A / dL are 16-byte aligned
+  const float* __restrict__ zb_b = a.zb + rb * N * ZB;
+
+  unsigned poff[NI];
+  const unsigned plim = (unsigned)N * (unsigned)N * ZB - 4u;
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int inst = wave * NI + k;
+    poff[k] = piece_off(inst * 64 + lane, i0, N);
+    if (inst < STAGE_INSTR) FL_DMA(zb_b + umin(poff[k], plim), slab + inst * 1024);
+  }
+
+  const float sq13 = sqrtf(1.0f / 3.0f);
+  const float gscale = sqrtf(1.0f / (3.0f * ((float)PQ * 9.0f / 2.0f)));
+  const float hwv = a.head_w[h];
+  const float gamma = softplus_f(hwv) * gscale;
+  // ---- resident operands
+  // dO^T as B operand (the forward's Q^T layout), and D's first term dO . o on the way
+  float4 dOf[C / 16];
+  float dsum = 0.f;
+  {
+    const float* d = a.dfeats + rg * LDF + h * C + 4 * kk;
+    const float* o = a.feats + rg * LDF + h * C + 4 * kk;
+#pragma unroll
+    for (int cc = 0; cc < C / 16; ++cc) {
+      dOf[cc] = ld4(d + 16 * cc);
+      const float4 ov = ld4(o + 16 * cc);
+      dsum += dOf[cc].x * ov.x + dOf[cc].y * ov.y + dOf[cc].z * ov.z + dOf[cc].w * ov.w;
+    }
+    // dout . opair: 32 floats per (row, head), 8 per lane
+    const float* dp = a.dfeats + rg * LDF + F_PAIR + h * CZ4 + 8 * kk;
+    const float* op = a.feats + rg * LDF + F_PAIR + h * CZ4 + 8 * kk;
+    const float4 d0 = ld4(dp), d1 = ld4(dp + 4), o0 = ld4(op), o1 = ld4(op + 4);
+    dsum += d0.x * o0.x + d0.y * o0.y + d0.z * o0.z + d0.w * o0.w + d1.x * o1.x + d1.y * o1.y + d1.z * o1.z + d1.w * o1.w;
+  }
+  dsum += __shfl_xor(dsum, 16);
+  dsum += __shfl_xor(dsum, 32);
+  const float D = dsum + a.ptdot[rg * H + h];
+  // dOpt^T as B operand: 36 floats per (row, head) in chunks of 16 | 16 | 4
+  float4 dgf[3];
+  {
+    const float* d = a.doptg + (rg * H + h) * (PV * 3) + 4 * kk;
+    dgf[0] = ld4(d);
+    dgf[1] = ld4(d + 16);
+    dgf[2] = kk == 0 ? ld4(d + 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // dout of the wave's own rows: as A operand [m = head][k = channel] for the o_pair part of dP, and as B operand
+  // [k = head][n = channel] for dzb's o_pair columns
+  float4 doutA[RPW][2];
+  float doutB[RPW][2][2];
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const long ri = rb + imin(i0 + wave * RPW + rr, N - 1);
+    const float* d = a.dfeats + ri * LDF + F_PAIR + g * HPB * CZ4;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+      doutA[rr][cb] = n < HPB ? ld4(d + n * CZ4 + 16 * cb + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) doutB[rr][ks][ct] = 4 * ks + kk < HPB ? d[(4 * ks + kk) * CZ4 + 16 * ct + n] : 0.f;
+  }
+  // centre of the point coordinates (as the forward); lane m = n of the key-point operand holds floats 4 m + e
+  const float* tc = a.trans + (rb + imin(i0 + TI / 2, N - 1)) * 3;
+  const float c0 = tc[0], c1 = tc[1], c2 = tc[2];
+  const int n3 = n % 3;                                       // component of float 4 n + e is (n + e) % 3
+  const float e0 = n3 == 0 ? c0 : n3 == 1 ? c1 : c2;
+  const float e1 = n3 == 0 ? c1 : n3 == 1 ? c2 : c0;
+  const float e2 = n3 == 0 ? c2 : n3 == 1 ? c0 : c1;
+
+  f32x4 dqk[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dqk[q] = zero4();
+  float sds = 0.f;
+  const float* __restrict__ vbase = a.proj + rb * LDP + KV_OFF + h * 2 * C + C;      // V rows of the head
+  const float* __restrict__ kpb = a.kp + (rb * H + h) * (PQ * 3);
+  const float* __restrict__ vpb = a.vp + (rb * H + h) * (PV * 3);
+  const float* __restrict__ Arow = a.A + (((long)b * H + h) * N + imin(i0 + n, N - 1)) * N;
+  float* __restrict__ dLrow = a.dL + (((long)b * H + h) * N + imin(i0 + n, N - 1)) * N;
+
+  // ---- operands of a key tile that are requested one tile ahead (their first use is late in the tile, or a dependent
+  // chain of its own): the probabilities, the key points (lanes n >= 6 read lane n - 6's piece and drop it: no branch around
+  // the loads) and the value points
+  float4 pA, kpn[4], vpn[3];
+  auto request = [&](int t) {
+    const int j0 = TI * t;
+    {
+      const int j = imin(j0 + 4 * kk, N - 4 < 0 ? 0 : N - 4);      // (a row tail is re-read scalar below)
+      pA = vec ? ld4(Arow + (j & ~3)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int m6 = n < 6 ? n : n - 6 < 6 ? n - 6 : n - 12;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kpn[r] = ld4(kpb + (unsigned)(imin(j0 + 4 * kk + r, N - 1) * (H * PQ * 3) + 4 * m6));
+    const float* pr = vpb + (unsigned)(imin(j0 + n, N - 1) * (H * PV * 3));
+    vpn[0] = ld4(pr + 4 * kk);
+    vpn[1] = ld4(pr + 16 + 4 * kk);
+    vpn[2] = ld4(pr + 32);                                          // (used by kk == 0)
+  };
+  request(0);
+
+  // dzb of the wave's rows for key tile t (exchange buffers t & 1): o_pair columns by MFMA, bias columns from Ys
+  auto emit_dzb = [&](int t) {
+    const int bf = t & 1;
+    const int j0 = TI * t;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int i = wave * RPW + rr;
+      // transposed product [32 channels x heads] x [heads x 16 keys]: lane (n = key, kk) ends up with the channels 4 kk .. + 3
+      // (+ 16) of ITS key -- 16 contiguous bytes of the dzb row per store
+      f32x4 z0 = zero4(), z1 = zero4();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float e = 4 * ks + kk < HPB ? Es[bf][4 * ks + kk][i][n] : 0.f;     // B operand [k = head 4 ks + kk][n = key]
+        z0 = fd::mfma_16x16x4(doutB[rr][ks][0], e, z0);
+        z1 = fd::mfma_16x16x4(doutB[rr][ks][1], e, z1);
+      }
+#ifdef FL_ABL_NODZB
+      if (i0 + i < N && z0[0] == 12345.f) {
+#else
+      if (i0 + i < N && j0 + n < N) {
+#endif
+        float* __restrict__ dz = a.dzb + ((rb + i0 + i) * N + j0 + n) * ZB;
+        *reinterpret_cast<float4*>(dz + H + 4 * kk) = make_float4(z0[0], z0[1], z0[2], z0[3]);
+        *reinterpret_cast<float4*>(dz + H + 16 + 4 * kk) = make_float4(z1[0], z1[1], z1[2], z1[3]);
+        // bias columns of the key: heads 2 kk, 2 kk + 1
+        *reinterpret_cast<float2*>(dz + 2 * kk) = make_float2(Ys[bf][2 * kk][i][n], Ys[bf][2 * kk + 1][i][n]);
+      }
+    }
+  };
+
+#pragma unroll 1
+  for (int t = 0; t < nti; ++t) {
+    fd::wait_vmem();
+    FL_SYNC();                 // stage t of the image has landed; exchange buffers of tile t - 1 are complete
+    if (t + 1 < nti) {
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int inst = wave * NI + k;
+        if (inst < STAGE_INSTR)
+          FL_DMA(zb_b + umin(poff[k] + (unsigned)(t + 1) * (TI * ZB), plim), slab + ((t + 1) & 1) * STAGE_BYTES + inst * 1024);
+      }
+    }
+    const int bf = t & 1;
+    const int j0 = TI * t;
+    // the first V chunks of this tile are on their way while dzb of the tile before and the o_pair part of dP are formed
+    constexpr int VPFB = 6;
+    float4 vfr[C / 16];
+    const float* vr = vbase + (unsigned)(imin(j0 + n, N - 1) * LDP + 4 * kk);
+#pragma unroll
+    for (int cc = 0; cc < VPFB; ++cc) vfr[cc] = ldkv(vr + 16 * cc);
+    if (t > 0) emit_dzb(t - 1);
+    const float* __restrict__ sl = reinterpret_cast<const float*>(slab + (t & 1) * STAGE_BYTES);
+    // ---- o_pair part of dP for the wave's rows: [heads x 32] x [32 x 16 keys]; k-step s of channel block cb contracts the
+    // channels {16 cb + 4 kk' + s}
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int i = wave * RPW + rr;
+      const float* zr = sl + i * ROW_F + (n >> 2) * GRP_F + (n & 3) * ZB + H + 4 * kk;     // lane (kk, key n)
+      f32x4 x = zero4();
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const float4 zv = ld4(zr + 16 * cb);
+        x = fd::mfma_16x16x4(doutA[rr][cb].x, zv.x, x);
+        x = fd::mfma_16x16x4(doutA[rr][cb].y, zv.y, x);
+        x = fd::mfma_16x16x4(doutA[rr][cb].z, zv.z, x);
+        x = fd::mfma_16x16x4(doutA[rr][cb].w, zv.w, x);
+      }
+      // C[m = head][n = key]: lane (n, kk) holds heads 4 kk + r
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * kk + r < HPB) Xs[bf][4 * kk + r][i][n] = x[r];
+    }
+    // ---- probabilities of (row n, keys j0 + 4 kk + r)
+    float p[4];
+    {
+      const int j = j0 + 4 * kk;
+      if (vec && j + 3 < N) {
+        p[0] = pA.x; p[1] = pA.y; p[2] = pA.z; p[3] = pA.w;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = j + r < N ? Arow[j + r] : 0.f;
+      }
+    }
+    *reinterpret_cast<float4*>(&Es[bf][wave][n][4 * kk]) = make_float4(p[0], p[1], p[2], p[3]);
+    // ---- dP^T = V dO^T + vpts dOpt^T
+    f32x4 s0 = zero4(), s1 = zero4(), spt = zero4();
+    {
+#pragma unroll
+      for (int cc = 0; cc < C / 16; cc += 2) {
+        if (cc + VPFB < C / 16) { vfr[cc + VPFB] = ldkv(vr + 16 * (cc + VPFB)); vfr[cc + VPFB + 1] = ldkv(vr + 16 * (cc + VPFB + 1)); }
+        const float4 v0 = vfr[cc], v1 = vfr[cc + 1];
+        s0 = fd::mfma_16x16x4(v0.x, dOf[cc].x, s0);
+        s1 = fd::mfma_16x16x4(v1.x, dOf[cc + 1].x, s1);
+        s0 = fd::mfma_16x16x4(v0.y, dOf[cc].y, s0);
+        s1 = fd::mfma_16x16x4(v1.y, dOf[cc + 1].y, s1);
+        s0 = fd::mfma_16x16x4(v0.z, dOf[cc].z, s0);
+        s1 = fd::mfma_16x16x4(v1.z, dOf[cc + 1].z, s1);
+        s0 = fd::mfma_16x16x4(v0.w, dOf[cc].w, s0);
+        s1 = fd::mfma_16x16x4(v1.w, dOf[cc + 1].w, s1);
+      }
+      const float4 u0 = vpn[0], u1 = vpn[1];
+      const float4 u2 = kk == 0 ? vpn[2] : make_float4(0.f, 0.f, 0.f, 0.f);
+      spt = fd::mfma_16x16x4(u0.x, dgf[0].x, spt);
+      spt = fd::mfma_16x16x4(u0.y, dgf[0].y, spt);
+      spt = fd::mfma_16x16x4(u0.z, dgf[0].z, spt);
+      spt = fd::mfma_16x16x4(u0.w, dgf[0].w, spt);
+      spt = fd::mfma_16x16x4(u1.x, dgf[1].x, spt);
+      spt = fd::mfma_16x16x4(u1.y, dgf[1].y, spt);
+      spt = fd::mfma_16x16x4(u1.z, dgf[1].z, spt);
+      spt = fd::mfma_16x16x4(u1.w, dgf[1].w, spt);
+      spt = fd::mfma_16x16x4(u2.x, dgf[2].x, spt);
+      spt = fd::mfma_16x16x4(u2.y, dgf[2].y, spt);
+      spt = fd::mfma_16x16x4(u2.z, dgf[2].z, spt);
+      spt = fd::mfma_16x16x4(u2.w, dgf[2].w, spt);
+    }
+    FL_SYNC();                 // Xs (and Es) of this tile are visible
+    // ---- dL
+    const float4 xv = ld4(&Xs[bf][wave][n][4 * kk]);
+    float dl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dP = (s0[r] + s1[r]) + spt[r] + f4(xv, r);
+      dl[r] = p[r] * (dP - D);
+    }
+    if (row_ok) {
+      const int j = j0 + 4 * kk;
+      if (vec && j + 3 < N) {
+        *reinterpret_cast<float4*>(dLrow + j) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (j + r < N) dLrow[j + r] = dl[r];
+      }
+    }
+    *reinterpret_cast<float4*>(&Ys[bf][wave][n][4 * kk]) = make_float4(sq13 * dl[0], sq13 * dl[1], sq13 * dl[2], sq13 * dl[3]);
+    sds += (dl[0] + dl[1]) + (dl[2] + dl[3]);
+    // ---- sum_j dL k'_j (24 floats) and sum_j dL |k'_j|^2 (row 6 of tile 0): A operand lane (m = n, kk) = floats 4 m + q of
+    // key j0 + 4 kk + r, m < 6
+#ifndef FL_ABL_NOPTS
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float4 kf = kpn[r];
+      kf = n < 6 ? make_float4(kf.x - e0, kf.y - e1, kf.z - e2, kf.w - e0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float nsq = fd::row16_sum(kf.x * kf.x + kf.y * kf.y + kf.z * kf.z + kf.w * kf.w);
+      if (n == 6) kf.x = nsq;
+      dqk[0] = fd::mfma_16x16x4(kf.x, dl[r], dqk[0]);
+      dqk[1] = fd::mfma_16x16x4(kf.y, dl[r], dqk[1]);
+      dqk[2] = fd::mfma_16x16x4(kf.z, dl[r], dqk[2]);
+      dqk[3] = fd::mfma_16x16x4(kf.w, dl[r], dqk[3]);
+    }
+#endif
+    if (t + 1 < nti) request(t + 1);
+  }
+  FL_SYNC();
+  emit_dzb(nti - 1);
+
+  // ---- epilogue: dqp = gamma (sum_j dL k'_j - q'_i sum_j dL), head-weight partial
+  sds += __shfl_xor(sds, 16);
+  sds += __shfl_xor(sds, 32);
+  // C layout of dqk[q]: lane (n = row i, kk), register r -> operand row m = 4 kk + r -> float 4 m + q
+  float qdot = 0.f, qsq = 0.f;
+  const float* qsrc = a.qp + (rg * H + h) * (PQ * 3);
+  float* qdst = a.dqp + (rg * H + h) * (PQ * 3);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = 4 * kk + r;
+    if (m < 6) {
+      float4 q = ld4(qsrc + 4 * m);
+      // component of float 4 m + e is (m + e) % 3
+      const int m3 = m % 3;
+      const float g0 = m3 == 0 ? c0 : m3 == 1 ? c1 : c2;
+      const float g1 = m3 == 0 ? c1 : m3 == 1 ? c2 : c0;
+      const float g2 = m3 == 0 ? c2 : m3 == 1 ? c0 : c1;
+      q = make_float4(q.x - g0, q.y - g1, q.z - g2, q.w - g0);
+      const float k0 = dqk[0][r], k1 = dqk[1][r], k2 = dqk[2][r], k3 = dqk[3][r];
+      qdot += q.x * k0 + q.y * k1 + q.z * k2 + q.w * k3;
+      qsq += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+      if (row_ok)
+        *reinterpret_cast<float4*>(qdst + 4 * m) =
+            make_float4(gamma * (k0 - q.x * sds), gamma * (k1 - q.y * sds), gamma * (k2 - q.z * sds), gamma * (k3 - q.w * sds));
+    }
+  }
+  qdot += __shfl_xor(qdot, 16);
+  qdot += __shfl_xor(qdot, 32);
+  qsq += __shfl_xor(qsq, 16);
+  qsq += __shfl_xor(qsq, 32);
+  const float skn = __shfl(dqk[0][2], n + 16);              // row m = 6 (kk = 1, r = 2) of tile q = 0
+  if (kk == 0 && row_ok) {
+    const float dgam = -0.5f * (qsq * sds + skn - 2.f * qdot);
+    const float sig = hwv > 20.f ? 1.f : 1.f / (1.f + expf(-hwv));
+    a.hw_part[rg * H + h] = dgam * gscale * sig;
+  }
+}
+
 }  // namespace
 
 extern "C" int fd_ipa_flash_fwd(const float* proj, const float* zb, const float* qp, const float* kp, const float* vp,
@@ -484,4 +824,25 @@ extern "C" int fd_ipa_flash_fwd(const float* proj, const float* zb, const float*
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_flash_fwd_kernel<2>), grid, dim3(128), 0, (hipStream_t)stream, a);
   FD_CHECK_LAUNCH("fd_ipa_flash_fwd");
   return FD_OK;
+}
+
+extern "C" int fd_ipa_flash_bwd(const float* proj, const float* A, const float* zb, const float* dfeats, const float* feats,
+                                const float* doptg, const float* ptdot, const float* qp, const float* kp, const float* vp,
+                                const float* head_w, const float* trans, float* dL, float* dzb, float* dqp, float* dkp,
+                                float* dhead_w, float* hw_part, int B, int N, void* stream) {
+  FD_CHECK_ARG(N <= MAXN, "fd_ipa_flash_bwd: N=%d exceeds %d", N, MAXN);
+  FD_CHECK_ARG(fd_aligned16(proj) && fd_aligned16(A) && fd_aligned16(zb) && fd_aligned16(dfeats) && fd_aligned16(feats) &&
+                   fd_aligned16(doptg) && fd_aligned16(qp) && fd_aligned16(kp) && fd_aligned16(vp) && fd_aligned16(dL) &&
+                   fd_aligned16(dzb) && fd_aligned16(dqp),
+               "fd_ipa_flash_bwd: tensor arguments must be 16-byte aligned");
+  if (B == 0 || N == 0) return FD_OK;
+  const long tiles = (long)B * ((N + TI - 1) / TI);
+  FlashBwdArgs a{proj, A, zb, dfeats, feats, doptg, ptdot, qp, kp, vp, head_w, trans, dL, dzb, dqp, hw_part, B, N};
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_flash_bwd_kernel<8>), dim3((unsigned)tiles), dim3(512), 0, (hipStream_t)stream, a);
+  FD_CHECK_LAUNCH("fd_ipa_flash_bwd");
+  {
+    int rc = fd_colsum_acc(hw_part, H, (long)B * N, H, dhead_w, stream);
+    if (rc != FD_OK) return rc;
+  }
+  return fd_ipa_kpts_bwd(dL, qp, kp, head_w, dkp, B, N, stream);
 }

@@ -303,7 +303,8 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None, out_view
              and (lib().is_device or opts.flash_ipa_min_tiles <= 0))
     # (the copy serves fd_ipa_attn_fwd/bwd only: the unfused softmax kernels, the fused pair pass and the flash kernel read kp)
     kpT = empty((B, H, PQ * 3, N), dev) if opts.fused_ipa_attn and (train or not flash) else None
-    lib().call("fd_ipa_points_fwd", proj, quat, trans, qp, kp, vp, kpT, N, R, H, C, PQ, PV)
+    par = (not train) and not flash            # sampling, launch sequence: independent launches on a second graph branch
+    ops.fork(lambda: lib().call("fd_ipa_points_fwd", proj, quat, trans, qp, kp, vp, kpT, N, R, H, C, PQ, PV), proj, par)
     W40, b40 = ipa_w40(P, pre, cache)
     L = lib()
     feats = empty((R, LDF), dev)
@@ -321,19 +322,26 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None, out_view
         A = empty((B, H, N, N), dev)
         L.gemm(proj, proj, A, N, N, C, (LDP, 1), (1, LDP), N, b_off=2048, batch=B * H, bdiv=H,
                a_bs=(N * LDP, C), b_bs=(N * LDP, 2 * C), c_bs=(H * N * N, N * N), alpha=math.sqrt(1.0 / (3 * C)))
+        if par:
+            ops.join(proj)                     # the points (and whatever else the branch carried) are there
         if fused_attn:
             # logits + softmax (A in place) + o_pair (the pair part of feats) of every query row in one launch
             L.call("fd_ipa_attn_fwd", A, zb, qp, kp, kpT, P[f"{pre}.head_weights"], mask, feats, B, N)
         else:
             L.call("fd_ipa_softmax_fwd", A, zb, qp, kp, P[f"{pre}.head_weights"], mask, B, N)
+        optg = empty((R, H, PV * 3), dev)
+
+        def _pts():                            # a v_pts and o_pt: other columns of feats than a v
+            L.gemm(A, vp, optg, N, PV * 3, N, (N, 1), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
+                   a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
+            L.call("fd_ipa_opt_fwd", optg, quat, trans, feats, R)
+        ops.fork(_pts, proj, par)
         L.gemm(A, proj, feats, N, C, N, (N, 1), (LDP, 1), LDF, b_off=2048 + C, batch=B * H, bdiv=H,
                a_bs=(H * N * N, N * N), b_bs=(N * LDP, 2 * C), c_bs=(N * LDF, C))
-        optg = empty((R, H, PV * 3), dev)
-        L.gemm(A, vp, optg, N, PV * 3, N, (N, 1), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
-               a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
-        L.call("fd_ipa_opt_fwd", optg, quat, trans, feats, R)
         if not fused_attn:
             L.call("fd_ipa_opair_fwd", A, zb, feats, B, N)
+        if par:
+            ops.join(proj)
     # out_view (a matrix view, sampling): x1 goes straight into the [R, 320] buffer whose columns 256.. take skip_embed -- the
     # operand of the first transformer layer's in_proj, which then normalises the first 256 columns itself (trunk.forward)
     x1 = empty((R, CS), dev) if out_view is None else out_view[0]
@@ -363,31 +371,43 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True, defer_dz=Fal
     dfeats = empty((R, LDF), dev)
     ops.linear_dx(mv(dm), mv(P[f"{pre}.linear_out.weight"]), mv(dfeats), R, CS, LDF)
     dproj = zeros((R, LDP), dev)
-    # dA = dO V^T ; dV = A^T dO
-    dA = empty((B, H, N, N), dev)
-    L.gemm(dfeats, proj, dA, N, N, C, (LDF, 1), (1, LDP), N, b_off=2048 + C, batch=B * H, bdiv=H,
-           a_bs=(N * LDF, C), b_bs=(N * LDP, 2 * C), c_bs=(H * N * N, N * N))
-    L.gemm(A, dfeats, dproj, N, C, N, (1, N), (LDF, 1), LDP, c_off=2048 + C, batch=B * H, bdiv=H,
-           a_bs=(H * N * N, N * N), b_bs=(N * LDF, C), c_bs=(N * LDP, 2 * C))
-    # o_pt
-    doptg = empty((R, H, PV * 3), dev)
-    L.call("fd_ipa_opt_bwd", dfeats, feats, quat, doptg, dframe, R)
-    L.gemm(doptg, vp, dA, N, N, PV * 3, (H * PV * 3, 1), (1, H * PV * 3), N, batch=B * H, bdiv=H,
-           a_bs=(N * H * PV * 3, PV * 3), b_bs=(N * H * PV * 3, PV * 3), c_bs=(H * N * N, N * N), beta=True)
-    dvp = empty((R, H, PV * 3), dev)
-    L.gemm(A, doptg, dvp, N, PV * 3, N, (1, N), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
-           a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
     dqp = empty((R, H, PQ * 3), dev); dkp = empty((R, H, PQ * 3), dev)
     dhw = G[f"{pre}.head_weights"] if G is not None else zeros((H,), dev)
     hw_part = empty((R, H), dev)
-    # o_pair backward + softmax backward (dA becomes dLogits) + point / bias / head-weight grads
     dzb = empty((Pn, ZB), dev)
-    if sv["fused_attn"]:
-        L.call("fd_ipa_attn_bwd", A, dA, zb, dfeats, qp, kp, sv["kpT"], P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw,
-               hw_part, B, N)
+    doptg = empty((R, H, PV * 3), dev)
+    flash = (opts.flash_ipa_bwd and B * ((N + 15) // 16) >= opts.flash_ipa_min_tiles and N <= 1024
+             and (L.is_device or opts.flash_ipa_min_tiles <= 0))
+    if flash:
+        # query side in one launch: dL = A (dP - D) with dP = dO V^T + dOpt vpts^T + dout . zd formed tile by tile on the MFMA
+        # (no dA in HBM), dzb, dqp, head-weight gradient; dkp from dL as before
+        ptdot = empty((R, H), dev)
+        L.call("fd_ipa_opt_bwd_dot", dfeats, feats, quat, sv["trans"], doptg, dframe, ptdot, R)
+        dA = empty((B, H, N, N), dev)          # receives dL
+        L.call("fd_ipa_flash_bwd", proj, A, zb, dfeats, feats, doptg, ptdot, qp, kp, vp, P[f"{pre}.head_weights"], sv["trans"],
+               dA, dzb, dqp, dkp, dhw, hw_part, B, N)
     else:
-        L.call("fd_ipa_opair_bwd", A, zb, dfeats, dA, dzb, B, N)
-        L.call("fd_ipa_softmax_bwd", A, dA, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, hw_part, B, N)
+        # dA = dO V^T
+        dA = empty((B, H, N, N), dev)
+        L.gemm(dfeats, proj, dA, N, N, C, (LDF, 1), (1, LDP), N, b_off=2048 + C, batch=B * H, bdiv=H,
+               a_bs=(N * LDF, C), b_bs=(N * LDP, 2 * C), c_bs=(H * N * N, N * N))
+        # o_pt
+        L.call("fd_ipa_opt_bwd", dfeats, feats, quat, doptg, dframe, R)
+        L.gemm(doptg, vp, dA, N, N, PV * 3, (H * PV * 3, 1), (1, H * PV * 3), N, batch=B * H, bdiv=H,
+               a_bs=(N * H * PV * 3, PV * 3), b_bs=(N * H * PV * 3, PV * 3), c_bs=(H * N * N, N * N), beta=True)
+        # o_pair backward + softmax backward (dA becomes dLogits) + point / bias / head-weight grads
+        if sv["fused_attn"]:
+            L.call("fd_ipa_attn_bwd", A, dA, zb, dfeats, qp, kp, sv["kpT"], P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw,
+                   hw_part, B, N)
+        else:
+            L.call("fd_ipa_opair_bwd", A, zb, dfeats, dA, dzb, B, N)
+            L.call("fd_ipa_softmax_bwd", A, dA, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, hw_part, B, N)
+    # dV = A^T dO ; dvp = A^T dOpt
+    L.gemm(A, dfeats, dproj, N, C, N, (1, N), (LDF, 1), LDP, c_off=2048 + C, batch=B * H, bdiv=H,
+           a_bs=(H * N * N, N * N), b_bs=(N * LDF, C), c_bs=(N * LDP, 2 * C))
+    dvp = empty((R, H, PV * 3), dev)
+    L.gemm(A, doptg, dvp, N, PV * 3, N, (1, N), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
+           a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
     sc = math.sqrt(1.0 / (3 * C))
     # dQ = sc * dL K ; dK = sc * dL^T Q
     L.gemm(dA, proj, dproj, N, C, N, (N, 1), (LDP, 1), LDP, b_off=2048, batch=B * H, bdiv=H,

@@ -175,6 +175,43 @@ def join_grad_stream():
         _SIDE["used"] = False
 
 
+# ---------------------------------------------------------------------------
+# fork / join for the sampling forward.  A lone backbone's forward is ~146 dependent launches of 5-12 us; a handful of them
+# do not depend on their neighbours (skip_embed of a block, the IPA point rotation beside q k^T, a v_pts + o_pt beside a v,
+# the backbone update beside the edge transition).  fork(fn, like) runs fn() on a second stream that first waits for the
+# current one; join(like) makes the current stream wait for it.  Under hipGraph capture (sampler.sample, use_graph) the
+# pair becomes two edges of the graph and the branch runs beside the main chain.  fn (and with it every tensor its
+# closure holds) stays referenced until the join.  Same single-caller contract as side().
+# ---------------------------------------------------------------------------
+_FORK = {"streams": {}, "pending": []}
+
+
+def fork_ok(like):
+    return bool(opts.graph_fork and like.is_cuda and lib().is_device)
+
+
+def fork(fn, like, enable=True):
+    if not (enable and fork_ok(like)):
+        fn()
+        return
+    key = like.device.index
+    st = _FORK["streams"].get(key)
+    if st is None:
+        st = _FORK["streams"][key] = torch.cuda.Stream(device=like.device)
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        fn()
+    _FORK["pending"].append((key, fn))
+
+
+def join(like=None):
+    if _FORK["pending"]:
+        cur = torch.cuda.current_stream()
+        for key in {k for k, _ in _FORK["pending"]}:
+            cur.wait_stream(_FORK["streams"][key])
+        _FORK["pending"].clear()
+
+
 # smallest K_in that sends an N_out = 128 pair-row weight gradient to the 128-row split-bf16 tile (256: the edge
 # transition's; 96 would add the edge embedder's 128 x 128 / 128 x 120 layers, measured slower)
 _DW_T6_MIN_K = 256

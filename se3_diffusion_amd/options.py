@@ -54,6 +54,8 @@ class Options:
                                       # (fd_ipa_flash_fwd: the probabilities never reach HBM in inference) ...
     flash_ipa_min_tiles: int = 96     # FD_IPA_FLASH_MIN_TILES: ... from this many 16-row query tiles (B * ceil(N / 16)) up: a lone
                                       # backbone has too few tiles to fill the CUs and keeps the launch sequence
+    flash_ipa_bwd: bool = True        # FD_IPA_FLASH_BWD: the query side of IPA's attention backward in one launch (fd_ipa_flash_bwd: no dA
+                                      # in HBM) instead of two batched GEMMs + fd_ipa_attn_bwd's per-row kernel; same size rule
     flash_ipa_hpb: int = 0            # FD_IPA_FLASH_HPB: heads per block of that kernel (0 = by size, 8 / 4 / 2)
     proj_merge: bool = True           # FD_PROJ_MERGE: IPA's four projections of s as one GEMM over back-to-back weights
     # -- node level
@@ -63,6 +65,10 @@ class Options:
     node_dw_blocks: int = 0           # FD_NODE_DW_BLOCKS: its persistent blocks (0 = 512: two per CU)
     ln_fold: bool = True              # FD_LN_FOLD: sampling -- the sequence transformer's LayerNorms inside the GEMM launches that
                                       # consume them (fd_ln_gemm) instead of launches of their own
+    graph_fork: bool = False          # FD_GRAPH_FORK (measured, OFF: 1.33-1.40 against 1.61 backbones/s at N=128, 1.06-1.09 against 1.23 at
+                                      # N=256 -- a cross-queue edge of the hipGraph costs ~20 us, more than the 5-12 us launch it hides): sampling -- launches that do not depend on each other (skip_embed, the IPA point
+                                      # rotation beside q k^T, a v_pts + o_pt beside a v, the backbone update beside the edge transition) go to a
+                                      # second stream and join before their consumer: parallel branches of the captured hipGraph
     # -- backward bookkeeping
     zero_arena: bool = True           # FD_ZERO_ARENA: one memset for every zero-initialised accumulator of a backward pass
     dx_splitk: bool = True            # FD_DX_SPLITK: accumulating dX GEMMs with a long reduction split over K (atomics)
@@ -80,11 +86,12 @@ class Options:
             fold_node_terms=_flag("FD_FOLD_NODE_TERMS", True),
             fused_ipa_attn=_flag("FD_IPA_ATTN_FUSED", True),
             flash_ipa=_flag("FD_IPA_FLASH", True), flash_ipa_min_tiles=_int("FD_IPA_FLASH_MIN_TILES", 96),
-            flash_ipa_hpb=_int("FD_IPA_FLASH_HPB", 0),
+            flash_ipa_hpb=_int("FD_IPA_FLASH_HPB", 0), flash_ipa_bwd=_flag("FD_IPA_FLASH_BWD", True),
             proj_merge=_flag("FD_PROJ_MERGE", True),
             fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),
             grouped_node_dw=_flag("FD_NODE_DW", True), node_dw_blocks=_int("FD_NODE_DW_BLOCKS", 0),
             ln_fold=_flag("FD_LN_FOLD", True),
+            graph_fork=_flag("FD_GRAPH_FORK", False),
             zero_arena=_flag("FD_ZERO_ARENA", True), dx_splitk=_flag("FD_DX_SPLITK", True))
 
 

@@ -69,7 +69,7 @@ def et_folds_node_terms(cache, save):
     return cache is not None and not save and opts.fold_node_terms and fused_edge()
 
 
-def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None, zb_next=None, n3_ln=None):
+def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None, zb_next=None, n3_ln=None, after_terms=None):
     """z' = emask * LN(W_f (relu(W_2 relu(W_1 x)) + x) + b_f), x = [z | e_i | e_j], e = W_init n3 -- the whole pair-level
     chain in ONE launch (fd_edge_mlp): h1 / h2 never reach HBM unless the backward needs them (save).
     zb_next = (W40 [40,128], b40 [40]) of the next block's IPA: its pair projection zb = W40 z' + b40 is formed by the same
@@ -106,6 +106,8 @@ def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None, zb_next
             ops.ln_linear(mv(t_in), g_in, b_in, mv(Wfold), bfold, mv(PQ), R, LDT, CS, ln_rowscale=rs_in, ln_out=mv(n3_out))
         else:
             ops.linear(mv(n3), mv(Wfold), bfold, mv(PQ), R, LDT, CS)
+        if after_terms is not None:
+            after_terms()          # (n3 exists from here on: the caller forks the backbone update beside the pair-level launch)
         P1, Q1, Pf, Qf = PQ[:, 0:], PQ[:, EH:], PQ[:, 2 * EH:], PQ[:, 2 * EH + CZ:]
         kw = dict(ld_pq=LDT, ld_pqf=LDT)
         e = None
@@ -480,6 +482,12 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
         fold1 = (not save) and nl >= 1 and node.is_cuda == z.is_cuda and ops.ln_linear_ok((node, 0, TD), (node, 0, TD), R, 3 * TD, TD)
         fold6 = fold1 and b < num_blocks - 1 and et_folds_node_terms(cache, save)
         cat = empty((R, TD), dev) if fold1 else None
+        ops.join(node)          # the backbone update of the block in front (sampling: a second graph branch)
+        if fold1:
+            # skip_embed depends on nothing but the embedder's output: beside the IPA launches (its own columns of `cat`)
+            tp = "score_model.trunk"
+            ops.fork(lambda: ops.linear(mv(init_node), mv(P[f"{tp}.skip_embed_{b}.weight"]), P[f"{tp}.skip_embed_{b}.bias"],
+                                        (cat, CS, TD), R, 64, CS), node)
         with rng(f"ipa_{b}.fwd"):
             x1, sv_ipa = nw.ipa_fwd(P, pre, mv(node), z, quat, trans, mask.view(-1), B, N, cache, zb=zb,
                                     out_view=(cat, 0, TD) if fold1 else None, save=save)
@@ -487,7 +495,7 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
             pend_ln = None      # a LayerNorm whose launch is folded into its consumer's (nw.tfmr_layer_fwd)
             if fold1:
                 tp = "score_model.trunk"
-                ops.linear(mv(init_node), mv(P[f"{tp}.skip_embed_{b}.weight"]), P[f"{tp}.skip_embed_{b}.bias"], (cat, CS, TD), R, 64, CS)
+                ops.join(node)
                 u = u0 = empty((R, TD), dev)             # written by the first layer's in_proj launch
                 pend_ln = (cat, P[f"{tp}.ipa_ln_{b}.weight"], P[f"{tp}.ipa_ln_{b}.bias"], None, CS, u0)
                 sv_ln = None
@@ -509,11 +517,14 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
         if fold6:
             n3_ln, sv_pn = sv_pn, None
             n3 = n3_ln[5]
+            # the backbone update needs the block's node output only: beside the edge transition, joined by the next block
+            bbo = {}
             with rng(f"edge_transition_{b}.fwd"):
-                z, sv_et, zb = edge_transition_fwd(P, b, None, z, emask, B, N, save=save, cache=cache,
-                                                   zb_next=nw.ipa_w40(P, f"score_model.trunk.ipa_{b + 1}", cache), n3_ln=n3_ln)
-            with rng(f"node_transition_{b}.fwd"):
-                q2, t2, sv_bb = bb_update_fwd(P, b, n3, dmask.view(-1), quat, trans, R)
+                z, sv_et, zb = edge_transition_fwd(
+                    P, b, None, z, emask, B, N, save=save, cache=cache,
+                    zb_next=nw.ipa_w40(P, f"score_model.trunk.ipa_{b + 1}", cache), n3_ln=n3_ln,
+                    after_terms=lambda: ops.fork(lambda: bbo.update(r=bb_update_fwd(P, b, n3, dmask.view(-1), quat, trans, R)), node))
+            q2, t2, sv_bb = bbo["r"]
         else:
             with rng(f"node_transition_{b}.fwd"):
                 q2, t2, sv_bb = bb_update_fwd(P, b, n3, dmask.view(-1), quat, trans, R)
@@ -525,6 +536,7 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
         node, quat, trans = n3, q2, t2
         if not save:
             stages[-1] = None
+    ops.join(node)
     with rng("heads.fwd"):
         out, sv_h = heads_fwd(P, node, quat, trans, f, B, N, dconf)
     if not save:

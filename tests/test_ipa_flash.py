@@ -150,3 +150,76 @@ def test_ipa_flash_fwd_gpu(hip_lib):
                                           (1, 256, 4, 0, 1.2), (1, 257, 5, 8, 1.2), (2, 400, 6, 0, 1.5), (1, 512, 7, 8, 1.5),
                                           (1, 600, 8, 8, 1.5)):
             _run("cuda", B, N, seed, hpb=hpb, spread=spread, log=log)
+
+
+# ------------------------------------------------------------------------------------------------------------------- backward
+def _bwd_sequence(L, proj, quat, zb, hw, qp, kp, vp, kpT, A, feats, dfeats, B, N):
+    """network.ipa_bwd's launches between dfeats and (dL, dzb, dqp, dkp, dhead_w): dA = dO V^T, fd_ipa_opt_bwd,
+    dA += dOpt vpts^T, fd_ipa_attn_bwd."""
+    R = B * N
+    dev = proj.device
+    dA = torch.empty(B, H, N, N, device=dev)
+    L.gemm(dfeats, proj, dA, N, N, C, (LDF, 1), (1, LDP), N, b_off=2048 + C, batch=B * H, bdiv=H,
+           a_bs=(N * LDF, C), b_bs=(N * LDP, 2 * C), c_bs=(H * N * N, N * N))
+    doptg = torch.empty(R, H, PV * 3, device=dev)
+    dframe = torch.zeros(R, 12, device=dev)
+    L.call("fd_ipa_opt_bwd", dfeats, feats, quat, doptg, dframe, R)
+    L.gemm(doptg, vp, dA, N, N, PV * 3, (H * PV * 3, 1), (1, H * PV * 3), N, batch=B * H, bdiv=H,
+           a_bs=(N * H * PV * 3, PV * 3), b_bs=(N * H * PV * 3, PV * 3), c_bs=(H * N * N, N * N), beta=True)
+    dzb = torch.empty(R * N, ZB, device=dev)
+    dqp = torch.empty(R, H, PQ * 3, device=dev); dkp = torch.empty(R, H, PQ * 3, device=dev)
+    dhw = torch.zeros(H, device=dev); part = torch.empty(R, H, device=dev)
+    L.call("fd_ipa_attn_bwd", A, dA, zb, dfeats, qp, kp, kpT, hw, dzb, dqp, dkp, dhw, part, B, N)
+    return dict(dL=dA, dzb=dzb, dqp=dqp, dkp=dkp, dhw=dhw, dframe=dframe)
+
+
+def _bwd_flash(L, proj, quat, trans, zb, hw, qp, kp, vp, A, feats, dfeats, B, N, poison=True):
+    R = B * N
+    dev = proj.device
+    doptg = torch.empty(R, H, PV * 3, device=dev)
+    dframe = torch.zeros(R, 12, device=dev)
+    ptdot = torch.empty(R, H, device=dev)
+    L.call("fd_ipa_opt_bwd_dot", dfeats, feats, quat, trans, doptg, dframe, ptdot, R)
+    # (poison: every element of the outputs must be written; the microbenchmark allocates like the launch sequence instead)
+    new = (lambda *sh: torch.full(sh, float("nan"), device=dev)) if poison else (lambda *sh: torch.empty(sh, device=dev))
+    dL = new(B, H, N, N)
+    dzb = new(R * N, ZB)
+    dqp = new(R, H, PQ * 3); dkp = new(R, H, PQ * 3)
+    dhw = torch.zeros(H, device=dev); part = torch.empty(R, H, device=dev)
+    L.call("fd_ipa_flash_bwd", proj, A, zb, dfeats, feats, doptg, ptdot, qp, kp, vp, hw, trans, dL, dzb, dqp, dkp, dhw, part, B, N)
+    return dict(dL=dL, dzb=dzb, dqp=dqp, dkp=dkp, dhw=dhw, dframe=dframe)
+
+
+def _run_bwd(dev, B, N, seed, spread=1.0, tol=2e-5, log=False):
+    L = ops.lib()
+    proj, quat, trans, zb, hw, mask = _inputs(dev, B, N, seed, spread)
+    qp, kp, vp, kpT = _points(L, proj, quat, trans, B, N)
+    feats, A = _sequence(L, proj, quat, trans, zb, hw, mask, qp, kp, vp, kpT, B, N)
+    g = torch.Generator().manual_seed(seed + 100)
+    dfeats = torch.randn(B * N, LDF, generator=g).to(dev)
+    ref = _bwd_sequence(L, proj, quat, zb, hw, qp, kp, vp, kpT, A, feats, dfeats, B, N)
+    out = _bwd_flash(L, proj, quat, trans, zb, hw, qp, kp, vp, A, feats, dfeats, B, N)
+    errs = {}
+    for k in ref:
+        assert bool(torch.isfinite(out[k]).all()), k
+        sc = float(ref[k].abs().max()) + 1e-30
+        errs[k] = float((out[k] - ref[k]).abs().max()) / sc
+        if log:
+            parity_log.out(f"flash_bwd.{k}", errs[k])
+    for k, e in errs.items():
+        assert e < tol, (k, e, errs)
+    return errs
+
+
+def test_ipa_flash_bwd_emu(use_emu):
+    _run_bwd("cpu", 1, 12, 0)
+    _run_bwd("cpu", 2, 37, 1)
+    _run_bwd("cpu", 1, 18, 2)            # N % 4 != 0: scalar rows of A / dL
+
+
+@pytest.mark.gpu
+def test_ipa_flash_bwd_gpu(hip_lib):
+    with parity_log.case("ipa_flash_bwd"):
+        for (B, N, seed, spread) in ((2, 128, 0, 1.0), (3, 100, 1, 1.0), (1, 256, 2, 1.2), (1, 257, 3, 1.2), (2, 400, 4, 1.5),
+                                     (1, 512, 5, 1.5)):
+            _run_bwd("cuda", B, N, seed, spread=spread, log=True)

@@ -67,8 +67,8 @@ def case(B, N, hpbs, spread=1.0):
 
 # compile-time variants of the kernel (prefetch distances, scheduling pins): second copies of the library with
 # fd_ipa_flash.hip recompiled under -D flags, built in the build container (`--build`) so that they travel with gpurun
-VARIANTS = {"abl_nobar": ["-DFL_ABL_NOBAR"], "abl_nokv_nodma": ["-DFL_ABL_NODMA", "-DFL_ABL_NOKV"], "abl_nokv_nodma_nobar": ["-DFL_ABL_NODMA", "-DFL_ABL_NOKV", "-DFL_ABL_NOBAR"],
-            "abl_all": ["-DFL_ABL_NODMA", "-DFL_ABL_NOKV", "-DFL_ABL_NOPAIR", "-DFL_ABL_NOSM"]}
+VARIANTS = {"abl_nodzb": ["-DFL_ABL_NODZB"], "abl_nopts": ["-DFL_ABL_NOPTS"], "abl_nodma": ["-DFL_ABL_NODMA"], "abl_nokv": ["-DFL_ABL_NOKV"],
+            "abl_nobar": ["-DFL_ABL_NOBAR"], "abl_all": ["-DFL_ABL_NODMA", "-DFL_ABL_NOKV", "-DFL_ABL_NODZB", "-DFL_ABL_NOPTS"]}
 PROBES = os.path.join(ROOT, "tools", "probes")
 
 
@@ -109,7 +109,62 @@ def variants(B, N, hpb, spread=1.0):
     print(" | ".join(line), flush=True)
 
 
+def case_bwd(B, N, spread=1.0):
+    """the query side of the backward: dA GEMM + fd_ipa_opt_bwd + dA += GEMM + fd_ipa_attn_bwd against fd_ipa_opt_bwd_dot +
+    fd_ipa_flash_bwd (both include the head-weight column sum and fd_ipa_kpts_bwd)"""
+    L = ops.lib()
+    dev = "cuda"
+    proj, quat, trans, zb, hw, mask = T._inputs(dev, B, N, 0, spread, masked=False)
+    qp, kp, vp, kpT = T._points(L, proj, quat, trans, B, N)
+    feats, A = T._sequence(L, proj, quat, trans, zb, hw, mask, qp, kp, vp, kpT, B, N)
+    dfeats = torch.randn(B * N, T.LDF, device=dev)
+    t_seq = timeit(lambda: T._bwd_sequence(L, proj, quat, zb, hw, qp, kp, vp, kpT, A, feats, dfeats, B, N))
+    t_fl = timeit(lambda: T._bwd_flash(L, proj, quat, trans, zb, hw, qp, kp, vp, A, feats, dfeats, B, N, poison=False))
+    ref = T._bwd_sequence(L, proj, quat, zb, hw, qp, kp, vp, kpT, A, feats, dfeats, B, N)
+    out = T._bwd_flash(L, proj, quat, trans, zb, hw, qp, kp, vp, A, feats, dfeats, B, N)
+    err = {k: float((out[k] - ref[k]).abs().max() / (ref[k].abs().max() + 1e-30)) for k in ref}
+    print(f"B={B:3d} N={N:4d} backward, query side: sequence {t_seq:8.1f} us | flash {t_fl:8.1f} us | maxdiff "
+          + " ".join(f"{k} {v:.1e}" for k, v in err.items()), flush=True)
+
+
+def variants_bwd(B, N, spread=1.0):
+    from se3_diffusion_amd import hip
+    dev = "cuda"
+    L0 = ops.lib()
+    proj, quat, trans, zb, hw, mask = T._inputs(dev, B, N, 0, spread, masked=False)
+    qp, kp, vp, kpT = T._points(L0, proj, quat, trans, B, N)
+    feats, A = T._sequence(L0, proj, quat, trans, zb, hw, mask, qp, kp, vp, kpT, B, N)
+    dfeats = torch.randn(B * N, T.LDF, device=dev)
+    R = B * N
+    doptg = torch.empty(R, T.H, T.PV * 3, device=dev); dframe = torch.zeros(R, 12, device=dev); ptdot = torch.empty(R, T.H, device=dev)
+    L0.call("fd_ipa_opt_bwd_dot", dfeats, feats, quat, trans, doptg, dframe, ptdot, R)
+    dL = torch.empty(B, T.H, N, N, device=dev); dzb = torch.empty(R * N, T.ZB, device=dev)
+    dqp = torch.empty(R, T.H, 24, device=dev); dkp = torch.empty(R, T.H, 24, device=dev)
+    dhw = torch.zeros(T.H, device=dev); part = torch.empty(R, T.H, device=dev)
+    line = [f"B={B:3d} N={N:4d} fd_ipa_flash_bwd (incl. column sum + fd_ipa_kpts_bwd)"]
+    for tag in ["shipped"] + sorted(VARIANTS):
+        path = hip.LIB_PATH if tag == "shipped" else os.path.join(PROBES, f"libfd_flash_{tag}.so")
+        if not os.path.exists(path):
+            continue
+        L = hip.FdLib(path)
+        t = timeit(lambda: L.call("fd_ipa_flash_bwd", proj, A, zb, dfeats, feats, doptg, ptdot, qp, kp, vp, hw, trans, dL, dzb, dqp,
+                                  dkp, dhw, part, B, N))
+        line.append(f"{tag} {t:7.1f} us")
+    t = timeit(lambda: L0.call("fd_ipa_kpts_bwd", dL, qp, kp, hw, dkp, B, N))
+    line.append(f"(fd_ipa_kpts_bwd alone {t:6.1f} us)")
+    print(" | ".join(line), flush=True)
+
+
 def main():
+    if "--variants-bwd" in sys.argv:
+        variants_bwd(30, 128)
+        variants_bwd(8, 512, spread=1.5)
+        return
+    if "--bwd" in sys.argv:
+        case_bwd(30, 128)
+        case_bwd(8, 512, spread=1.5)
+        case_bwd(7, 256, spread=1.2)
+        return
     if "--build" in sys.argv:
         build_variants()
         return
