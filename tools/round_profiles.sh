@@ -17,6 +17,7 @@ python tools/bench_pair_dw.py > $O/pair_dw_microbench.log 2>&1
 python tools/bench_group_dw.py > $O/group_dw_microbench.log 2>&1
 python tools/bench_embed_bwd.py > $O/embed_bwd_microbench.log 2>&1
 python tools/bench_ipa_attn.py 30 128 > $O/ipa_attn_microbench.log 2>&1
+(timeout 200 python tools/bench_ipa_flash.py; timeout 200 python tools/bench_ipa_flash.py --bwd) > $O/ipa_flash_microbench.log 2>&1
 python tools/bench_gemm.py --only kk --iters 50 > $O/gemm_s64_microbench.log 2>&1
 # per-kernel time of the training step, launches serialised
 FD_BENCH_PROFILE=1 FD_GRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python bench.py --steps 5 --warmup 2 --no-sampling --no-cpu-baseline > $O/kt.log 2>&1
@@ -24,6 +25,8 @@ python tools/kernel_stats_md.py $O/kt/p_kernel_stats.csv "training step B=30 x N
 # sampling forward kernels
 rocprofv3 --kernel-trace --stats -d $O/ks -o p --output-format csv -- python bench.py --mode sample --n-res 128 --batch 1 --num-t 100 --steps 1 --warmup 0 --no-graph > $O/ks.log 2>&1
 python tools/kernel_stats_md.py $O/ks/p_kernel_stats.csv "sampling N=128 B=1, 100 steps, eager launches" > $O/sample_n128_b1_kernel_stats.md
+rocprofv3 --kernel-trace --stats -d $O/ks5 -o p --output-format csv -- python bench.py --mode sample --n-res 512 --batch 8 --num-t 12 --steps 1 --warmup 0 --no-graph > $O/ks5.log 2>&1
+python tools/kernel_stats_md.py $O/ks5/p_kernel_stats.csv "sampling N=512 B=8, 12 steps, eager launches" > $O/sample_n512_b8_kernel_stats.md
 if [ -z "$LITE" ]; then   # (LITE=1: the counter passes are skipped -- kernels unchanged since the last full run)
 bash tools/pmc_roofline.sh ${1:-r04} > $O/pmc_roofline.txt 2>&1      # HBM bytes per kernel of the step, calibrated -> bench.py
 bash tools/pmc_step_sq.sh > $O/pmc_step_sq.txt 2>&1                   # SQ / LDS / clock counters of the big kernels IN the step
