@@ -29,6 +29,14 @@ def _run(dev):
     S, feats = nan(1, 8, 1, 1), nan(1, 2688)
     L.call("fd_ipa_attn_fwd", S, z(1, 40), z(1, 8, 24), z(1, 8, 24), None, z(8), z(1), feats, 0, 1)
     assert torch.isnan(S).all() and torch.isnan(feats).all()
+    feats2, A2 = nan(1, 2688), nan(1, 8, 1, 1)
+    L.call("fd_ipa_flash_fwd", z(1, 6816), z(1, 40), z(1, 8, 24), z(1, 8, 24), z(1, 8, 36), z(8), z(1), z(1, 4), z(1, 3), feats2, A2,
+           0, 1, 0)
+    assert torch.isnan(feats2).all() and torch.isnan(A2).all()
+    dL, dzb, dqp, dkp, dhw = nan(1, 8, 1, 1), nan(1, 40), nan(1, 8, 24), nan(1, 8, 24), nan(8)
+    L.call("fd_ipa_flash_bwd", z(1, 6816), z(1, 8, 1, 1), z(1, 40), z(1, 2688), z(1, 2688), z(1, 8, 36), z(1, 8), z(1, 8, 24),
+           z(1, 8, 24), z(1, 8, 36), z(8), z(1, 3), dL, dzb, dqp, dkp, dhw, z(1, 8), 0, 1)
+    assert all(torch.isnan(t).all() for t in (dL, dzb, dqp, dkp, dhw))
     o = nan(1, 320)
     L.call("fd_seq_attn_fwd", z(1, 960), None, o, None, 1.0, 0, 1)
     assert torch.isnan(o).all()

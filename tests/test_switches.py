@@ -55,6 +55,7 @@ GROUPS = [
     (dict(flash_ipa=False), 1e-4),            # fd_ipa_flash_fwd (probabilities written for the backward) vs the launch sequence
     (dict(flash_ipa_hpb=2), 1e-4),            # (its 2-heads-per-block shape against the default pick)
     (dict(flash_ipa_bwd=False), 1e-4),        # fd_ipa_flash_bwd vs dA GEMMs + fd_ipa_attn_bwd
+    (dict(fused_seq_attn_bwd=True), 1e-4),    # fd_seq_attn_bwd (off by default: slower) vs four batched GEMMs + row-softmax backward
     (dict(zero_arena=False, dx_splitk=False, grad_stream=False), 1e-4),
     (dict(grouped_pair_dw=False), 1e-4),
     (dict(grouped_node_dw=False), 1e-4),
@@ -89,7 +90,7 @@ def test_switches_emu(use_emu):
 
 def test_switches_two_blocks_emu(use_emu):
     # with an edge transition between the blocks: the fused LayerNorm-backward / dzb W40 prologue against the separate kernels
-    _compare("cpu", B=1, N=8, blocks=2, groups=[GROUPS[2], GROUPS[4], GROUPS[10], GROUPS[11], GROUPS[12], GROUPS[13]])
+    _compare("cpu", B=1, N=8, blocks=2, groups=[GROUPS[2], GROUPS[4], GROUPS[5], GROUPS[11], GROUPS[12], GROUPS[13], GROUPS[14]])
 
 
 def _dynamic_vs_static(dev, B, N, blocks):
@@ -133,4 +134,4 @@ def test_options_override_restores():
 @pytest.mark.gpu
 def test_switches_gpu(hip_lib):
     _compare("cuda", B=2, N=24, blocks=2)
-    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:6] + GROUPS[7:15])
+    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:7] + GROUPS[8:16])
