@@ -376,8 +376,8 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True, defer_dz=Fal
     hw_part = empty((R, H), dev)
     dzb = empty((Pn, ZB), dev)
     doptg = empty((R, H, PV * 3), dev)
-    flash = (opts.flash_ipa_bwd and B * ((N + 15) // 16) >= opts.flash_ipa_min_tiles and N <= 1024
-             and (L.is_device or opts.flash_ipa_min_tiles <= 0))
+    flash = (opts.flash_ipa_bwd and B * ((N + 15) // 16) >= opts.flash_ipa_bwd_min_tiles and N <= 1024
+             and (L.is_device or opts.flash_ipa_bwd_min_tiles <= 0))
     if flash:
         # query side in one launch: dL = A (dP - D) with dP = dO V^T + dOpt vpts^T + dout . zd formed tile by tile on the MFMA
         # (no dA in HBM), dzb, dqp, head-weight gradient; dkp from dL as before

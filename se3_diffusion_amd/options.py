@@ -52,10 +52,13 @@ class Options:
     fused_ipa_attn: bool = True       # FD_IPA_ATTN_FUSED: logits + softmax + o_pair of a query row in one launch
     flash_ipa: bool = True            # FD_IPA_FLASH: q k^T, logits, softmax, a v, a v_pts, o_pt and o_pair of a block in ONE launch
                                       # (fd_ipa_flash_fwd: the probabilities never reach HBM in inference) ...
-    flash_ipa_min_tiles: int = 96     # FD_IPA_FLASH_MIN_TILES: ... from this many 16-row query tiles (B * ceil(N / 16)) up: a lone
-                                      # backbone has too few tiles to fill the CUs and keeps the launch sequence
+    flash_ipa_min_tiles: int = 80     # FD_IPA_FLASH_MIN_TILES: ... from this many 16-row query tiles (B * ceil(N / 16)) up: a lone
+                                      # backbone has too few tiles to fill the CUs and keeps the launch sequence (measured: 95 tiles
+                                      # 151 against 180 us with the probabilities written, 75 tiles 192 against 195, 56 tiles 210 against 171)
     flash_ipa_bwd: bool = True        # FD_IPA_FLASH_BWD: the query side of IPA's attention backward in one launch (fd_ipa_flash_bwd: no dA
-                                      # in HBM) instead of two batched GEMMs + fd_ipa_attn_bwd's per-row kernel; same size rule
+                                      # in HBM) instead of two batched GEMMs + fd_ipa_attn_bwd's per-row kernel ...
+    flash_ipa_bwd_min_tiles: int = 128  # FD_IPA_FLASH_BWD_MIN_TILES: ... from this many query tiles up (8 heads per block only: 112 tiles
+                                      # 195 against 199 us, 95 tiles 224 against 207)
     flash_ipa_hpb: int = 0            # FD_IPA_FLASH_HPB: heads per block of that kernel (0 = by size, 8 / 4 / 2)
     proj_merge: bool = True           # FD_PROJ_MERGE: IPA's four projections of s as one GEMM over back-to-back weights
     # -- node level
@@ -88,7 +91,8 @@ class Options:
             fused_ln_bwd=_flag("FD_EDGE_LN_BWD", True), edge_dynamic_tiles=_flag("FD_EDGE_DYN_TILES", True), packed_gates=_flag("FD_PACKED_GATES", True),
             fold_node_terms=_flag("FD_FOLD_NODE_TERMS", True),
             fused_ipa_attn=_flag("FD_IPA_ATTN_FUSED", True),
-            flash_ipa=_flag("FD_IPA_FLASH", True), flash_ipa_min_tiles=_int("FD_IPA_FLASH_MIN_TILES", 96),
+            flash_ipa=_flag("FD_IPA_FLASH", True), flash_ipa_min_tiles=_int("FD_IPA_FLASH_MIN_TILES", 80),
+            flash_ipa_bwd_min_tiles=_int("FD_IPA_FLASH_BWD_MIN_TILES", 128),
             flash_ipa_hpb=_int("FD_IPA_FLASH_HPB", 0), flash_ipa_bwd=_flag("FD_IPA_FLASH_BWD", True),
             proj_merge=_flag("FD_PROJ_MERGE", True),
             fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),

@@ -25,7 +25,7 @@ from se3_diffusion_amd.optim import FlatAdam  # noqa: E402
 
 def _step(dev, B, N, blocks, **kw):
     # (0: the fused sequence attention and the one-launch IPA attention at any size)
-    with options.override(seq_attn_min_rows=0, flash_ipa_min_tiles=0, **kw):
+    with options.override(seq_attn_min_rows=0, flash_ipa_min_tiles=0, flash_ipa_bwd_min_tiles=0, **kw):
         conf = dict(fo.CONF, num_blocks=blocks)
         m = ScoreNetwork(ts.base_model_conf(blocks), diffuser=None)
         m.load_state_dict(fo.synth_params(seed=11, conf=conf), strict=True)
