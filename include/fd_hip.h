@@ -400,6 +400,15 @@ int fd_ipa_attn_bwd(const float* A, float* dA, const float* zb, const float* dfe
 int fd_ipa_flash_fwd(const float* proj, const float* zb, const float* qp, const float* kp, const float* vp,
                      const float* head_w, const float* mask, const float* quat, const float* trans, float* feats,
                      float* A, int B, int N, int heads_per_block, void* stream);
+/* The same with the KEYS of a query tile split over key_splits blocks (inference on a lone backbone: B ceil(N/16) query tiles do
+ * not fill 256 CUs): block ks walks the key tiles [ks nt / key_splits, (ks + 1) nt / key_splits) and leaves unnormalised sums
+ * + (running maximum, denominator) per (split, residue, head) in `part` -- key_splits * B * N * 8 * FD_IPA_FLASH_PART_LD floats,
+ * 16-byte aligned -- and a second launch (one block per residue) combines the splits and writes feats.  key_splits == 1 is
+ * fd_ipa_flash_fwd; A must be null when key_splits > 1. */
+#define FD_IPA_FLASH_PART_LD 328
+int fd_ipa_flash_fwd_split(const float* proj, const float* zb, const float* qp, const float* kp, const float* vp,
+                           const float* head_w, const float* mask, const float* quat, const float* trans, float* feats,
+                           float* A, int B, int N, int heads_per_block, int key_splits, float* part, void* stream);
 
 /* Query side of the IPA attention backward in ONE launch (autograd of model/ipa_pytorch.py:380-457 with the probabilities A
  * saved by the forward) -- replaces  fd_gemm (dA = dO V^T) -> fd_gemm (dA += dOpt vpts^T) -> fd_ipa_attn_bwd's per-row kernel;

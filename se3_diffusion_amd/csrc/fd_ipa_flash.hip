@@ -78,7 +78,13 @@ struct FlashArgs {
   const float *proj, *zb, *qp, *kp, *vp, *head_w, *mask, *quat, *trans;
   float *feats, *A;
   int B, N;
+  // key split (a lone backbone has too few query tiles to fill the chip): KS > 1 blocks share a query tile, block ks walks
+  // the key tiles [ks nti / KS, (ks + 1) nti / KS) and leaves its unnormalised sums + (max, denominator) in
+  // part [KS][R][8][PART_LD]; ipa_flash_merge_kernel combines them.  KS == 1: part unused, the kernel writes feats itself.
+  float* part;
+  int KS;
 };
+constexpr int PART_O = 0, PART_PT = C, PART_PAIR = C + PV * 3, PART_ML = C + PV * 3 + CZ4, PART_LD = 328;
 
 struct Rot { float r[9]; };
 __device__ __forceinline__ Rot quat_to_rot(const float* __restrict__ q) {
@@ -138,8 +144,10 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
 
   const int N = a.N;
   const int nti = (N + TI - 1) / TI;
-  const int lid = fd_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+  const int lid0 = fd_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+  const int KS = a.KS, ksi = lid0 % KS, lid = lid0 / KS;
   const int g = lid % NG, it = (lid / NG) % nti, b = lid / (NG * nti);
+  const int t0 = (int)((long)ksi * nti / KS), t1 = (int)((long)(ksi + 1) * nti / KS);      // this block's key tiles
   const int lane = fd::lane_id();
   const int wave = fd::uniform(fd::wave_id());     // (wave-uniform: the head's pointers live in SGPRs)
   const int n = lane & 15, kk = lane >> 4;
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
   for (int k = 0; k < NI; ++k) {
     const int inst = wave * NI + k;
     poff[k] = piece_off(inst * 64 + lane, i0, N);
-    if (inst < STAGE_INSTR) FL_DMA(zb_b + umin(poff[k], plim), slab + inst * 1024);
+    if (inst < STAGE_INSTR) FL_DMA(zb_b + umin(poff[k] + (unsigned)t0 * (TI * ZB), plim), slab + (t0 & 1) * STAGE_BYTES + inst * 1024);
   }
 
   // ---- per-wave operands that stay in registers
@@ -209,14 +217,14 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
 #endif
   const float* __restrict__ vpb = a.vp + (rb * H + h) * (PV * 3);
   {
-    const float* kr = kbase + (unsigned)(imin(n, N - 1) * LDP + 4 * kk);
+    const float* kr = kbase + (unsigned)(imin(TI * t0 + n, N - 1) * LDP + 4 * kk);
 #pragma unroll
     for (int cc = 0; cc < KPF; ++cc) kf[cc] = ldkv(kr + 16 * cc);
   }
 
   // the copy of the next key tile's zb image (its stage was last read in the o_pair phase of tile t - 1)
   auto next_stage = [&](int t) {
-    if (t + 1 < nti) {
+    if (t + 1 < t1) {
 #pragma unroll
       for (int k = 0; k < NI; ++k) {
         const int inst = wave * NI + k;
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
 #define FL_NEXT_STAGE() next_stage(t)
 
 #pragma unroll 1
-  for (int t = 0; t < nti; ++t) {
+  for (int t = t0; t < t1; ++t) {
     fd::wait_vmem();
     FL_SYNC();                 // stage t of the image has landed; every wave is done with tile t - 1 (its stage, Es, Fs)
 #ifndef FL_DMA_MID
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
       FL_PIN();
     }
     // the next key tile's first K fragments (in flight across the barrier and the o_pair phase)
-    if (t + 1 < nti) {
+    if (t + 1 < t1) {
       const float* kr = kbase + (unsigned)(imin(j0 + TI + n, N - 1) * LDP + 4 * kk);
 #pragma unroll
       for (int cc = 0; cc < KPF; ++cc) kf[cc] = ldkv(kr + 16 * cc);
@@ -393,6 +401,39 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
 #endif
   }
 
+  // ---- key split: unnormalised sums + (max, denominator) to the workspace; the merge launch finishes the job
+  if (KS > 1) {
+    if (row_ok) {
+      float* __restrict__ po = a.part + (((long)ksi * a.B * N + rg) * H + h) * PART_LD;
+#pragma unroll
+      for (int cb4 = 0; cb4 < 4; ++cb4)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<float4*>(po + PART_O + 64 * cb4 + 16 * kk + 4 * r) =
+              make_float4(O[4 * cb4][r], O[4 * cb4 + 1][r], O[4 * cb4 + 2][r], O[4 * cb4 + 3][r]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * kk + r < 9)
+          *reinterpret_cast<float4*>(po + PART_PT + 16 * kk + 4 * r) = make_float4(OP[0][r], OP[1][r], OP[2][r], OP[3][r]);
+      if (kk == 0) { po[PART_ML] = m_run; po[PART_ML + 1] = l_run; }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int i = wave * RPW + rr;
+      if (i0 + i < N) {
+        float* __restrict__ pp = a.part + (((long)ksi * a.B * N + rb + i0 + i) * H + g * HPB) * PART_LD + PART_PAIR + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int hl = 4 * kk + r;
+          if (hl < HPB) {
+            pp[hl * PART_LD] = PA[rr][0][r];
+            pp[hl * PART_LD + 16] = PA[rr][1][r];
+          }
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue
   const float inv = 1.0f / l_run;
   if (kk == 0) Ls[n][wave] = inv;
@@ -458,6 +499,47 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
   }
 }
 
+
+// Key-split epilogue: one block per residue, thread groups of 32 per head.  part [KS][R][8][PART_LD] ->
+// feats [R, 2688] (o, o_pt + norm in the residue's frame, o_pair).
+__global__ __launch_bounds__(256) void ipa_flash_merge_kernel(const float* __restrict__ part, const float* __restrict__ quat,
+                                                              const float* __restrict__ trans, float* __restrict__ feats,
+                                                              long R_, int KS) {
+  __shared__ float og[H][PV * 3];
+  const long r = blockIdx.x;
+  const int h = (int)threadIdx.x >> 5, l = (int)threadIdx.x & 31;
+  const float* __restrict__ p0 = part + (r * H + h) * PART_LD;
+  const long ks_stride = R_ * H * PART_LD;
+  float M = -INFINITY;
+  for (int k = 0; k < KS; ++k) M = fmaxf(M, p0[k * ks_stride + PART_ML]);
+  float L = 0.f;
+  for (int k = 0; k < KS; ++k) L += expf(p0[k * ks_stride + PART_ML] - M) * p0[k * ks_stride + PART_ML + 1];
+  const float inv = 1.0f / L;
+  float* __restrict__ f = feats + r * LDF;
+  // 324 values per head (256 o | 36 o_pt sums | 32 o_pair): lane l takes l, l + 32, ...
+  for (int e = l; e < PART_ML; e += 32) {
+    float acc = 0.f;
+    for (int k = 0; k < KS; ++k) acc += expf(p0[k * ks_stride + PART_ML] - M) * p0[k * ks_stride + e];
+    acc *= inv;
+    if (e < PART_PT) f[h * C + e] = acc;
+    else if (e < PART_PAIR) og[h][e - PART_PT] = acc;
+    else f[F_PAIR + h * CZ4 + (e - PART_PAIR)] = acc;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < H * PV) {
+    const int hp = (int)threadIdx.x, hh = hp / PV, pt = hp % PV;
+    const Rot Rm = quat_to_rot(quat + r * 4);
+    const float* tt = trans + r * 3;
+    const float ux = og[hh][3 * pt] - tt[0], uy = og[hh][3 * pt + 1] - tt[1], uz = og[hh][3 * pt + 2] - tt[2];
+    const float lx = Rm.r[0] * ux + Rm.r[3] * uy + Rm.r[6] * uz;
+    const float ly = Rm.r[1] * ux + Rm.r[4] * uy + Rm.r[7] * uz;
+    const float lz = Rm.r[2] * ux + Rm.r[5] * uy + Rm.r[8] * uz;
+    f[F_PT + hp] = lx;
+    f[F_PT + H * PV + hp] = ly;
+    f[F_PT + 2 * H * PV + hp] = lz;
+    f[F_NORM + hp] = sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Backward, query side (reference: autograd of ipa_pytorch.py:380-457).  With the probabilities A saved by the forward,
@@ -803,6 +885,14 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_bwd_kernel(FlashBwdArgs a)
 extern "C" int fd_ipa_flash_fwd(const float* proj, const float* zb, const float* qp, const float* kp, const float* vp,
                                 const float* head_w, const float* mask, const float* quat, const float* trans,
                                 float* feats, float* A, int B, int N, int heads_per_block, void* stream) {
+  return fd_ipa_flash_fwd_split(proj, zb, qp, kp, vp, head_w, mask, quat, trans, feats, A, B, N, heads_per_block, 1,
+                                nullptr, stream);
+}
+
+extern "C" int fd_ipa_flash_fwd_split(const float* proj, const float* zb, const float* qp, const float* kp, const float* vp,
+                                      const float* head_w, const float* mask, const float* quat, const float* trans,
+                                      float* feats, float* A, int B, int N, int heads_per_block, int key_splits,
+                                      float* part, void* stream) {
   FD_CHECK_ARG(N <= MAXN, "fd_ipa_flash_fwd: N=%d exceeds %d", N, MAXN);
   FD_CHECK_ARG(feats != nullptr, "fd_ipa_flash_fwd: feats is required");
   FD_CHECK_ARG(fd_aligned16(proj) && fd_aligned16(zb) && fd_aligned16(qp) && fd_aligned16(kp) && fd_aligned16(vp) &&
@@ -810,12 +900,16 @@ extern "C" int fd_ipa_flash_fwd(const float* proj, const float* zb, const float*
                "fd_ipa_flash_fwd: proj, zb, qp, kp, vp and feats must be 16-byte aligned");
   FD_CHECK_ARG(heads_per_block == 0 || heads_per_block == 2 || heads_per_block == 4 || heads_per_block == 8,
                "fd_ipa_flash_fwd: heads_per_block must be 0 (pick), 2, 4 or 8, got %d", heads_per_block);
+  const int nti = (N + TI - 1) / TI;
+  FD_CHECK_ARG(key_splits >= 1 && (key_splits == 1 || (part != nullptr && fd_aligned16(part) && A == nullptr)),
+               "fd_ipa_flash_fwd_split: key_splits > 1 needs the 16-byte aligned workspace (fd_ipa_flash_part_floats) and no A");
   if (B == 0 || N == 0) return FD_OK;
-  const long tiles = (long)B * ((N + TI - 1) / TI);
+  if (key_splits > nti) key_splits = nti;
+  const long tiles = (long)B * nti;
   int hpb = heads_per_block;
-  if (hpb == 0) hpb = tiles >= 128 ? 8 : tiles >= 32 ? 4 : 2;      // (a lone N = 128 backbone: 8 query tiles -> 32 blocks)
-  FlashArgs a{proj, zb, qp, kp, vp, head_w, mask, quat, trans, feats, A, B, N};
-  const dim3 grid((unsigned)(tiles * (H / hpb)));
+  if (hpb == 0) hpb = tiles >= 128 ? 8 : tiles >= 32 || key_splits > 1 ? 4 : 2;      // (a lone N = 128 backbone: 8 query tiles)
+  FlashArgs a{proj, zb, qp, kp, vp, head_w, mask, quat, trans, feats, A, B, N, part, key_splits};
+  const dim3 grid((unsigned)(tiles * (H / hpb) * key_splits));
   if (hpb == 8)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_flash_fwd_kernel<8>), grid, dim3(512), 0, (hipStream_t)stream, a);
   else if (hpb == 4)
@@ -823,6 +917,11 @@ extern "C" int fd_ipa_flash_fwd(const float* proj, const float* zb, const float*
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_flash_fwd_kernel<2>), grid, dim3(128), 0, (hipStream_t)stream, a);
   FD_CHECK_LAUNCH("fd_ipa_flash_fwd");
+  if (key_splits > 1) {
+    hipLaunchKernelGGL(ipa_flash_merge_kernel, dim3((unsigned)((long)B * N)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)part, quat, trans, feats, (long)B * N, key_splits);
+    FD_CHECK_LAUNCH("fd_ipa_flash_fwd (merge)");
+  }
   return FD_OK;
 }
 

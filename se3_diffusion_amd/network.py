@@ -301,6 +301,10 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None, out_view
     train = bool(save)             # a backward pass will read the probabilities A (and the [B, 8, 24, N] key-point copy)
     flash = (opts.flash_ipa and B * ((N + 15) // 16) >= opts.flash_ipa_min_tiles and N <= 1024
              and (lib().is_device or opts.flash_ipa_min_tiles <= 0))
+    # a long lone backbone (inference): too few query tiles for the kernel above, but enough keys to split them over 4 blocks
+    split = 4 if (opts.flash_ipa and not flash and not train and opts.flash_ipa_split_min_n <= N <= 1024
+                  and (lib().is_device or opts.flash_ipa_split_min_n <= 16)) else 1      # (<= 16: the interpreter tests)
+    flash = flash or split > 1
     # (the copy serves fd_ipa_attn_fwd/bwd only: the unfused softmax kernels, the fused pair pass and the flash kernel read kp)
     kpT = empty((B, H, PQ * 3, N), dev) if opts.fused_ipa_attn and (train or not flash) else None
     par = (not train) and not flash            # sampling, launch sequence: independent launches on a second graph branch
@@ -316,8 +320,13 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None, out_view
         # one launch: q k^T, logits, softmax, a v, a v_pts, o_pt (+ norm), o_pair; the probabilities are written out only for
         # the backward pass (training)
         A = empty((B, H, N, N), dev) if train else None
-        L.call("fd_ipa_flash_fwd", proj, zb, qp, kp, vp, P[f"{pre}.head_weights"], mask, quat, trans, feats, A, B, N,
-               opts.flash_ipa_hpb)
+        if split > 1:
+            part = empty((split * R * H * 328,), dev)
+            L.call("fd_ipa_flash_fwd_split", proj, zb, qp, kp, vp, P[f"{pre}.head_weights"], mask, quat, trans, feats, None, B, N,
+                   opts.flash_ipa_hpb or 4, split, part)
+        else:
+            L.call("fd_ipa_flash_fwd", proj, zb, qp, kp, vp, P[f"{pre}.head_weights"], mask, quat, trans, feats, A, B, N,
+                   opts.flash_ipa_hpb)
     else:
         A = empty((B, H, N, N), dev)
         L.gemm(proj, proj, A, N, N, C, (LDP, 1), (1, LDP), N, b_off=2048, batch=B * H, bdiv=H,

@@ -59,6 +59,9 @@ class Options:
                                       # in HBM) instead of two batched GEMMs + fd_ipa_attn_bwd's per-row kernel ...
     flash_ipa_bwd_min_tiles: int = 128  # FD_IPA_FLASH_BWD_MIN_TILES: ... from this many query tiles up (8 heads per block only: 112 tiles
                                       # 195 against 199 us, 95 tiles 224 against 207)
+    flash_ipa_split_min_n: int = 384  # FD_IPA_FLASH_SPLIT_MIN_N: inference below flash_ipa_min_tiles -- from this N up the KEYS of a query tile are
+                                      # split over 4 blocks + a merge launch (fd_ipa_flash_fwd_split: 86 against 112 us at N=512 B=1; 55
+                                      # against 49 at N=256, 42 against 39 at N=128: the launch sequence stays there)
     flash_ipa_hpb: int = 0            # FD_IPA_FLASH_HPB: heads per block of that kernel (0 = by size, 8 / 4 / 2)
     proj_merge: bool = True           # FD_PROJ_MERGE: IPA's four projections of s as one GEMM over back-to-back weights
     # -- node level
@@ -93,6 +96,7 @@ class Options:
             fused_ipa_attn=_flag("FD_IPA_ATTN_FUSED", True),
             flash_ipa=_flag("FD_IPA_FLASH", True), flash_ipa_min_tiles=_int("FD_IPA_FLASH_MIN_TILES", 80),
             flash_ipa_bwd_min_tiles=_int("FD_IPA_FLASH_BWD_MIN_TILES", 128),
+            flash_ipa_split_min_n=_int("FD_IPA_FLASH_SPLIT_MIN_N", 384),
             flash_ipa_hpb=_int("FD_IPA_FLASH_HPB", 0), flash_ipa_bwd=_flag("FD_IPA_FLASH_BWD", True),
             proj_merge=_flag("FD_PROJ_MERGE", True),
             fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),

@@ -102,14 +102,19 @@ def _float64(proj, quat, trans, zb, hw, mask, B, N):
 GROUPS = (("o", 0, F_PT), ("o_pt", F_PT, F_NORM), ("norm", F_NORM, F_PAIR), ("o_pair", F_PAIR, LDF))
 
 
-def _run(dev, B, N, seed, hpb=0, spread=1.0, want_A=True, tol=2e-5, tol_seq=2e-5, log=None):
+def _run(dev, B, N, seed, hpb=0, spread=1.0, want_A=True, tol=2e-5, tol_seq=2e-5, log=None, splits=1):
     L = ops.lib()
     proj, quat, trans, zb, hw, mask = _inputs(dev, B, N, seed, spread)
     qp, kp, vp, kpT = _points(L, proj, quat, trans, B, N)
     f_seq, A_seq = _sequence(L, proj, quat, trans, zb, hw, mask, qp, kp, vp, kpT, B, N)
     feats = torch.full((B * N, LDF), float("nan"), device=dev)          # (every column must be written)
     A = torch.full((B, H, N, N), float("nan"), device=dev) if want_A else None
-    L.call("fd_ipa_flash_fwd", proj, zb, qp, kp, vp, hw, mask, quat, trans, feats, A, B, N, hpb)
+    if splits > 1:
+        part = torch.full((splits * B * N * H * 328,), float("nan"), device=dev)
+        L.call("fd_ipa_flash_fwd_split", proj, zb, qp, kp, vp, hw, mask, quat, trans, feats, None, B, N, hpb, splits, part)
+        want_A = False
+    else:
+        L.call("fd_ipa_flash_fwd", proj, zb, qp, kp, vp, hw, mask, quat, trans, feats, A, B, N, hpb)
     assert bool(torch.isfinite(feats).all())
     f64, a64 = _float64(proj, quat, trans, zb, hw, mask, B, N)
     rows = (mask.cpu() > 0)                                               # rows of masked residues: see test_ipa_attn.py
@@ -141,6 +146,8 @@ def test_ipa_flash_fwd_emu(use_emu):
     _run("cpu", 2, 37, 1, hpb=4)          # three tiles, ragged rows and keys, two head groups
     _run("cpu", 1, 33, 2, hpb=2)
     _run("cpu", 1, 20, 3, hpb=0, want_A=False)
+    _run("cpu", 1, 37, 4, hpb=4, splits=3)          # key split: 3 blocks per query tile + merge launch
+    _run("cpu", 1, 33, 5, hpb=0, splits=8)          # (more splits than key tiles: clamped)
 
 
 @pytest.mark.gpu
@@ -150,6 +157,9 @@ def test_ipa_flash_fwd_gpu(hip_lib):
                                           (1, 256, 4, 0, 1.2), (1, 257, 5, 8, 1.2), (2, 400, 6, 0, 1.5), (1, 512, 7, 8, 1.5),
                                           (1, 600, 8, 8, 1.5)):
             _run("cuda", B, N, seed, hpb=hpb, spread=spread, log=log)
+        for (B, N, seed, hpb, ks) in ((1, 128, 10, 4, 4), (1, 128, 11, 4, 2), (1, 256, 12, 4, 4), (1, 256, 13, 4, 8), (1, 300, 14, 2, 4),
+                                      (1, 512, 15, 4, 8)):
+            _run("cuda", B, N, seed, hpb=hpb, spread=1.2, log=log, splits=ks)
 
 
 # ------------------------------------------------------------------------------------------------------------------- backward
@@ -223,3 +233,33 @@ def test_ipa_flash_bwd_gpu(hip_lib):
         for (B, N, seed, spread) in ((2, 128, 0, 1.0), (3, 100, 1, 1.0), (1, 256, 2, 1.2), (1, 257, 3, 1.2), (2, 400, 4, 1.5),
                                      (1, 512, 5, 1.5)):
             _run_bwd("cuda", B, N, seed, spread=spread, log=True)
+
+
+# ------------------------------------------------------------------------------------------------- inside the network forward
+def _forward_paths(dev, B, N, blocks=2):
+    """the eval-mode ScoreNetwork forward with IPA attention as (a) the launch sequence, (b) the one-launch kernel, (c) the
+    key-split kernel + merge launch: same outputs (model/ipa_pytorch.py:380-457 inside IpaScore.forward)"""
+    from se3_diffusion_amd import options, train_step as ts
+    from se3_diffusion_amd.model.score_network import ScoreNetwork
+    m = ScoreNetwork(ts.base_model_conf(blocks), diffuser=None).to(dev).eval()
+    ts.perturb_final_layers(m, seed=0)
+    batch = ts.synthetic_batch(B, N, dev, seed=3)
+    outs = []
+    with torch.no_grad():
+        for kw in (dict(flash_ipa=False), dict(flash_ipa_min_tiles=0), dict(flash_ipa_min_tiles=1 << 30, flash_ipa_split_min_n=16)):
+            with options.override(**kw):
+                outs.append({k: v.clone() for k, v in m(batch).items() if torch.is_tensor(v)})
+    for o in outs[1:]:
+        for k in ("rot_score", "trans_score", "rigids", "psi", "atom37"):
+            sc = float(outs[0][k].abs().max()) + 1e-12
+            assert float((o[k] - outs[0][k]).abs().max()) / sc < 2e-5, k
+
+
+def test_forward_paths_emu(use_emu):
+    _forward_paths("cpu", 1, 40)
+
+
+@pytest.mark.gpu
+def test_forward_paths_gpu(hip_lib):
+    _forward_paths("cuda", 1, 400, blocks=2)
+    _forward_paths("cuda", 2, 128, blocks=2)

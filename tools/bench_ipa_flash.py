@@ -109,6 +109,26 @@ def variants(B, N, hpb, spread=1.0):
     print(" | ".join(line), flush=True)
 
 
+def case_split(B, N, spread=1.0):
+    """a lone backbone: the launch sequence against the key-split kernel + merge launch (fd_ipa_flash_fwd_split)"""
+    L = ops.lib()
+    dev = "cuda"
+    proj, quat, trans, zb, hw, mask = T._inputs(dev, B, N, 0, spread, masked=False)
+    qp, kp, vp, kpT = T._points(L, proj, quat, trans, B, N)
+    t_seq = timeit(lambda: T._sequence(L, proj, quat, trans, zb, hw, mask, qp, kp, vp, kpT, B, N))
+    f_seq, _ = T._sequence(L, proj, quat, trans, zb, hw, mask, qp, kp, vp, kpT, B, N)
+    feats = torch.empty(B * N, T.LDF, device=dev)
+    line = [f"B={B:3d} N={N:4d}: sequence (5 launches) {t_seq:7.1f} us"]
+    for hpb in (4, 2):
+        for ks in (1, 2, 4, 8):
+            part = torch.empty(max(1, ks * B * N * T.H * 328), device=dev)
+            t = timeit(lambda: L.call("fd_ipa_flash_fwd_split", proj, zb, qp, kp, vp, hw, mask, quat, trans, feats, None, B, N, hpb,
+                                      ks, part))
+            err = float((feats - f_seq).abs().max() / f_seq.abs().max())
+            line.append(f"hpb={hpb} x{ks}: {t:6.1f} ({err:.0e})")
+    print(" | ".join(line), flush=True)
+
+
 def case_bwd(B, N, spread=1.0):
     """the query side of the backward: dA GEMM + fd_ipa_opt_bwd + dA += GEMM + fd_ipa_attn_bwd against fd_ipa_opt_bwd_dot +
     fd_ipa_flash_bwd (both include the head-weight column sum and fd_ipa_kpts_bwd)"""
@@ -156,6 +176,10 @@ def variants_bwd(B, N, spread=1.0):
 
 
 def main():
+    if "--split" in sys.argv:
+        for (B, N, sp) in ((1, 128, 1.0), (1, 256, 1.2), (1, 512, 1.5), (2, 256, 1.2), (4, 128, 1.0)):
+            case_split(B, N, sp)
+        return
     if "--variants-bwd" in sys.argv:
         variants_bwd(30, 128)
         variants_bwd(8, 512, spread=1.5)
