@@ -27,6 +27,10 @@ constexpr int GD_PANELS = 8;                        // 4 of A (128 columns of dY
 constexpr int GD_PLANE = GD_PANELS * DW_PSTRIDE;
 constexpr int GD_STAGE = 3 * GD_PLANE;              // 26,112 B
 constexpr int GD_RING = 2;
+#ifndef GD_NSET
+#define GD_NSET 4          // register sets of global loads: stage k is requested GD_NSET stages before it is split into the ring
+#endif
+static_assert(GD_NSET == 2 || GD_NSET == 4, "register sets");
 static_assert(2 * GD_RING * GD_STAGE <= 160 * 1024, "LDS: two blocks per CU");
 
 struct GdUnit {
@@ -53,7 +57,7 @@ __device__ __forceinline__ void gd_unit(const GdUnit& u, char* lds, const int db
   const long nrows = u.row1 - u.row0, last = nrows - 1;
   const int nst = (int)((nrows + DW_KS - 1) / DW_KS);
 
-  float4 rg[2][4];           // [register set][A row kk, A row kk+8, B row kk, B row kk+8]
+  float4 rg[GD_NSET][4];     // [register set][A row kk, A row kk+8, B row kk, B row kk+8]
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
 
   auto sel = [](const float4 v, bool ok) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
@@ -114,8 +118,8 @@ __device__ __forceinline__ void gd_unit(const GdUnit& u, char* lds, const int db
   };
 
   // full stages through running pointers (no clamp / select of the row index)
-  const float* pa = A + ((long)3 * DW_KS + kk) * u.lda + ca;
-  const float* pb = B + ((long)3 * DW_KS + kk) * u.ldb + cb;
+  const float* pa = A + ((long)(GD_NSET + 1) * DW_KS + kk) * u.lda + ca;
+  const float* pb = B + ((long)(GD_NSET + 1) * DW_KS + kk) * u.ldb + cb;
   const long sa = (long)DW_KS * u.lda, sb = (long)DW_KS * u.ldb, ha = 8 * u.lda, hb = 8 * u.ldb;
   auto load_fast = [&](float4 (&r)[4]) __attribute__((always_inline)) {
     r[0] = sel(*reinterpret_cast<const float4*>(pa), aok);
@@ -126,11 +130,11 @@ __device__ __forceinline__ void gd_unit(const GdUnit& u, char* lds, const int db
     pb += sb;
   };
 
-  // pipeline: stage s lives in register set s & 1 (loaded two stages ahead) and ring slot s & 1
-  load(rg[0], 0);
-  load(rg[1], 1);
+  // pipeline: stage s lives in register set s % GD_NSET (requested GD_NSET stages before its split) and ring slot s & 1
+#pragma unroll
+  for (int k = 0; k < GD_NSET; ++k) load(rg[k], k);
   put(rg[0], lds);
-  load(rg[0], 2);
+  load(rg[0], GD_NSET);
   __syncthreads();
   // dbg (FD_GROUP_DW_DEBUG, measurements only): 1 = no flush, 2 = no MFMA phase, 4 = no split / LDS writes
   auto step_fast = [&](int s, float4 (&r)[4]) __attribute__((always_inline)) {
@@ -142,18 +146,19 @@ __device__ __forceinline__ void gd_unit(const GdUnit& u, char* lds, const int db
   auto step = [&](int s, float4 (&r)[4]) __attribute__((always_inline)) {
     if (!(dbg & 2)) mma(lds + (s & 1) * GD_STAGE);
     if (!(dbg & 4)) put(r, lds + ((s + 1) & 1) * GD_STAGE);
-    load(r, s + 3);
+    load(r, s + GD_NSET + 1);
     __syncthreads();
   };
   const int nfull = (int)(nrows / DW_KS);
   int s = 0;
-  for (; s + 5 <= nfull; s += 2) {
-    step_fast(s, rg[1]);
-    step_fast(s + 1, rg[0]);
+  // (step s splits stage s + 1 out of set (s + 1) % GD_NSET and requests stage s + GD_NSET + 1 into it)
+  for (; s + 2 * GD_NSET + 1 <= nfull; s += GD_NSET) {
+#pragma unroll
+    for (int k = 0; k < GD_NSET; ++k) step_fast(s + k, rg[(k + 1) % GD_NSET]);
   }
-  for (; s < nst; s += 2) {
-    step(s, rg[1]);
-    step(s + 1, rg[0]);          // nst odd: one stage of zeros
+  for (; s < nst; s += GD_NSET) {
+#pragma unroll
+    for (int k = 0; k < GD_NSET; ++k) step(s + k, rg[(k + 1) % GD_NSET]);      // (stages past nst: zeros)
   }
 
   // flush: C += acc, atomically (every row range of the tile adds its part); lanes run along n (one line per 32 lanes)
