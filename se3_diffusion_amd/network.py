@@ -379,7 +379,7 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True, defer_dz=Fal
     _lin_grads(G, f"{pre}.linear_out.weight", f"{pre}.linear_out.bias", mv(dm), mv(feats), R, CS, LDF)
     dfeats = empty((R, LDF), dev)
     ops.linear_dx(mv(dm), mv(P[f"{pre}.linear_out.weight"]), mv(dfeats), R, CS, LDF)
-    dproj = zeros((R, LDP), dev)
+    dproj = empty((R, LDP), dev)            # (every column is assigned: dQ | dK, dV per head | the raw point gradients)
     dqp = empty((R, H, PQ * 3), dev); dkp = empty((R, H, PQ * 3), dev)
     dhw = G[f"{pre}.head_weights"] if G is not None else zeros((H,), dev)
     hw_part = empty((R, H), dev)
