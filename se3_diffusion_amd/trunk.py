@@ -557,11 +557,11 @@ def backward(P, G, sv, d_out, on_done=None):
     dev = sv["mask"]
     if sv["bool_mask"]:
         raise NotImplementedError("backward is defined for the training-mode (additive) transformer mask")
-    # every zero-initialised accumulator of the pass from one memset (per block: dproj [R,6816], the node-term sums of the
-    # edge transition [R,2*(128+384)], du0, ds, dframe, ...: ~R * 8,700 floats)
+    # every zero-initialised accumulator of the pass from one memset (per block: the node-term sums of the edge transition
+    # [R,2*(128+384)], du0, ds, dframe, ...: ~R * 1,650 floats; IPA's dproj [R,6816] is assigned, not accumulated)
     ops.reset_dw_queue()        # nothing an interrupted earlier pass queued may leak into this one's gradients
     try:
-        with ops.zero_arena(R * (nb * 8800 + 1024) + 65536 if opts.zero_arena else 0, dev):
+        with ops.zero_arena(R * (nb * 2048 + 1024) + 65536 if opts.zero_arena else 0, dev):
             _backward(P, G, sv, d_out, notify)
     except BaseException:
         ops.reset_dw_queue()

@@ -256,7 +256,7 @@ def _forward_paths(dev, B, N, blocks=2):
 
 
 def test_forward_paths_emu(use_emu):
-    _forward_paths("cpu", 1, 40)
+    _forward_paths("cpu", 1, 24, blocks=1)
 
 
 @pytest.mark.gpu

@@ -85,12 +85,14 @@ def _compare(dev, B, N, blocks, groups=GROUPS):
 
 
 def test_switches_emu(use_emu):
-    _compare("cpu", B=2, N=8, blocks=1)
+    # (the heads-per-block shapes of the IPA kernel and the sequence-attention backward have kernel-level interpreter tests of
+    #  their own -- tests/test_ipa_flash.py, tests/test_seq_attn.py -- and run inside a step on the GPU tier)
+    _compare("cpu", B=2, N=8, blocks=1, groups=[g for g in GROUPS if not ({"flash_ipa_hpb", "fused_seq_attn_bwd"} & set(g[0]))])
 
 
 def test_switches_two_blocks_emu(use_emu):
     # with an edge transition between the blocks: the fused LayerNorm-backward / dzb W40 prologue against the separate kernels
-    _compare("cpu", B=1, N=8, blocks=2, groups=[GROUPS[2], GROUPS[4], GROUPS[5], GROUPS[11], GROUPS[12], GROUPS[13], GROUPS[14]])
+    _compare("cpu", B=1, N=8, blocks=2, groups=[GROUPS[4], GROUPS[11], GROUPS[12], GROUPS[13], GROUPS[14]])
 
 
 def _dynamic_vs_static(dev, B, N, blocks):
