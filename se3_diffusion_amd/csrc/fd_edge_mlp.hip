@@ -58,6 +58,13 @@ namespace {
 constexpr int EM_UNITS = 128;              // units per tile
 constexpr int EM_ZB_UNITS = 4;             // + the next IPA block's [linear_b ; down_z] (40 <- 128: 4 k-steps x one n-group)
 constexpr int EM_ZB = 40;
+// the training saves (h1 / h2, d2 / d1: 2 x 755 MB per launch that only the weight-gradient launch reads, much later):
+// -DEM_NT_SAVES stores them with the non-temporal hint
+#ifdef EM_NT_SAVES
+#define EM_SAVE4(p, v) fd::store_nt4((p), (v)[0], (v)[1], (v)[2], (v)[3])
+#else
+#define EM_SAVE4(p, v) (*reinterpret_cast<float4*>(p) = make_float4((v)[0], (v)[1], (v)[2], (v)[3]))
+#endif
 #ifndef EM_RING
 // LDS stages of the weight stream and how many stages ahead of its use a stage's copy is issued (EM_AHEAD <= EM_RING - 1: the
 // slot a copy lands in was last read one barrier ago at the latest).  Round 2: ring 3 / ahead 2 with two 4-wave blocks per CU
@@ -569,8 +576,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
               // of eight back to back in the epilogue
 #pragma unroll
               for (int i = 0; i < 2; ++i)
-                *reinterpret_cast<float4*>(d.save1 + row * EM_H + 128 * c + 16 * (2 * ks + i) + 4 * g) =
-                    make_float4(acc1[2 * ks + i][0], acc1[2 * ks + i][1], acc1[2 * ks + i][2], acc1[2 * ks + i][3]);
+                EM_SAVE4(d.save1 + row * EM_H + 128 * c + 16 * (2 * ks + i) + 4 * g, acc1[2 * ks + i]);
             }
           }
           em16_mma_half(acc2[a], acc2[a + 1], H[hh & 1], b);
@@ -650,9 +656,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
           em16_split2(acc2[2 * ks], acc2[2 * ks + 1], b[0], b[1], b[2]);
           if (STORE_SPREAD && rok) {      // the save of h2 / d1, two blocks per k-step of layer 3
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-              *reinterpret_cast<float4*>(d.save2 + row * EM_H + 16 * (2 * ks + i) + 4 * g) =
-                  make_float4(acc2[2 * ks + i][0], acc2[2 * ks + i][1], acc2[2 * ks + i][2], acc2[2 * ks + i][3]);
+            for (int i = 0; i < 2; ++i) EM_SAVE4(d.save2 + row * EM_H + 16 * (2 * ks + i) + 4 * g, acc2[2 * ks + i]);
           }
         }
         em16_mma_half(acc3[a], acc3[a + 1], H[hh & 1], b);

@@ -163,6 +163,13 @@ __device__ __forceinline__ void sched_group() { __builtin_amdgcn_sched_group_bar
 // (per-head pointers, loop bounds) stays in SGPRs
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// 16-byte store with the non-temporal hint (global_store_dwordx4 ... nt): data nobody re-reads before it has left the L2
+__device__ __forceinline__ void store_nt4(float* p, float x, float y, float z, float w) {
+  f32x4 v;
+  v[0] = x; v[1] = y; v[2] = z; v[3] = w;
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 

@@ -171,6 +171,7 @@ static inline void sched_fence() {}
 static inline void sched_pin() {}
 
 
+static inline void store_nt4(float* p, float x, float y, float z, float w) { p[0] = x; p[1] = y; p[2] = z; p[3] = w; }
 static inline int uniform(int v) { return v; }
 static inline int lane_id() { return hipemu::g_cur->lane; }
 static inline int wave_id() { return hipemu::g_cur->wave; }

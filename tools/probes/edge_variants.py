@@ -20,9 +20,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # tag -> extra flags ("" = the product library itself)
 VARIANTS = {
     "shipped": None,
-    "store_lump": ["-DEM_STORE_LUMP"],
+    "nt_saves": ["-DEM_NT_SAVES"],
     "shipped again": [],
-    "store_lump again": ["-DEM_STORE_LUMP"],
+    "nt_saves again": ["-DEM_NT_SAVES"],
 }
 if os.environ.get("EDGE_VARIANTS_EXTRA"):          # "tag:-DX=1,-DY=2;tag2:..."
     for item in os.environ["EDGE_VARIANTS_EXTRA"].split(";"):
