@@ -204,6 +204,7 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
   const bool row_ok = i0 + n < N;
   float* __restrict__ Arow = a.A != nullptr ? a.A + (((long)b * H + h) * N + imin(i0 + n, N - 1)) * N : nullptr;
+  const bool avec = (N & 3) == 0 && (((unsigned long long)a.A) & 15ull) == 0;       // rows of A are 16-byte aligned
 
   // K fragments are requested KPF chunks ahead of the MFMAs that consume them, V fragments VPF loads ahead (a wave has one
   // partner on its SIMD and an L2 round trip is ~20 MFMA issue slots); the first KPF chunks of the NEXT key tile are
@@ -321,9 +322,14 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
       s[r] = j0 + 4 * kk + r < N ? x : -INFINITY;
     }
     if (Arow != nullptr && row_ok) {
+      const int j = j0 + 4 * kk;
+      if (avec && j + 3 < N) {
+        *reinterpret_cast<float4*>(Arow + j) = make_float4(s[0], s[1], s[2], s[3]);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (j0 + 4 * kk + r < N) Arow[j0 + 4 * kk + r] = s[r];
+        for (int r = 0; r < 4; ++r)
+          if (j + r < N) Arow[j + r] = s[r];
+      }
     }
     float tmax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
@@ -490,12 +496,18 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
   }
   // ---- training: logits -> probabilities, by the lane that wrote them
   if (Arow != nullptr && row_ok) {
-    for (int t = 0; t < nti; ++t)
+    for (int t = 0; t < nti; ++t) {
+      const int j = TI * t + 4 * kk;
+      if (avec && j + 3 < N) {
+        const float4 v = ld4(Arow + j);
+        *reinterpret_cast<float4*>(Arow + j) =
+            make_float4(expf(v.x - m_run) * inv, expf(v.y - m_run) * inv, expf(v.z - m_run) * inv, expf(v.w - m_run) * inv);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = TI * t + 4 * kk + r;
-        if (j < N) Arow[j] = expf(Arow[j] - m_run) * inv;
+        for (int r = 0; r < 4; ++r)
+          if (j + r < N) Arow[j + r] = expf(Arow[j + r] - m_run) * inv;
       }
+    }
   }
 }
 
