@@ -36,6 +36,8 @@ struct GemmArgs {
   int ksplit;
   int mtiles;   // consecutive M tiles pipelined by one block
   int epi_vec;  // 16-byte epilogue through LDS (needs mtiles == 1 and 4-element aligned C / gate / resid / pair)
+  int zbatch;   // > 0: the batch index rides in blockIdx.x (grid.x = tiles x zbatch), XCD-swizzled over the WHOLE grid so that
+                // the tiles of one batch element -- which re-read its A rows / B columns -- share an XCD's L2
 };
 
 // Stages a ROWS x BK operand tile: global -> registers (load) -> LDS (store).
@@ -334,13 +336,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   const int T = g.mtiles;
   const int nblk_mg = (g.nblk_m + T - 1) / T;
   const int nblk = nblk_mg * g.nblk_n;
-  const int lid = fd_xcd_swizzle((int)blockIdx.x, nblk);
+  int lid, z;
+  if (g.zbatch > 0) {
+    const int L = fd_xcd_swizzle((int)blockIdx.x, nblk * g.zbatch);
+    z = L / nblk;
+    lid = L % nblk;
+  } else {
+    lid = fd_xcd_swizzle((int)blockIdx.x, nblk);
+    z = (int)blockIdx.y;
+  }
   const int bmg = lid / g.nblk_n, bn = lid % g.nblk_n;
   const int mt0 = bmg * T;
   const int ntile = (g.nblk_m - mt0 < T) ? g.nblk_m - mt0 : T;
   const int n0 = bn * BN;
 
-  const int z = (int)blockIdx.y;
   const int zo = z / d.bdiv, zi = z % d.bdiv;
   const float* __restrict__ A = d.A + zo * d.a_so + zi * d.a_si;
   const float* __restrict__ B = d.B + zo * d.b_so + zi * d.b_si;
@@ -524,7 +533,7 @@ int persist_blocks() {
 
 template <int BM>
 int launch_bx3(const FdGemmDesc& d, hipStream_t stream) {
-  GemmArgs g;
+  GemmArgs g{};
   g.d = d;
   g.nblk_m = fd_cdiv(d.M, BM);
   g.nblk_n = fd_cdiv(d.N, XBN);
@@ -622,7 +631,7 @@ int plan_tile(const FdGemmDesc& d, bool fast) {
 
 template <int BM, int BN, int WGM, int WGN, bool FAST>
 int launch_cfg(const FdGemmDesc& d, hipStream_t stream) {
-  GemmArgs g;
+  GemmArgs g{};
   g.d = d;
   g.nblk_m = fd_cdiv(d.M, BM);
   g.nblk_n = fd_cdiv(d.N, BN);
@@ -645,7 +654,10 @@ int launch_cfg(const FdGemmDesc& d, hipStream_t stream) {
   g.epi_vec = epilogue_vectorisable(d, g.ksplit) && (d.mtiles <= 1);
   if (g.epi_vec) g.mtiles = 1;
   const int nblk_mg = (g.nblk_m + g.mtiles - 1) / g.mtiles;
-  dim3 grid(nblk_mg * g.nblk_n, nb, g.ksplit), block(256, 1, 1);
+  // batched launches (attention products: a handful of tiles per batch element): a [tiles, batch] grid puts tile t of EVERY batch
+  // element on XCD t % 8 and each element's operands are fetched by several L2s (126 MB per launch for 25 MB of operands)
+  g.zbatch = (nb > 1 && (long)nblk_mg * g.nblk_n * nb < (1l << 30) && getenv("FD_GEMM_BATCH_Y") == nullptr) ? nb : 0;
+  dim3 grid(nblk_mg * g.nblk_n * (g.zbatch > 0 ? nb : 1), g.zbatch > 0 ? 1 : nb, g.ksplit), block(256, 1, 1);
   if constexpr (BM == 64 && BN == 64 && FAST) {
     if (d.a_rowsum && !a_kc && !b_kc) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<BM, BN, WGM, WGN, false, false, true, true>), grid, block, 0, stream, g);

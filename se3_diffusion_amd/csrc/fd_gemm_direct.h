@@ -144,7 +144,7 @@ bool direct_ok(const FdGemmDesc& d) {
 }
 
 int launch_direct(const FdGemmDesc& d, hipStream_t stream) {
-  GemmArgs g;
+  GemmArgs g{};
   g.d = d;
   g.nblk_m = fd_cdiv(d.M, 32);
   g.nblk_n = fd_cdiv(d.N, 32);

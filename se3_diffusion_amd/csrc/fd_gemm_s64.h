@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void gemm_s64_kernel(GemmArgs g) {
 }
 
 int launch_s64(const FdGemmDesc& d, hipStream_t stream) {
-  GemmArgs g;
+  GemmArgs g{};
   g.d = d;
   g.nblk_m = fd_cdiv(d.M, 64);
   g.nblk_n = fd_cdiv(d.N, 64);
