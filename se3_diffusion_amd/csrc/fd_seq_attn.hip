@@ -31,7 +31,11 @@ __global__ __launch_bounds__(256) void seq_attn_fwd_kernel(const float* __restri
   float* S = lds;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int i0 = (int)blockIdx.x * QT, hd = (int)blockIdx.y, b = (int)blockIdx.z;
+  // 1-D grid, XCD-swizzled as a whole: the query tiles of one (batch, head) -- which all read its K and V -- run on one XCD
+  // (a [tiles, heads, batch] grid puts tile t of every head on XCD t % 8: eight L2s fetch the same K / V)
+  const int nqt = (N + QT - 1) / QT;
+  const int lid = fd_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+  const int i0 = (lid % nqt) * QT, hd = (lid / nqt) % TH, b = lid / (nqt * TH);
   const float* base = qkv + (long)b * N * LDQ + hd * THD;
 
   // ---- scores: S[i][j] = scale * q_i . k_j + key_add[j]; wave w takes the key tiles w, w + 4, ... ----
@@ -350,7 +354,7 @@ extern "C" int fd_seq_attn_fwd(const float* qkv, const float* key_add, float* ou
   FD_CHECK_ARG(fd_aligned16(qkv), "fd_seq_attn_fwd: qkv must be 16-byte aligned");
   FD_CHECK_ARG(N <= 1024, "fd_seq_attn_fwd: N=%d exceeds 1024", N);
   if (B == 0 || N == 0) return FD_OK;
-  const dim3 grid((unsigned)((N + QT - 1) / QT), TH, (unsigned)B);
+  const dim3 grid((unsigned)((N + QT - 1) / QT) * TH * (unsigned)B);
   if (N <= 256)
     hipLaunchKernelGGL(seq_attn_fwd_kernel<256>, grid, dim3(256), 0, (hipStream_t)stream, qkv, key_add, out, A_out, scale, N);
   else
