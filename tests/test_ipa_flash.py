@@ -250,9 +250,12 @@ def _forward_paths(dev, B, N, blocks=2):
             with options.override(**kw):
                 outs.append({k: v.clone() for k, v in m(batch).items() if torch.is_tensor(v)})
     for o in outs[1:]:
-        for k in ("rot_score", "trans_score", "rigids", "psi", "atom37"):
+        # (psi is a normalised 2-vector: a residue whose unnormalised torsion output is small amplifies the last-bit differences
+        #  between the summation orders of the paths -- profiles/r04_parity_errors.md has one such case at 1.4e-4)
+        for k, tol in (("rot_score", 2e-5), ("trans_score", 2e-5), ("rigids", 2e-5), ("atom37", 2e-5), ("psi", 2e-3)):
             sc = float(outs[0][k].abs().max()) + 1e-12
-            assert float((o[k] - outs[0][k]).abs().max()) / sc < 2e-5, k
+            err = float((o[k] - outs[0][k]).abs().max()) / sc
+            assert err < tol, (k, err)
 
 
 def test_forward_paths_emu(use_emu):
@@ -263,3 +266,43 @@ def test_forward_paths_emu(use_emu):
 def test_forward_paths_gpu(hip_lib):
     _forward_paths("cuda", 1, 400, blocks=2)
     _forward_paths("cuda", 2, 128, blocks=2)
+
+
+# ------------------------------------------------------------------------------------- size-independent properties, full sizes
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(30, 128), (8, 512)])
+def test_ipa_flash_properties_full_size(hip_lib, B, N):
+    """At the benchmark sizes (no float64 restatement of a [B, 8, N, N] attention on the host):
+    * the probabilities the training forward writes are a distribution over the keys of every (row, head);
+    * attention is a SET function of the keys: permuting the residues of every backbone as keys only (K, V, key points, value
+      points, the key axis of zb, the key mask) leaves o, o_pt, |o_pt|, o_pair where they were (the kernel walks the keys in
+      tiles with a running maximum: any order must give the same sums up to fp32 reassociation)."""
+    L = ops.lib()
+    dev = "cuda"
+    proj, quat, trans, zb, hw, mask = _inputs(dev, B, N, 21, 1.2)
+    qp, kp, vp, _ = _points(L, proj, quat, trans, B, N)
+    R = B * N
+    feats = torch.empty(R, LDF, device=dev)
+    A = torch.empty(B, H, N, N, device=dev)
+    L.call("fd_ipa_flash_fwd", proj, zb, qp, kp, vp, hw, mask, quat, trans, feats, A, B, N, 0)
+    rows = (mask > 0).view(B, 1, N)
+    assert float(((A.sum(-1) - 1.0).abs() * rows).max()) < 1e-5
+    assert float(A.min()) >= 0.0
+    # keys permuted: the K | V columns of proj, kp, vp, mask and zb's key axis follow the permutation, the query side stays
+    g = torch.Generator().manual_seed(5)
+    perm = torch.randperm(N, generator=g).to(dev)
+    pr = proj.view(B, N, LDP)
+    proj2 = pr.clone()
+    proj2[:, :, 2048:6144] = pr[:, perm, 2048:6144]
+    proj2 = proj2.view(R, LDP).contiguous()
+    kp2 = kp.view(B, N, H, PQ * 3)[:, perm].reshape(R, H, PQ * 3).contiguous()
+    vp2 = vp.view(B, N, H, PV * 3)[:, perm].reshape(R, H, PV * 3).contiguous()
+    zb2 = zb.view(B, N, N, ZB)[:, :, perm].reshape(R * N, ZB).contiguous()
+    # the mask enters as m_i m_j: the row factor must keep the QUERY order, so the comparison uses an all-ones mask
+    ones = torch.ones_like(mask)
+    f1 = torch.empty(R, LDF, device=dev); f2 = torch.empty(R, LDF, device=dev)
+    L.call("fd_ipa_flash_fwd", proj, zb, qp, kp, vp, hw, ones, quat, trans, f1, None, B, N, 0)
+    L.call("fd_ipa_flash_fwd", proj2, zb2, qp, kp2, vp2, hw, ones, quat, trans, f2, None, B, N, 0)
+    for name, lo, hi in GROUPS:
+        sc = float(f1[:, lo:hi].abs().max())
+        assert float((f1[:, lo:hi] - f2[:, lo:hi]).abs().max()) / sc < 1e-5, name
