@@ -30,6 +30,10 @@
 // Epilogue: o / l, R_i^T (o_pt - t_i) and its norm (fd_ipa_opt_fwd's arithmetic), o_pair / l -> feats [R, 2688].
 // Training (A != nullptr): the logits are written to A [B, 8, N, N] on the way and turned into probabilities by the lane that
 // wrote them once the row's maximum and denominator are final -- the backward kernels read A as before.
+// Key split (fd_ipa_flash_fwd_split, inference on a long lone backbone): KS blocks share a query tile, each walks 1 / KS of the
+// key tiles and leaves its unnormalised sums with (maximum, denominator) in a workspace; ipa_flash_merge_kernel (one block per
+// residue) combines the splits with the usual exp(m_k - M) weights and applies the epilogue.
+// The second kernel of this file, ipa_flash_bwd_kernel, is the query side of the backward on the same skeleton (see there).
 #include "fd_common.h"
 #include "../../include/fd_hip.h"
 
