@@ -143,6 +143,8 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
     finally:
         # an exception mid-trajectory must not leave the weight-derived cache, eval mode or the profiling switch behind
         model.__dict__.pop("_fd_static", None)
+        from . import ops as _ops
+        _ops.join()                      # (options.graph_fork: nothing of an interrupted forward stays referenced on the branch)
         if was_training:
             model.train()
         lib.gemm_profile = saved_prof

@@ -50,3 +50,26 @@ def test_trajectory_emu(use_emu):
 @pytest.mark.gpu
 def test_trajectory_gpu(hip_lib):
     _run("cuda")
+
+
+@pytest.mark.gpu
+def test_graph_fork_matches_single_stream_gpu(hip_lib):
+    """options.graph_fork (independent launches of the sampling forward on a second stream = parallel branches of the captured
+    hipGraph; off by default, measured slower) gives the trajectory of the single-stream forward: same noise, eager and graph."""
+    from se3_diffusion_amd import options
+    dev = "cuda"
+    diff = se3_diffuser.SE3Diffuser(dconf())
+    m = ScoreNetwork(ts.base_model_conf(2), diff)
+    m.load_state_dict(fo.synth_params(seed=3, conf=dict(fo.CONF, num_blocks=2)), strict=True)
+    m = m.to(dev).eval()
+    B, N, steps = 1, 64, 6
+    g = torch.Generator().manual_seed(0)
+    z = [(torch.randn(B, N, 3, generator=g, dtype=torch.float64), torch.randn(B, N, 3, generator=g, dtype=torch.float64))
+         for _ in range(steps)]
+    outs = []
+    for fork, graph in ((False, False), (True, False), (True, True)):
+        with options.override(graph_fork=fork):
+            feats = sampler.init_feats(diff, B, N, dev, generator=torch.Generator(device=dev).manual_seed(1))
+            outs.append(sampler.sample(m, diff, feats, num_t=steps, noise_fn=lambda i, shape: z[i], use_graph=graph)["rigids"].clone())
+    for o in outs[1:]:
+        assert float((o - outs[0]).abs().max()) < 1e-4
