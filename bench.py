@@ -276,8 +276,8 @@ def make_diffuser():
 _FWD_FLOOR_MS = {128: 0.26, 256: 0.99, 512: 3.87}
 
 
-def sampling_rates(dev, blocks, num_t_run, lib, cases=((128, 1, True), (128, 8, False), (256, 1, True), (512, 1, False),
-                                                        (512, 8, False))):
+def sampling_rates(dev, blocks, num_t_run, lib, cases=((128, 1, True), (128, 8, False), (128, 32, False), (256, 1, True),
+                                                        (512, 1, False), (512, 8, False))):
     """The sampling half of the metric.  Cases flagged True run the FULL 500-step trajectory (config/inference.yaml:18-24:
     N=128 and N=256 at B=1, under two seconds together); the others run num_t_run diffusion steps (num_t_run + 1 network
     forwards) and are scaled to the 501 forwards of a 500-step trajectory.  Every case carries the roofline of the dominant
@@ -495,7 +495,11 @@ def main():
         sys.exit(spawn_ranks(a.gpus))
     from se3_diffusion_amd import dist as fdist
     rank, world, local = fdist.init_from_env()
-    assert world == a.gpus, f"--gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks"
+    if world != a.gpus:
+        # the launcher decides (torchrun --nproc-per-node=N bench.py without --gpus N is a valid way to start N ranks)
+        if rank == 0:
+            sys.stderr.write(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks; measuring {world} ranks\n")
+        a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an AMD GPU (the hot path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -752,6 +756,30 @@ def main():
                      "all_gemm_tflops": round(all_flops / max(tot_t, 1e-9) / 1e12, 2),
                      "step_model_tflops": round(all_flops / nprof / (dt / a.steps) / 1e12, 2)},
     }
+    if world == 1 and a.mode == "train" and not a.no_sampling and not a.mixed_n and not os.environ.get("FD_BENCH_PROFILE"):
+        # BASELINE configs[3] on this GPU inside the same driver-timed command: 12 steps of the mixed-length schedule
+        # (dist.mixed_length_schedule: N ~ U{100..512}, B = min(32, 5e5 // N^2)); every length runs once untimed first (new
+        # lengths = first use of kernel variants + allocator growth)
+        try:
+            m_warm, m_steps = 3, 12
+            m_sched = fdist.mixed_length_schedule(m_warm + m_steps)
+            data[:] = [make_batch(n, b, 1000 * i + rank) for i, (n, b) in enumerate(m_sched)]
+            for i in range(m_warm + m_steps):
+                step(i)
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(m_steps):
+                step(m_warm + i)
+            barrier()
+            m_dt = time.perf_counter() - t0
+            m_res = sum(n * b for n, b in m_sched[m_warm:])
+            res["config"]["mixed_n"] = {
+                "residues_per_s": round(m_res / m_dt, 1), "steps": m_steps, "ms_per_step": round(m_dt / m_steps * 1e3, 3),
+                "schedule_n_b": [list(x) for x in m_sched[m_warm:]],
+                "note": "BASELINE configs[3] on one GPU: the full training step on a seeded mixed-length schedule, N ~ U{100..512}, "
+                        "B = min(32, 5e5 // N^2); `python bench.py --mixed-n` is the same measurement as its own line"}
+        except Exception as e:  # noqa: BLE001 -- must not lose the training measurement
+            res["config"]["mixed_n"] = {"error": repr(e)}
     if world == 1 and a.mode == "train" and not a.no_sampling and not a.mixed_n:
         try:
             data.clear()

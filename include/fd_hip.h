@@ -25,6 +25,9 @@ const char* fd_last_error(void);
 int fd_abi_version(void);
 /* "gfx950" for the product library; "emu" for the test-only host interpreter. */
 const char* fd_backend(void);
+/* "" for a product build; "FD_PROBE_BUILD" when the library was built by tools/probes with the timing / ablation hooks of the
+ * kernel sources enabled (csrc/fd_probe.h: those hooks do not compile in a product build). */
+const char* fd_build_flags(void);
 
 /* ---- dense: C = epi(alpha * A*B) --------------------------------------
  * Replaces torch Linear/matmul on the path: model/ipa_pytorch.py:101-166
@@ -106,43 +109,43 @@ int fd_rowscale(const float* x, long ldx, const float* rs, float* y, long ldy, l
  * One kernel per direction for the whole 128 -> 384 -> 384 -> 128 chain of a pair row (se3_diffusion_amd/csrc/
  * fd_edge_mlp.hip): the hidden activations stay in the registers of the wave that owns the row, the weights stream
  * through LDS from a pre-packed bf16-plane image (fd_edge_mlp_pack, once per optimiser step, FD_EDGE_MLP_IMAGE_BYTES).
- * Split-bf16 arithmetic (fp32-accurate, as fd_gemm tile 4).
- *   forward : h1 = relu(A1 x + p1[b,i] + q1[b,j]); h2 = relu(A2 h1 + bias2); y = A3 x + A4 h2 + pf[b,i] + qf[b,j];
- *             out = rowscale * LayerNorm(y; gamma, beta, eps).  Optional saves for the backward: save1 = h1, save2 = h2,
- *             y, mean, rstd.
- *   backward: x = dy; d2 = [gate1 > 0] (A1 x); d1 = [gate2 > 0] (A2 d2); out = A3 x + A4 d1, with the image packed
- *             from the TRANSPOSED weights (A1 = Wf^T, A2 = W2^T, A3 = Wfz^T, A4 = W1z^T; gate1 = h2, gate2 = h1);
- *             save1 = d2, save2 = d1 (operands of the weight-gradient GEMMs).
- * A1 [384,128], A2 [384,384], A3 [128,128], A4 [128,384] are given as (pointer, row stride, column stride).
+ * Split-bf16 arithmetic (fp32-accurate, as fd_gemm tile 4).  x [rows,128] = z.
+ *   forward : h1 = relu(W1z x + p1[b,i] + q1[b,j]); h2 = relu(W2 h1 + bias2); y = Wf (h2 + [x | 0 | 0]) + pf[b,i] + qf[b,j]
+ *             (W1z = W1[:, 0:128]; the residual through the final layer, ipa_pytorch.py:231, costs no product of its own);
+ *             out = rowscale * LayerNorm(y; gamma, beta, eps).  Training outputs (all four or none): save1 = h1,
+ *             save2 = h2 + [x | 0 | 0] (the operand of the final layer's weight gradient), mask1 / mask2 = the packed signs of
+ *             h1 / h2 (the backward's ReLU gates); optionally y, mean, rstd of the LayerNorm.
+ *   backward: x = dy; u = Wf^T x; d2 = [gmask1] u; d1 = [gmask2] (W2^T d2); out = u[0:128] + W1z^T d1, with the image packed
+ *             from the transposed weights (fd_edge_mlp_pack_bwd; gmask1 / gmask2 = the forward's mask2 / mask1);
+ *             save1 = d2, save2 = d1 (operands of the weight-gradient GEMMs), both required.
  * Optional fourth forward layer (zb_out != NULL): zb_out[rows,40] = W40 out + zb_bias, W40 = [linear_b.weight ; down_z.weight]
  * of the NEXT trunk block's IPA (ipa_pytorch.py:380-386,455) -- the pair bias and the down-projected pair features of its
  * attention, taken from the output while it is in registers; the image then carries four more units
  * (fd_edge_mlp_pack_zb, after fd_edge_mlp_pack). */
-#define FD_EDGE_MLP_IMAGE_BYTES (132 * 12288)
+#define FD_EDGE_MLP_IMAGE_BYTES (124 * 12288)
 int fd_edge_mlp_pack_zb(const float* W40, void* image, void* stream);
-/* backward image for the fused-prologue backward (FdEdgeMlpDesc.ln_y): Wf [128,384], W2 [384,384], W1 [384,384] row-major with
- * row stride ld; W40 [40,128] of the IPA block BEHIND the transition or null (then no dzb term) */
+/* forward image: trunk.0.weight W1 [384,384], trunk.2.weight W2 [384,384], final_layer.weight Wf [128,384], row-major with row
+ * stride ld (ipa_pytorch.py:204-216) */
+int fd_edge_mlp_pack(const float* W1, const float* W2, const float* Wf, long ld, void* image, void* stream);
+/* backward image (the transposed chain, hidden chunks in the order the backward kernel walks them); W40 [40,128] of the IPA block
+ * BEHIND the transition or null: four leading units for the dzb term of the fused prologue (FdEdgeMlpDesc.dzb) */
 int fd_edge_mlp_pack_bwd(const float* Wf, const float* W2, const float* W1, long ld, const float* W40, void* image, void* stream);
-int fd_edge_mlp_pack(const float* A1, long rs1, long cs1, const float* A2, long rs2, long cs2, const float* A3,
-                     long rs3, long cs3, const float* A4, long rs4, long cs4, void* image, void* stream);
 typedef struct FdEdgeMlpDesc {
   const float* x;        /* [rows,128] */
   const void* img;       /* weight image of fd_edge_mlp_pack */
   const float* p1;       /* forward: [B*nres,384] term of residue i */
   const float* q1;       /* forward: [B*nres,384] term of residue j (carries the layer-1 bias) */
   const float* bias2;    /* forward: [384] */
-  const float* gate1;    /* backward: [rows,384] h2 */
-  const float* gate2;    /* backward: [rows,384] h1 */
-  float* save1;          /* optional [rows,384] */
-  float* save2;          /* optional [rows,384] */
+  float* save1;          /* [rows,384]: forward (training) h1; backward d2 */
+  float* save2;          /* [rows,384]: forward (training) h2 + [x | 0 | 0]; backward d1 */
   const float* pf;       /* forward: [B*nres,128] */
   const float* qf;       /* forward: [B*nres,128] (carries the final bias) */
   const float* gamma;    /* forward: LayerNorm weight [128] */
   const float* beta;     /* forward: LayerNorm bias [128] */
   const float* rowscale; /* forward, optional: [rows] pair mask */
-  float* y;              /* forward, optional: [rows,128] pre-LayerNorm values */
-  float* mean;           /* forward, optional: [rows] */
-  float* rstd;           /* forward, optional: [rows] */
+  float* y;              /* forward (training), optional: [rows,128] pre-LayerNorm values */
+  float* mean;           /* forward (training), optional: [rows] */
+  float* rstd;           /* forward (training), optional: [rows] */
   float* out;            /* [rows,128] */
   long rows;             /* B * nres * nres */
   int nres;
@@ -153,10 +156,10 @@ typedef struct FdEdgeMlpDesc {
   long ld_pqf;           /* row stride of pf / qf (0 = 128) */
   float* zb_out;         /* forward, optional: [rows,40] (see above) */
   const float* zb_bias;  /* forward, optional: [40] */
-  unsigned* mask1;       /* forward, optional: [rows,12] packed signs of h1: bit 4 nb + e of word 4 c + g <-> unit 128 c + 16 nb + 4 g + e */
-  unsigned* mask2;       /* forward, optional: [rows,12] packed signs of h2 */
-  const unsigned* gmask1; /* backward, optional: the forward's mask2 (replaces gate1: 48 B instead of 1536 B read per row) */
-  const unsigned* gmask2; /* backward, optional: the forward's mask1 (replaces gate2) */
+  unsigned* mask1;       /* forward (training): [rows,12] packed signs of h1: bit 4 nb + e of word 4 c + g <-> unit 128 c + 16 nb + 4 g + e */
+  unsigned* mask2;       /* forward (training): [rows,12] packed signs of h2 */
+  const unsigned* gmask1; /* backward: the forward's mask2 (48 B per row instead of the 1536 B of h2) */
+  const unsigned* gmask2; /* backward: the forward's mask1 */
   /* Backward, optional -- fused prologue (image from fd_edge_mlp_pack_bwd): x is then the UPSTREAM gradient of the transition's
    * output (may be null with dzb), the kernel's own input dy = LayerNorm-backward(x [+ dzb W40]; ln_y, ln_mean, ln_rstd,
    * ln_gamma, ln_rowscale) is formed in registers, written to dy_out (optional) and ln_dgamma / ln_dbeta (+=, optional). */
@@ -518,6 +521,12 @@ int fd_se3_reverse_step_f32(const float* rig_t, const float* rot_score, const fl
                         double b_t, const double* tparams /* optional device {g_rot, b_t}: overrides the scalars,
                         lets one captured hipGraph serve every t */, double dt, double noise_scale,
                         double coord_scale, int center, int diffuse_rot, int diffuse_trans, float* out, void* stream);
+/* The per-step host glue of the reverse loop (experiments/train_se3_diffusion.py:746-781: t = reverse_steps[i], the draws of
+ * diffuser.reverse) as the FIRST NODE of a captured step: idx = *counter; t_out[0..B) = all_t[idx]; tparams[0..2) =
+ * all_tp[2 idx ..] ({g_rot(t), b(t)} of fd_se3_reverse_step); z_out[0..nz) = z_all[(idx % K) nz ..] (K steps of normal draws,
+ * rotation block then translation block per step, refilled by the caller every K steps); *counter = idx + 1.  One block. */
+int fd_sample_advance(int* counter, const float* all_t, const double* all_tp, const double* z_all, int K, long nz, float* t_out,
+                      int B, double* tparams, double* z_out, void* stream);
 
 /* ---- training loss (the step next to the hot path): experiments/train_se3_diffusion.py:524-693 ----
  * Experiment.loss_fn, both rotation branches: translation score / x0 loss, rotation axis + angle (or joint MSE) loss,

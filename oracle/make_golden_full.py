@@ -10,6 +10,10 @@ from the UNMODIFIED reference (model/score_network.py:170-215, experiments/train
                   wrapper around diffuser.reverse snapshots the numpy RNG state to learn the draws it is about to make)
     traj_n128_t50 50 reverse steps (51 forwards) of the unmodified Experiment.inference_fn at B=1 x N=128: error growth of the
                   device-resident / hipGraph-replayed loop over a tenth of the metric's 500-step trajectory
+    traj_n128_t500  THE METRIC'S SCHEDULE: 500 reverse steps (501 forwards, dt = 1/500, the 500-point t grid of
+                  config/inference.yaml) of the unmodified Experiment.inference_fn at B=1 x N=128; every 10th step's frames are
+                  stored, and instead of the 3 MB of normal draws the state of numpy's global generator at the first
+                  diffuser.reverse call (the generator checks that the draws of all 500 calls are consecutive from it)
 
 Run in the build container only (needs /root/reference):  python oracle/make_golden_full.py
 The oracle (oracle/framediff_oracle.py) is pinned against the same runs (PINNING_REPORT_FULL.txt).
@@ -148,11 +152,11 @@ def main():
                             final_rigids=feats_t["rigids_t"].numpy(), final_psi=mo["psi"].numpy(), step_rigids=np.stack(per_step))
         print("trajectory golden (N=128) written", flush=True)
 
-    for name, Bt, Nt, num_t, seed in (("traj_n256", 1, 256, 5, 42), ("traj_n512_b2", 2, 512, 5, 43),
-                                      ("traj_n128_t50", 1, 128, 50, 44)):
+    for name, Bt, Nt, num_t, seed, stride in (("traj_n256", 1, 256, 5, 42, 1), ("traj_n512_b2", 2, 512, 5, 43, 1),
+                                              ("traj_n128_t50", 1, 128, 50, 44, 1), ("traj_n128_t500", 1, 128, 500, 45, 10)):
         if not only or name in only.split(","):
             t0 = time.time()
-            traj_via_experiment(name, Bt, Nt, num_t, seed)
+            traj_via_experiment(name, Bt, Nt, num_t, seed, stride=stride)
             print(f"{name} written ({time.time() - t0:.0f} s)", flush=True)
 
     if not report:
@@ -165,10 +169,12 @@ def main():
     print("wrote", GOLD)
 
 
-def traj_via_experiment(name, B, N, num_t, seed, min_t=0.01, noise_scale=0.1):
+def traj_via_experiment(name, B, N, num_t, seed, min_t=0.01, noise_scale=0.1, stride=1):
     """The reverse loop of the reference's own Experiment.inference_fn (experiments/train_se3_diffusion.py:718-818), called
     unmodified on the reference's ScoreNetwork / SE3Diffuser.  Recorded: the initial draws of sample_ref, the (rot, trans)
-    normal draws of every diffuser.reverse call (se3_diffuser.py:213-262: rotation first), every step's frames, the last psi."""
+    normal draws of every diffuser.reverse call (se3_diffuser.py:213-262: rotation first), every step's frames, the last psi.
+    stride > 1 (the 500-step fixture): every stride-th step's frames, and the generator STATE at the first reverse call instead of
+    the draws themselves (legacy numpy streams are stable across versions; checked here: all draws are consecutive from it)."""
     from hydra.core.hydra_config import HydraConfig
     HydraConfig.initialized = lambda: False
     from experiments import train_se3_diffusion as tr
@@ -194,8 +200,12 @@ def traj_via_experiment(name, B, N, num_t, seed, min_t=0.01, noise_scale=0.1):
     noises = []
     orig_reverse = exp.diffuser.reverse
 
+    first_state = []
+
     def recording_reverse(*a, **kw):
         st = np.random.get_state()
+        if not first_state:
+            first_state.append(st)
         noises.append((np.random.normal(size=(B, N, 3)), np.random.normal(size=(B, N, 3))))
         np.random.set_state(st)
         return orig_reverse(*a, **kw)
@@ -203,6 +213,21 @@ def traj_via_experiment(name, B, N, num_t, seed, min_t=0.01, noise_scale=0.1):
     out = exp.inference_fn(feats, num_t=num_t, min_t=min_t, aux_traj=True, noise_scale=noise_scale)
     rt = np.asarray(out["rigid_traj"])[::-1]            # inference_fn flips the trajectory: back to init, step 1, ...
     assert rt.shape == (num_t + 1, B, N, 7) and np.abs(rt[0] - rig_init.numpy()).max() == 0.0
+    if stride > 1:
+        # nothing but diffuser.reverse consumed the global generator between the calls: the recorded draws are one stream
+        rs = np.random.RandomState()
+        rs.set_state(first_state[0])
+        for zr_, zt_ in noises:
+            assert np.array_equal(rs.normal(size=(B, N, 3)), zr_) and np.array_equal(rs.normal(size=(B, N, 3)), zt_)
+        kind, keys, pos, has_gauss, cached = first_state[0]
+        idx = np.arange(stride - 1, num_t, stride)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), B=B, N=N, num_t=num_t, min_t=min_t, noise_scale=noise_scale,
+                            seed=seed, blocks=4, init_randn=zr, init_rand=ur, init_normal=zt, rig_init=rig_init.numpy(),
+                            rng_keys=np.asarray(keys, dtype=np.uint32), rng_pos=int(pos), rng_has_gauss=int(has_gauss),
+                            rng_cached=float(cached), n_reverse=len(noises), step_index=idx,
+                            final_rigids=rt[-1].astype(np.float32), final_psi=out["psi_pred"][0].numpy(),
+                            step_rigids=rt[1:][idx].astype(np.float32))
+        return
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), B=B, N=N, num_t=num_t, min_t=min_t, noise_scale=noise_scale, seed=seed,
                         blocks=4, init_randn=zr, init_rand=ur, init_normal=zt, rig_init=rig_init.numpy(),
                         z_rot=np.stack([n[0] for n in noises]), z_trans=np.stack([n[1] for n in noises]),

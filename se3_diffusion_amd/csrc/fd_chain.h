@@ -76,11 +76,9 @@ __device__ __forceinline__ void em16_mma_half(f32x4& a0, f32x4& a1, const Em16Ha
 }
 
 // Order of a half-unit's instructions in the stage loops (the fragment reads of half-unit i + 1 are in flight while half-unit i is
-// multiplied).  Default (round 4): one scheduling region per half-unit in which the six ds_read_b128 ride between its first six
-// MFMAs -- a wave's own MFMA stream has no read-issue gap and the compiler keeps the fragments' live ranges short (0 - 9 spilled
-// VGPRs instead of 12 - 34 in fd_edge_mlp.hip): -3 ... -8 % per launch (profiles/r04_edge_variants_*.log).  -DEM_NO_INTERLEAVE: the
-// round-3 order -- the six reads in a block in front of the twelve MFMAs, a sched_barrier between them.
-#ifndef EM_NO_INTERLEAVE
+// multiplied): one scheduling region per half-unit in which the six ds_read_b128 ride between its first six MFMAs -- a wave's own
+// MFMA stream has no read-issue gap and the compiler keeps the fragments' live ranges short: -3 ... -8 % per launch against the
+// six reads standing in a block in front of the twelve MFMAs (round 3's order; profiles/r04_edge_variants_*.log).
 #define EM_PIN_TOP() fd::sched_pin()
 #define EM_PIN_MID()
 // (the six reads ride behind the FIRST six MFMAs -- one each --, so the last one has six MFMAs = ~100 cycles to return before the
@@ -92,8 +90,3 @@ __device__ __forceinline__ void em16_mma_half(f32x4& a0, f32x4& a1, const Em16Ha
     fd::sched_group<0x008, 1>(); fd::sched_group<0x100, 1>(); fd::sched_group<0x008, 1>(); fd::sched_group<0x100, 1>(); \
     fd::sched_group<0x008, 6>();                                                                \
   }
-#else
-#define EM_PIN_TOP()
-#define EM_PIN_MID() fd::sched_pin()
-#define EM_GROUPS(has_read)
-#endif

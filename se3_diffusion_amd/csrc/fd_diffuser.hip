@@ -270,7 +270,38 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(
   }
 }
 
+// First node of a captured diffusion step (sampler.sample, one hipGraph for all num_t steps): the step index lives in a device
+// counter, so the captured launch sequence needs nothing from the host between replays -- it sets the network's time input
+// t[B] = all_t[idx], the reverse step's scalars {g_rot(t), b(t)} = all_tp[idx] and copies the step's normal draws (rotation then
+// translation, se3_diffuser.py:213-262) out of a buffer that holds K steps' worth (refilled by ONE generator launch every K
+// steps), then advances the counter.  Replaces three launches per step (fill_, copy_, normal_) in front of every replay.
+__global__ __launch_bounds__(1024) void sample_advance_kernel(int* __restrict__ counter, const float* __restrict__ all_t,
+                                                              const double* __restrict__ all_tp,
+                                                              const double* __restrict__ z_all, int K, long nz,
+                                                              float* __restrict__ t_out, int B, double* __restrict__ tparams,
+                                                              double* __restrict__ z_out) {
+  const int idx = *counter;                         // (every thread reads it before thread 0 advances it: barrier below)
+  const int tid = (int)threadIdx.x;
+  if (tid < B) t_out[tid] = all_t[idx];
+  if (tid < 2) tparams[tid] = all_tp[2 * idx + tid];
+  const double* __restrict__ src = z_all + (long)(idx % K) * nz;
+  for (long i = tid; i < nz; i += blockDim.x) z_out[i] = src[i];
+  for (int b = tid + (int)blockDim.x; b < B; b += (int)blockDim.x) t_out[b] = all_t[idx];
+  __syncthreads();
+  if (tid == 0) *counter = idx + 1;
+}
+
 }  // namespace
+
+extern "C" int fd_sample_advance(int* counter, const float* all_t, const double* all_tp, const double* z_all, int K, long nz,
+                                 float* t_out, int B, double* tparams, double* z_out, void* stream) {
+  FD_CHECK_ARG(counter && all_t && all_tp && z_all && t_out && tparams && z_out, "fd_sample_advance: null operand");
+  FD_CHECK_ARG(K >= 1 && nz >= 0 && B >= 1, "fd_sample_advance: bad extents");
+  hipLaunchKernelGGL(sample_advance_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counter, all_t, all_tp, z_all, K, nz,
+                     t_out, B, tparams, z_out);
+  FD_CHECK_LAUNCH("fd_sample_advance");
+  return FD_OK;
+}
 
 extern "C" int fd_igso3_tables(const double* sigma, const double* omega, int ns, int no, int L, double* pdf,
                                double* cdf, double* score_norms, void* stream) {

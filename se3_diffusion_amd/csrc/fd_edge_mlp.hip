@@ -1,10 +1,16 @@
 // Edge transition (model/ipa_pytorch.py:194-233) as ONE kernel per direction: the 128 -> 384 -> 384 -> 128 chain of a
 // pair row never leaves the CU.
 //
-//   forward :  h1 = relu(W1z z + P1_i + Q1_j)      h2 = relu(W2 h1 + b2)      y = Wf h2 + Wfz z + Pf_i + Qf_j
+//   forward :  h1 = relu(W1z z + P1_i + Q1_j)      h2 = relu(W2 h1 + b2)      y = Wf (h2 + [z | 0 | 0]) + Pf_i + Qf_j
 //              z' = mask * LayerNorm(y)                          (P/Q: the node halves of W [z | e_i | e_j], trunk.py)
-//   backward:  d2 = [h2 > 0] Wf^T dy               d1 = [h1 > 0] W2^T d2      dz = Wfz^T dy + W1z^T d1
+//   backward:  u = Wf^T dy        d2 = [h2 > 0] u        d1 = [h1 > 0] W2^T d2        dz = u[0:128] + W1z^T d1
 //              (the same dataflow with transposed weights and ReLU gates instead of bias + ReLU)
+//
+// The residual through the final layer (reference: final_layer(trunk(x) + x), ipa_pytorch.py:231) costs NO product of its own
+// (round 5; rounds 2-4 ran Wf[:, :128] z and its transpose as an eight-unit region per direction = 6.25 % of the MFMAs and of
+// the weight stream): the input z is held in the registers in layer-OUTPUT layout, so the forward adds it to the first 128
+// units of h2 before the last layer, and the backward takes the z gradient's first term from the ungated accumulator of the
+// first layer's chunk that covers hidden units 0..127 (that chunk is processed LAST, so the accumulator is simply kept).
 //
 // Arithmetic: the split-bf16 scheme of fd_gemm_split.h -- every fp32 operand is three exact bf16 terms, six bf16 MFMA
 // products per k-step, fp32 accumulation: fp32-accurate (not bitwise an fmaf chain).
@@ -14,32 +20,32 @@
 // (m = l & 15, g = l >> 4) ends up with hidden units n = 16 nb + 4 g + r of ITS OWN row.  Two consecutive 16-blocks of
 // those registers are exactly a B-operand fragment of the next GEMM's 32-k step if the next layer's weights are stored
 // with the k order permuted to match (slot (g, e') <-> k = 16 (e' >> 2) + 4 g + (e' & 3)): activations go accumulator
-// -> relu -> bf16 split -> MFMA operand without touching LDS, without a barrier, without leaving the wave.  LDS only
+// -> relu -> bf16 split -> MFMA operand without touching LDS, without a barrier, without leaving the wave.  The kernel's
+// input is loaded in the same layout (a lane reads columns 16 nb + 4 g .. + 3 of its row).  LDS only
 // streams the weights, packed ONCE per optimiser step (fd_edge_mlp_pack) into bf16-plane fragments in the exact order
 // the kernel consumes them: staging is a straight LDS-DMA copy (global_load_lds_dwordx4, no VGPRs, no VALU) and every
 // fragment read a conflict-free ds_read_b128 of a lane-linear 1 KB piece (PMC: SQ_LDS_BANK_CONFLICT = 0).
 //
-// Block = 4 waves x 16 rows = 64-row tiles, persistent, TWO blocks per CU (<= 256 registers per wave, 48 KB of LDS per
-// block): two waves share a SIMD, so while one waits (LDS fragment, pair-term load, barrier) the other feeds the matrix
-// pipe, and the two blocks of a CU drift apart, so one block's barrier / epilogue runs under the other's MFMAs.
-// Measured at B=30 x N=128 (491,520 rows): first version -- 4 waves x 32 rows, v_mfma_f32_32x32x16_bf16, one
-// 512-register wave per SIMD, every wait of the in-order stream = MFMA idle time -- 1.47 ms, PMC pipe busy 40 %;
-// 8 waves x 16 rows, one block per CU: 1.27 ms, 50 %; this shape: 1.28 ms there and 0.059 vs 0.077 ms on the 16,384 rows
-// of a single N = 128 backbone (256 tiles instead of 128); the unfused launch sequence takes 2.11 / 0.125 ms.
-// Per tile the weight stream is 128 units of 12 KB (4 n-blocks of 16 x one 32-k step x 3 planes) in stages of two
-// units through a two-stage LDS ring; stage s+1 is in flight while stage s is multiplied:
+// Per tile the weight stream is 120 units of 12 KB (4 n-blocks of 16 x one 32-k step x 3 planes) through a two-stage LDS ring;
+// stage s+1 is in flight while stage s is multiplied:
 //     for c in 0..2:   8 units  W1z[n in chunk c]        (layer 1, K = 128)      -> h1 chunk c (32 registers)
 //                     24 units  W2[all n][k in chunk c]  (layer 2, partial K)    -> acc2 (96 registers) += ...
-//     8 units Wfz, 24 units Wf                           (layer 3, K = 128 + 384)
-// Algorithmic HBM bytes per pair row: 512 read + 512 written (PMC: 1.1 KB) (+ h1, h2, y saved for the backward in
+//     24 units Wf                                        (layer 3, K = 384)
+// (backward: the chunks in the order 1, 2, 0 of the hidden units -- see above.)
+// Algorithmic HBM bytes per pair row: 512 read + 512 written (PMC: 1.1 KB) (+ h1, h2 + z, y saved for the backward in
 // training).
 // Two shapes of the same kernel are built (round 4):
-//   fd_edge_mlp.hip itself      4 waves x 64-row tiles, two blocks per CU, 24 KB stages (two units), ring of two: launches with
+//   fd_edge_mlp.hip itself      4 waves x 64-row tiles, two blocks per CU, 24 KB stages (two units): launches with
 //                               few tiles per CU (single backbones)
-//   fd_edge_mlp_w8.hip          8 waves x 128-row tiles, ONE block per CU, 48 KB stages (four units), ring of two: half the barriers
+//   fd_edge_mlp_w8.hip          8 waves x 128-row tiles, ONE block per CU, 48 KB stages (four units): half the barriers
 //                               per MFMA and one weight stream per CU instead of two (half the L2 -> LDS traffic): -5 ... -8 % per
 //                               launch from 65,536 pair rows up (profiles/r04_edge_variants_*.log)
 // (that file defines EM_SHAPE_W8 + the shape macros and includes this one; the pack kernels and the C entry points live here only)
+// Shape history (4 waves x 32 rows on 32x32x16, deeper rings, stepped per-residue terms, non-temporal saves, lumped saves): DESIGN.md
+// section 6 -- the variants that lost are no longer in this source.
+#if defined(EM_PHASE_TIMING) || defined(EM_ABLATE_PQ)
+#include "fd_probe.h"      // timing / ablation hooks: tools/probes builds only (-DFD_PROBE_BUILD)
+#endif
 #include "fd_common.h"
 #include "../../include/fd_hip.h"
 
@@ -55,28 +61,12 @@ namespace {
 
 #include "fd_chain.h"
 
-constexpr int EM_UNITS = 128;              // units per tile
+constexpr int EM_UNITS = 120;              // units per tile
 constexpr int EM_ZB_UNITS = 4;             // + the next IPA block's [linear_b ; down_z] (40 <- 128: 4 k-steps x one n-group)
 constexpr int EM_ZB = 40;
-// the training saves (h1 / h2, d2 / d1: 2 x 755 MB per launch that only the weight-gradient launch reads, much later):
-// -DEM_NT_SAVES stores them with the non-temporal hint
-#ifdef EM_NT_SAVES
-#define EM_SAVE4(p, v) fd::store_nt4((p), (v)[0], (v)[1], (v)[2], (v)[3])
-#else
-#define EM_SAVE4(p, v) (*reinterpret_cast<float4*>(p) = make_float4((v)[0], (v)[1], (v)[2], (v)[3]))
-#endif
-#ifndef EM_RING
-// LDS stages of the weight stream and how many stages ahead of its use a stage's copy is issued (EM_AHEAD <= EM_RING - 1: the
-// slot a copy lands in was last read one barrier ago at the latest).  Round 2: ring 3 / ahead 2 with two 4-wave blocks per CU
-// made the kernel 2-3 % faster on its own but cost 144 KB of LDS per CU, and the training step lost its overlap with the
-// gradient side stream (29.0 vs 26.0 ms).  Round 4 (-DEM_WAVES=8: ONE 8-wave block per CU, one weight stream for 128 rows, half the
-// L2 -> LDS traffic): the ring can be four or five 24 KB stages deep.
-#define EM_RING 2
-#endif
-#ifndef EM_AHEAD
-#define EM_AHEAD (EM_RING - 1)
-#endif
-static_assert(EM_AHEAD >= 1 && EM_AHEAD <= 3 && EM_AHEAD <= EM_RING - 1, "copy distance: 1..3 stages, at most ring - 1");
+// LDS ring of the weight stream: two stages, the copy of stage s + 1 in flight while stage s is multiplied (deeper rings measured
+// in rounds 2 and 4: no gain on the one-block-per-CU shape, and 144 KB per CU cost the step its overlap with the gradient stream)
+constexpr int EM_RING = 2;
 constexpr int EM_H = 384, EM_C = 128;
 
 // Probe build only (tools/probes/edge_phases.py compiles this file with -DEM_PHASE_TIMING into its own library): wave-level
@@ -86,7 +76,7 @@ constexpr int EM_H = 384, EM_C = 128;
 #ifdef EM_PHASE_TIMING
 __device__ unsigned long long em_phase[12];
 #define EM_TICK_TO(var)                                                \
-  if (!MASK) { /* (the MASK instantiations trip a code-generator assertion with the timers in: not timed) */ \
+  {                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                 \
     const long long t_ = (long long)__builtin_amdgcn_s_memtime();      \
     __builtin_amdgcn_sched_barrier(0);                                 \
@@ -105,41 +95,35 @@ struct EmMat {
   long rs, cs;
 };
 
-// weight image: 128 units in consumption order; a unit = [4 n-blocks of 16][3 planes][64 lanes] x 16 B for one 32-k
-// step; the fragment of lane (n = l & 15, g = l >> 4) holds slots e' = 0..7.  natural k order (operand loaded from
-// memory): k = k0 + 8 g + e'; chained k order (operand = the previous layer's accumulator): k = k0 + 16 (e' >> 2) +
-// 4 g + (e' & 3).  Unit order inside a region: k-step major, n-group minor (the activation planes of a k-step are split
-// once and reused by its n-groups).
-// x_chained: the two regions that consume the kernel's INPUT (layer 1, layer 3's x part) in chained k order too -- the backward
-// with the fused LayerNorm-backward prologue holds its input in layer-output register layout
-__global__ __launch_bounds__(256) void edge_mlp_pack16_kernel(EmMat A1, EmMat A2, EmMat A3, EmMat A4, char* __restrict__ img,
-                                                              int x_chained) {
+// weight image: 120 units in consumption order; a unit = [4 n-blocks of 16][3 planes][64 lanes] x 16 B for one 32-k
+// step; the fragment of lane (n = l & 15, g = l >> 4) holds slots e' = 0..7 in CHAINED k order (every operand of the chain,
+// the kernel's input included, sits in the registers in layer-output layout): k = k0 + 16 (e' >> 2) + 4 g + (e' & 3).
+// Unit order inside a region: k-step major, n-group minor (the activation planes of a k-step are split once and reused by its
+// n-groups).  A1 [384,128] layer 1, A2 [384,384] layer 2, A4 [128,384] layer 3.
+// rot: the image's chunk c holds the hidden units of chunk (c + rot) % 3 (backward: 1 -- hidden units 0..127 last, see the top)
+__global__ __launch_bounds__(256) void edge_mlp_pack16_kernel(EmMat A1, EmMat A2, EmMat A4, char* __restrict__ img, int rot) {
   const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x);   // (unit, n-block, lane)
   if (gid >= EM_UNITS * 4 * 64) return;
   const int lane = gid & 63, i = (gid >> 6) & 3, u = gid >> 8;
   const int m = lane & 15, g = lane >> 4;
   EmMat M;
   int n, k0;
-  bool chained;
   if (u < 96) {
-    const int c = u / 32, r = u % 32;
-    if (r < 8) {                    // layer 1: k-step r >> 1, n-group r & 1 of chunk c
-      M = A1; n = 128 * c + 64 * (r & 1) + 16 * i + m; k0 = 32 * (r >> 1); chained = x_chained != 0;
-    } else {                        // layer 2: k-step (r - 8) / 6 of chunk c, n-group (r - 8) % 6
+    const int c = u / 32, r = u % 32, hc = (c + rot) % 3;
+    if (r < 8) {                    // layer 1: k-step r >> 1, n-group r & 1 of hidden chunk hc
+      M = A1; n = 128 * hc + 64 * (r & 1) + 16 * i + m; k0 = 32 * (r >> 1);
+    } else {                        // layer 2: k-step (r - 8) / 6 of hidden chunk hc, n-group (r - 8) % 6
       const int r2 = r - 8;
-      M = A2; n = 64 * (r2 % 6) + 16 * i + m; k0 = 128 * c + 32 * (r2 / 6); chained = true;
+      M = A2; n = 64 * (r2 % 6) + 16 * i + m; k0 = 128 * hc + 32 * (r2 / 6);
     }
-  } else if (u < 104) {             // layer 3, x part
-    const int r = u - 96;
-    M = A3; n = 64 * (r & 1) + 16 * i + m; k0 = 32 * (r >> 1); chained = x_chained != 0;
-  } else {                          // layer 3, hidden part
-    const int v = u - 104;
-    M = A4; n = 64 * (v & 1) + 16 * i + m; k0 = 32 * (v >> 1); chained = true;
+  } else {                          // layer 3
+    const int v = u - 96;
+    M = A4; n = 64 * (v & 1) + 16 * i + m; k0 = 32 * (v >> 1);
   }
   float x[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const int k = chained ? k0 + 16 * (e >> 2) + 4 * g + (e & 3) : k0 + 8 * g + e;
+    const int k = k0 + 16 * (e >> 2) + 4 * g + (e & 3);
     x[e] = M.p[(long)n * M.rs + (long)k * M.cs];
   }
   uint4 s0, s1, s2;
@@ -150,7 +134,7 @@ __global__ __launch_bounds__(256) void edge_mlp_pack16_kernel(EmMat A1, EmMat A2
   *reinterpret_cast<uint4*>(dst + 2 * EM_PIECE) = s2;
 }
 
-// units 128..131 of the forward image: W40 = [linear_b.weight ; down_z.weight] [40,128] of the NEXT trunk block's IPA
+// units 120..123 of the forward image: W40 = [linear_b.weight ; down_z.weight] [40,128] of the NEXT trunk block's IPA
 // (ipa_pytorch.py:380-386,455), rows 40..63 zero, chained k order (its operand is the LayerNorm output in registers)
 __global__ __launch_bounds__(256) void edge_mlp_pack_zb_kernel(const float* __restrict__ W40, char* __restrict__ img) {
   const int gid = (int)(blockIdx.x * blockDim.x + threadIdx.x);   // (k-step, n-block, lane)
@@ -199,15 +183,19 @@ __global__ __launch_bounds__(256) void edge_mlp_pack_zbw_kernel(const float* __r
 // ZB (forward only): a fourth chained layer on the kernel's own output -- zb = [linear_b ; down_z] z' + b40 of the next
 // trunk block's IPA -- so that block needs no pass over z' [P,128] for it (fd_gemm: 119 us per block at B=30 x N=128, 252 MB
 // read); +3 % of the chain's MFMAs, 160 B more written per pair row
-// MASK (forward, training): also write the packed signs of h1 / h2 for the backward's gates
+// TRAIN (forward): the saves of the backward -- save1 = h1, save2 = h2 + [z | 0 | 0] (the operand of the final layer's weight
+// gradient; the ReLU gates of the backward come from the masks, so nobody needs h2 alone), the packed signs of h1 / h2 (mask1 /
+// mask2), optionally y / mean / rstd of the LayerNorm.  The saves leave the wave two 16-blocks at a time where the next layer
+// splits them.  The backward always saves (save1 = d2, save2 = d1: the operands of the weight gradients) and always gates on
+// the packed masks.
 // LNB (backward): the kernel's input dy is formed HERE from the upstream gradient of the transition's output -- the LayerNorm
-// backward of ipa_pytorch.py:232 (dgamma / dbeta accumulated in LDS, one atomic per column and block) -- in layer-output
-// register layout; the backward image then holds its two x-consuming regions in chained k order (fd_edge_mlp_pack x_chained).
+// backward of ipa_pytorch.py:232 (dgamma / dbeta accumulated in LDS, one atomic per column and block).
 // ZBW (with LNB): and the upstream gradient first gets the IPA pair-projection term  dz += dzb W40  of the block behind this
 // transition (autograd of linear_b / down_z w.r.t. z, ipa_pytorch.py:380-386,455) as a K = 40 product on four leading units.
-// SV: save1 and save2 are both given (training) and leave the wave two 16-blocks at a time where the next layer splits them
-template <bool BWD, bool ZB = false, bool MASK = false, bool LNB = false, bool ZBW = false, bool SV = false>
+template <bool BWD, bool ZB = false, bool TRAIN = false, bool LNB = false, bool ZBW = false>
 __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpDesc d) {
+  static_assert(!BWD || (!ZB && TRAIN), "backward: no zb layer, always with the saves");
+  static_assert(BWD || (!LNB && !ZBW), "the fused prologue is a backward option");
   constexpr int EM_NSTAGE = (EM_UNITS + (ZB ? EM_ZB_UNITS : 0) + (ZBW ? EM_ZB_UNITS : 0)) / EM_UPS;
   __shared__ __attribute__((aligned(16))) char lds[EM_RING * EM_STAGE];
   __shared__ float lnacc[LNB ? 2 * EM_C : 1];      // dgamma | dbeta of the fused LayerNorm backward
@@ -249,7 +237,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
   const int nmine = (ntiles - first + G - 1) / G;
   const int total_stages = dyn ? 0x7fffffff : nmine * EM_NSTAGE;   // (dyn: the weight stream keeps one stage ahead to the end)
 
-  // ---- weight stream: every wave copies an eighth (6 pieces) of each stage; stage s lives in buffer s & 1 ----
+  // ---- weight stream: every wave copies its share (EM_PPW pieces) of each stage; stage s lives in buffer s & 1 ----
   const char* __restrict__ img_lane = static_cast<const char*>(d.img) + wave * (EM_STAGE / EM_WAVES) + lane * 16;
   char* const lds_wave = lds + wave * (EM_STAGE / EM_WAVES);
   int issued = 0, consumed = 0;
@@ -267,19 +255,8 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
   // begin the next stage: its copy (issued one stage ago) has landed and is visible to the block; every wave is done
   // with the previous stage, whose buffer takes the copy after next.  Returns the stage's LDS address + 16 * lane.
   auto stage_begin = [&]() __attribute__((always_inline)) -> const char* {
-    // EM_AHEAD > 1: the copies of the stages AFTER this one (EM_PPW LDS-DMA instructions per wave and stage, issued during the
-    // previous stages) may stay in flight across the barrier; no younger copy in flight -- the last stage of the launch: wait for
-    // everything
     EM_TICK_TO(tb_);
-    // (vmcnt retires in issue order: "at most y x EM_PPW outstanding" = this stage's copy, issued before the y younger stages'
-    // copies, has landed; any other memory operation issued since only makes the wait stricter)
-    const int younger = issued - consumed - 1;
-    if (EM_AHEAD >= 3 && younger >= 2)
-      fd::wait_vmem_keep<2 * EM_PPW>();
-    else if (EM_AHEAD >= 2 && younger >= 1)
-      fd::wait_vmem_keep<EM_PPW>();
-    else
-      fd::wait_vmem();
+    fd::wait_vmem();
     __syncthreads();
     EM_TICK_TO(p1_);
     const char* cur = lds + (consumed % EM_RING) * EM_STAGE + lane * 16;
@@ -287,14 +264,11 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
     return cur;
   };
   // the copy of the stage after this one goes out behind the first unit's fragment reads and MFMAs (it has the other
-  // three units' time to land; issuing it first would put ~500 cycles of LDS-DMA issue in front of every stage)
+  // units' time to land; issuing it first would put ~500 cycles of LDS-DMA issue in front of every stage)
   auto stage_prefetch = [&]() __attribute__((always_inline)) {
     if (issued < total_stages) issue_stage();
   };
   issue_stage();
-#pragma unroll
-  for (int a = 1; a < EM_AHEAD; ++a)
-    if (a < total_stages) issue_stage();
   if (LNB) {
     if (tid < 2 * EM_C) lnacc[tid] = 0.f;           // (ordered before its first use by the first stage barrier / the one below)
     __syncthreads();
@@ -310,27 +284,17 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
     const long qi = rc / d.nres;                  // (b, i)
     const long qj = (qi / d.nres) * d.nres + (rc - qi * d.nres);   // (b, j)
 
-    // x in B-operand layout: k = 32 ks + 8 g + e  (LNB: slot e' of k-step ks holds k = 32 ks + 16 (e' >> 2) + 4 g + (e' & 3))
-    float xr[4][8];
-    if (!LNB) {
-      const float* xp = d.x + rc * EM_C + 8 * g;
+    // the kernel's input row in layer-output layout: lane (m, g) holds columns 16 nb + 4 g + r -- two consecutive blocks are the
+    // B operand of a 32-k step in chained k order
+    f32x4 X[8];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const float4 v = *reinterpret_cast<const float4*>(xp + 32 * ks);
-        const float4 w = *reinterpret_cast<const float4*>(xp + 32 * ks + 4);
-        xr[ks][0] = v.x; xr[ks][1] = v.y; xr[ks][2] = v.z; xr[ks][3] = v.w;
-        xr[ks][4] = w.x; xr[ks][5] = w.y; xr[ks][6] = w.z; xr[ks][7] = w.w;
-      }
-    } else {
-      // ---- fused prologue of the backward: dz (upstream) [+ dzb W40]  ->  LayerNorm backward  ->  dy, in layer-output layout
-      // (lane (m, g): columns 16 nb + 4 g + r) ----
-      f32x4 X[8];
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (d.x != nullptr) v = *reinterpret_cast<const float4*>(d.x + rc * EM_C + 16 * nb + 4 * g);
-        X[nb][0] = v.x; X[nb][1] = v.y; X[nb][2] = v.z; X[nb][3] = v.w;
-      }
+    for (int nb = 0; nb < 8; ++nb) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!LNB || d.x != nullptr) v = *reinterpret_cast<const float4*>(d.x + rc * EM_C + 16 * nb + 4 * g);
+      X[nb][0] = v.x; X[nb][1] = v.y; X[nb][2] = v.z; X[nb][3] = v.w;
+    }
+    if (LNB) {
+      // ---- fused prologue of the backward: dz (upstream) [+ dzb W40]  ->  LayerNorm backward  ->  dy ----
       if (ZBW) {
         // X += dzb W40: operand = the row's 40 values of dzb in natural k order (two 32-k steps, zero beyond k = 40), four
         // leading units of the image = W40^T (n = 128 columns in two n-groups), the upstream gradient as the initial value
@@ -360,7 +324,6 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
             const int r = EM_UPS * sg + (hh >> 1), g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
             EM_PIN_TOP();
             if (hh + 1 < 2 * EM_UPS) em16_read_half(Hz[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-            EM_PIN_MID();
             if (g2 == 0 && (hh & 1) == 0) em_split8(kz[r >> 1], bz[0], bz[1], bz[2]);
             em16_mma_half(X[a], X[a + 1], Hz[hh & 1], bz);
             EM_GROUPS(hh + 1 < 2 * EM_UPS);
@@ -414,19 +377,13 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
             *reinterpret_cast<float4*>(d.dy_out + row * EM_C + col) = make_float4(X[nb][0], X[nb][1], X[nb][2], X[nb][3]);
         }
       }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xr[ks][e] = X[2 * ks + (e >> 2)][e & 3];
     }
 
     EM_BODY_TO(LNB ? 9 : 0);
-    // backward with packed ReLU gates (gmask1 / gmask2: the forward's mask2 / mask1 outputs): bit 4 nb + e of word (row, chunk c,
-    // g) says whether hidden unit 128 c + 16 nb + 4 g + e was positive -- 6 dwords per lane and tile, fetched here, instead of
-    // 3 KB of h2 / h1 per row fetched (and waited for) inside the epilogues
+    // backward: packed ReLU gates (gmask1 / gmask2 = the forward's mask2 / mask1 outputs): bit 4 nb + e of word (row, chunk c, g)
+    // says whether hidden unit 128 c + 16 nb + 4 g + e was positive -- 6 dwords per lane and tile, fetched here
     unsigned gm1[3] = {0u, 0u, 0u}, gm2[3] = {0u, 0u, 0u};
-    const bool packed_gates = BWD && d.gmask1 != nullptr;
-    if (packed_gates) {
+    if (BWD) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         gm1[c] = d.gmask1[rc * 12 + 4 * c + g];
@@ -444,38 +401,13 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
       acc2[nb][0] = a.x; acc2[nb][1] = a.y; acc2[nb][2] = a.z; acc2[nb][3] = a.w;
     }
 
-    // -DEM_PQ_STEP (measured in round 4, NOT the default): the per-residue terms P1_i / Q1_j of epilogue 1 two 16-blocks (one
-    // k-step of layer 2) at a time -- requested one step ahead into 16 registers, consumed behind a stage boundary whose vmcnt wait
-    // has already retired them -- instead of sixteen loads issued and waited for between layer 1 and layer 2 (6 % of a forward
-    // launch, profiles/r03_edge_phases.txt).  The 16 registers cost 44 - 64 spilled VGPRs and the launch is no faster (B=30 x N=128:
-    // 1.20-1.33 / 1.55-1.61 ms against 1.23 / 1.59; B=8 x N=512 with saves 6.30 against 5.97 ms, profiles/r04_edge_variants_round3_*).
-#ifdef EM_PQ_STEP
-    constexpr bool PQ_STEP = !BWD;
-#else
-    constexpr bool PQ_STEP = false;
-#endif
-    // SV: the training saves (h1 / h2 forward, d2 / d1 backward) leave the wave two 16-blocks at a time where the next layer splits
-    // them (otherwise, and in rounds 2-3 always: 8 / 24 stores back to back in epilogues 1 / 2 behind run-time null checks)
-    constexpr bool STORE_SPREAD = SV;
-    float4 pq[4];        // P (blocks 2 ks, 2 ks + 1), Q (the same blocks)
-    auto pq_load = [&](int cn, int kn) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int col = 128 * cn + 16 * (2 * kn + i) + 4 * g;
-#ifdef EM_ABLATE_PQ
-        pq[i] = make_float4(0.1f, 0.2f, -0.1f, 0.f);
-        pq[2 + i] = make_float4(0.f, 0.1f, 0.f, -0.2f);
-#else
-        pq[i] = *reinterpret_cast<const float4*>(d.p1 + qi * ld_pq + col);
-        pq[2 + i] = *reinterpret_cast<const float4*>(d.q1 + qj * ld_pq + col);
-#endif
-      }
-    };
-    if (PQ_STEP) pq_load(0, 0);
-
+    f32x4 acc1[8];
+#pragma clang loop unroll(full)
     for (int c = 0; c < 3; ++c) {
-      // ---- layer 1, chunk c: 128 hidden units x K = 128: units (k-step r >> 1, n-group r & 1) ----
-      f32x4 acc1[8];
+      // hidden chunk of this pass: the backward walks 1, 2, 0 so that the UNGATED layer-1 accumulator of hidden units 0..127 -- the
+      // first term of dz = (Wf^T dy)[0:128] + W1z^T d1 -- is the one still in the registers when layer 3 starts
+      const int hc = BWD ? (c + 1) % 3 : c;
+      // ---- layer 1, chunk hc: 128 hidden units x K = 128: units (k-step r >> 1, n-group r & 1) ----
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
@@ -489,94 +421,63 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
           const int r = EM_UPS * sg + (hh >> 1), g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
           EM_PIN_TOP();
           if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-          EM_PIN_MID();
-          if (g2 == 0 && (hh & 1) == 0) em_split8(xr[r >> 1], b[0], b[1], b[2]);
+          if (g2 == 0 && (hh & 1) == 0) em16_split2(X[2 * (r >> 1)], X[2 * (r >> 1) + 1], b[0], b[1], b[2]);
           em16_mma_half(acc1[a], acc1[a + 1], H[hh & 1], b);
           EM_GROUPS(hh + 1 < 2 * EM_UPS);
           if (hh == 1) stage_prefetch();
         }
       }
-      // epilogue 1: forward  h1 = relu(acc + P1_i + Q1_j);  backward  d2 = acc gated by h2 > 0
-      // (-DEM_PQ_STEP: the forward's, in four pieces behind the first four stage boundaries of layer 2 instead)
+      // epilogue 1, forward: h1 = relu(acc + P1_i + Q1_j)   (backward: the gate is applied where layer 2 splits the blocks)
       EM_BODY_TO(2);
-      unsigned bits1 = 0u;
+      if (!BWD) {
+        unsigned bits1 = 0u;
 #pragma unroll
-      for (int nb = 0; nb < (PQ_STEP ? 0 : 8); ++nb) {
-        const int col = 128 * c + 16 * nb + 4 * g;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc1[nb][e];
-        if (!BWD) {
+        for (int nb = 0; nb < 8; ++nb) {
+          const int col = 128 * hc + 16 * nb + 4 * g;
 #ifdef EM_ABLATE_PQ      // (probe build only: what the kernel would take if the per-residue terms cost no fetch)
           const float4 a = make_float4(0.1f, 0.2f, -0.1f, 0.f), bq = make_float4(0.f, 0.1f, 0.f, -0.2f);
 #else
           const float4 a = *reinterpret_cast<const float4*>(d.p1 + qi * ld_pq + col);
           const float4 bq = *reinterpret_cast<const float4*>(d.q1 + qj * ld_pq + col);
 #endif
-          v[0] += a.x + bq.x; v[1] += a.y + bq.y; v[2] += a.z + bq.z; v[3] += a.w + bq.w;
+          float v[4] = {acc1[nb][0] + (a.x + bq.x), acc1[nb][1] + (a.y + bq.y), acc1[nb][2] + (a.z + bq.z),
+                        acc1[nb][3] + (a.w + bq.w)};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if (MASK) bits1 |= (v[e] > 0.f ? 1u : 0u) << (4 * nb + e);
-            v[e] = v[e] > 0.f ? v[e] : 0.f;
+            if (TRAIN) bits1 |= (v[e] > 0.f ? 1u : 0u) << (4 * nb + e);
+            acc1[nb][e] = v[e] > 0.f ? v[e] : 0.f;
           }
-        } else if (packed_gates) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ((gm1[c] >> (4 * nb + e)) & 1u) ? v[e] : 0.f;
-        } else {
-          const float4 gt = *reinterpret_cast<const float4*>(d.gate1 + rc * EM_H + col);
-          v[0] = gt.x > 0.f ? v[0] : 0.f; v[1] = gt.y > 0.f ? v[1] : 0.f;
-          v[2] = gt.z > 0.f ? v[2] : 0.f; v[3] = gt.w > 0.f ? v[3] : 0.f;
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc1[nb][e] = v[e];
-        if (!STORE_SPREAD && d.save1 != nullptr && rok)
-          *reinterpret_cast<float4*>(d.save1 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
+        if (TRAIN && rok) d.mask1[row * 12 + 4 * hc + g] = bits1;
       }
-      if (!PQ_STEP && !BWD && MASK && rok) d.mask1[row * 12 + 4 * c + g] = bits1;
       EM_BODY_TO(3);
-      // ---- layer 2, k in chunk c: units (k-step u2 / 6, n-group u2 % 6) ----
+      // ---- layer 2, k in chunk hc: units (k-step u2 / 6, n-group u2 % 6) ----
 #pragma clang loop unroll(full)
       for (int sg = 0; sg < 24 / EM_UPS; ++sg) {
         const char* st = stage_begin();
-        if (PQ_STEP && (EM_UPS * sg) % 4 == 0 && (EM_UPS * sg) / 4 < 4) {
-          // Epilogue 1 of the two 16-blocks that k-step ks = u2 / 4 of layer 2 consumes (k-step ks starts at unit 6 ks >= 4 ks),
-          // HERE: right behind a stage boundary, whose vmcnt wait has already retired the per-residue terms requested one step
-          // ago -- no wait of its own; then the request for the next step's terms (the next chunk's first step after the last).
-          const int ks = (EM_UPS * sg) / 4;
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int nb = 2 * ks + i, col = 128 * c + 16 * nb + 4 * g;
-            float v[4];
-            v[0] = acc1[nb][0] + (pq[i].x + pq[2 + i].x); v[1] = acc1[nb][1] + (pq[i].y + pq[2 + i].y);
-            v[2] = acc1[nb][2] + (pq[i].z + pq[2 + i].z); v[3] = acc1[nb][3] + (pq[i].w + pq[2 + i].w);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if (MASK) bits1 |= (v[e] > 0.f ? 1u : 0u) << (4 * nb + e);
-              v[e] = v[e] > 0.f ? v[e] : 0.f;
-              acc1[nb][e] = v[e];
-            }
-            if (d.save1 != nullptr && rok)
-              *reinterpret_cast<float4*>(d.save1 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
-          }
-          if (MASK && ks == 3 && rok) d.mask1[row * 12 + 4 * c + g] = bits1;
-          const int cn = ks < 3 ? c : c + 1, kn = ks < 3 ? ks + 1 : 0;
-          if (cn < 3) pq_load(cn, kn);
-        }
         em16_read_half(H[0], st);
 #pragma clang loop unroll(full)
         for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
           const int u2 = EM_UPS * sg + (hh >> 1), ks = u2 / 6, g6 = u2 % 6, a = 4 * g6 + 2 * (hh & 1);
           EM_PIN_TOP();
           if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-          EM_PIN_MID();
           if (g6 == 0 && (hh & 1) == 0) {
-            em16_split2(acc1[2 * ks], acc1[2 * ks + 1], b[0], b[1], b[2]);
-            if (STORE_SPREAD && !PQ_STEP && rok) {
-              // the save of h1 / d2: the two 16-blocks this k-step consumes, HERE (two stores per six units of MFMAs) instead
-              // of eight back to back in the epilogue
+            // the two 16-blocks this k-step consumes: (backward) gated, split, and (training) saved HERE -- two stores per six
+            // units of MFMAs instead of eight back to back in an epilogue
+            f32x4 t[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float v = acc1[2 * ks + i][e];
+                t[i][e] = BWD ? (((gm1[hc] >> (4 * (2 * ks + i) + e)) & 1u) ? v : 0.f) : v;
+              }
+            em16_split2(t[0], t[1], b[0], b[1], b[2]);
+            if (TRAIN && rok) {
 #pragma unroll
               for (int i = 0; i < 2; ++i)
-                EM_SAVE4(d.save1 + row * EM_H + 128 * c + 16 * (2 * ks + i) + 4 * g, acc1[2 * ks + i]);
+                *reinterpret_cast<float4*>(d.save1 + row * EM_H + 128 * hc + 16 * (2 * ks + i) + 4 * g) =
+                    make_float4(t[i][0], t[i][1], t[i][2], t[i][3]);
             }
           }
           em16_mma_half(acc2[a], acc2[a + 1], H[hh & 1], b);
@@ -586,62 +487,35 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
       }
     }
 
-    // epilogue 2: forward  h2 = relu(acc2);  backward  d1 = acc2 gated by h1 > 0
+    // epilogue 2: forward  h2 = relu(acc2), + z on the first 128 units (the residual into the final layer);  backward  d1 = acc2
+    // gated by h1 > 0
     EM_BODY_TO(4);
     unsigned bits2 = 0u;
 #pragma unroll
     for (int nb = 0; nb < 24; ++nb) {
-      const int col = 16 * nb + 4 * g;
-      float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc2[nb][e];
-      if (!BWD) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (MASK) bits2 |= (v[e] > 0.f ? 1u : 0u) << (4 * (nb & 7) + e);
-          v[e] = v[e] > 0.f ? v[e] : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        const float v = acc2[nb][e];
+        if (!BWD) {
+          if (TRAIN) bits2 |= (v > 0.f ? 1u : 0u) << (4 * (nb & 7) + e);
+          acc2[nb][e] = (v > 0.f ? v : 0.f) + (nb < 8 ? X[nb & 7][e] : 0.f);
+        } else {
+          acc2[nb][e] = ((gm2[nb >> 3] >> (4 * (nb & 7) + e)) & 1u) ? v : 0.f;
         }
-      } else if (packed_gates) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = ((gm2[nb >> 3] >> (4 * (nb & 7) + e)) & 1u) ? v[e] : 0.f;
-      } else {
-        const float4 gt = *reinterpret_cast<const float4*>(d.gate2 + rc * EM_H + col);
-        v[0] = gt.x > 0.f ? v[0] : 0.f; v[1] = gt.y > 0.f ? v[1] : 0.f;
-        v[2] = gt.z > 0.f ? v[2] : 0.f; v[3] = gt.w > 0.f ? v[3] : 0.f;
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc2[nb][e] = v[e];
-      if (!STORE_SPREAD && d.save2 != nullptr && rok)
-        *reinterpret_cast<float4*>(d.save2 + row * EM_H + col) = make_float4(v[0], v[1], v[2], v[3]);
-      if (!BWD && MASK && (nb & 7) == 7) {
+      if (!BWD && TRAIN && (nb & 7) == 7) {
         if (rok) d.mask2[row * 12 + 4 * (nb >> 3) + g] = bits2;
         bits2 = 0u;
       }
     }
 
     EM_BODY_TO(5);
-    // ---- layer 3: 128 outputs x (K = 128 of x, then K = 384 of the hidden layer) ----
+    // ---- layer 3: 128 outputs x K = 384 of the hidden layer; the backward starts from (Wf^T dy)[0:128], ungated ----
     f32x4 acc3[8];
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc3[nb][r] = 0.f;
-#pragma clang loop unroll(full)
-    for (int sg = 0; sg < 8 / EM_UPS; ++sg) {
-      const char* st = stage_begin();
-      em16_read_half(H[0], st);
-#pragma clang loop unroll(full)
-      for (int hh = 0; hh < 2 * EM_UPS; ++hh) {
-        const int r = EM_UPS * sg + (hh >> 1), g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
-        EM_PIN_TOP();
-        if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-        EM_PIN_MID();
-        if (g2 == 0 && (hh & 1) == 0) em_split8(xr[r >> 1], b[0], b[1], b[2]);
-        em16_mma_half(acc3[a], acc3[a + 1], H[hh & 1], b);
-        EM_GROUPS(hh + 1 < 2 * EM_UPS);
-        if (hh == 1) stage_prefetch();
-      }
-    }
+      for (int r = 0; r < 4; ++r) acc3[nb][r] = BWD ? acc1[nb][r] : 0.f;
 #pragma clang loop unroll(full)
     for (int sg = 0; sg < 24 / EM_UPS; ++sg) {
       const char* st = stage_begin();
@@ -651,12 +525,13 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
         const int v = EM_UPS * sg + (hh >> 1), ks = v >> 1, g2 = v & 1, a = 4 * g2 + 2 * (hh & 1);
         EM_PIN_TOP();
         if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-        EM_PIN_MID();
         if (g2 == 0 && (hh & 1) == 0) {
           em16_split2(acc2[2 * ks], acc2[2 * ks + 1], b[0], b[1], b[2]);
-          if (STORE_SPREAD && rok) {      // the save of h2 / d1, two blocks per k-step of layer 3
+          if (TRAIN && rok) {      // the save of h2 + [z | 0 | 0] / d1, two blocks per k-step of layer 3
 #pragma unroll
-            for (int i = 0; i < 2; ++i) EM_SAVE4(d.save2 + row * EM_H + 16 * (2 * ks + i) + 4 * g, acc2[2 * ks + i]);
+            for (int i = 0; i < 2; ++i)
+              *reinterpret_cast<float4*>(d.save2 + row * EM_H + 16 * (2 * ks + i) + 4 * g) =
+                  make_float4(acc2[2 * ks + i][0], acc2[2 * ks + i][1], acc2[2 * ks + i][2], acc2[2 * ks + i][3]);
           }
         }
         em16_mma_half(acc3[a], acc3[a + 1], H[hh & 1], b);
@@ -681,7 +556,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
 #endif
         acc3[nb][0] += pa.x + qa.x; acc3[nb][1] += pa.y + qa.y; acc3[nb][2] += pa.z + qa.z; acc3[nb][3] += pa.w + qa.w;
         s += (acc3[nb][0] + acc3[nb][1]) + (acc3[nb][2] + acc3[nb][3]);
-        if (d.y != nullptr && rok)
+        if (TRAIN && d.y != nullptr && rok)
           *reinterpret_cast<float4*>(d.y + row * EM_C + col) = make_float4(acc3[nb][0], acc3[nb][1], acc3[nb][2], acc3[nb][3]);
       }
       s += __shfl_xor(s, 16);
@@ -700,7 +575,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
       vs += __shfl_xor(vs, 32);
       const float rstd = 1.0f / sqrtf(vs * (1.0f / 128.0f) + d.eps);
       const float rs = d.rowscale != nullptr ? d.rowscale[rc] : 1.f;
-      if (rok && g == 0) {
+      if (TRAIN && rok && g == 0) {
         if (d.mean != nullptr) d.mean[row] = mean;
         if (d.rstd != nullptr) d.rstd[row] = rstd;
       }
@@ -736,7 +611,6 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
             const int ks = EM_UPS * sg + (hh >> 1), a = 2 * (hh & 1);
             EM_PIN_TOP();
             if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-            EM_PIN_MID();
             if ((hh & 1) == 0) em16_split2(acc3[2 * ks], acc3[2 * ks + 1], b[0], b[1], b[2]);
             em16_mma_half(acc4[a], acc4[a + 1], H[hh & 1], b);
             EM_GROUPS(hh + 1 < 2 * EM_UPS);
@@ -816,27 +690,16 @@ int EM_LAUNCH(const FdEdgeMlpDesc& d, hipStream_t st) {
   } else {
     dd.sched = nullptr;
   }
-  const bool zbv = d.zb_out != nullptr, mk = d.mask1 != nullptr;
-#ifdef EM_STORE_LUMP
-  const bool sv = false;
-#else
-  const bool sv = d.save1 != nullptr && d.save2 != nullptr;
-#endif
+  const bool zbv = d.zb_out != nullptr, train = d.save1 != nullptr;
 #define EM_GO(...) hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mlp16_kernel<__VA_ARGS__>), g3, b3, 0, st, dd)
-  if (d.backward && d.ln_y != nullptr && d.dzb != nullptr) {
-    if (sv) EM_GO(true, false, false, true, true, true); else EM_GO(true, false, false, true, true, false);
-  } else if (d.backward && d.ln_y != nullptr) {
-    if (sv) EM_GO(true, false, false, true, false, true); else EM_GO(true, false, false, true, false, false);
-  } else if (d.backward) {
-    if (sv) EM_GO(true, false, false, false, false, true); else EM_GO(true, false, false, false, false, false);
-  } else if (zbv && mk) {
-    if (sv) EM_GO(false, true, true, false, false, true); else EM_GO(false, true, true, false, false, false);
+  if (d.backward) {
+    if (d.ln_y != nullptr && d.dzb != nullptr) EM_GO(true, false, true, true, true);
+    else if (d.ln_y != nullptr) EM_GO(true, false, true, true, false);
+    else EM_GO(true, false, true, false, false);
   } else if (zbv) {
-    EM_GO(false, true, false);
-  } else if (mk) {
-    if (sv) EM_GO(false, false, true, false, false, true); else EM_GO(false, false, true, false, false, false);
+    if (train) EM_GO(false, true, true); else EM_GO(false, true, false);
   } else {
-    EM_GO(false, false, false);
+    if (train) EM_GO(false, false, true); else EM_GO(false, false, false);
   }
 #undef EM_GO
   FD_CHECK_LAUNCH("fd_edge_mlp");
@@ -844,22 +707,21 @@ int EM_LAUNCH(const FdEdgeMlpDesc& d, hipStream_t st) {
 }
 
 #ifndef EM_SHAPE_W8
-extern "C" int fd_edge_mlp_pack(const float* A1, long rs1, long cs1, const float* A2, long rs2, long cs2,
-                                const float* A3, long rs3, long cs3, const float* A4, long rs4, long cs4, void* img,
-                                void* stream) {
-  FD_CHECK_ARG(A1 && A2 && A3 && A4 && img, "fd_edge_mlp_pack: null operand");
+extern "C" int fd_edge_mlp_pack(const float* W1, const float* W2, const float* Wf, long ld, void* img, void* stream) {
+  // forward image: A1 = W1[:, 0:128] [384,128], A2 = W2 [384,384], A4 = Wf [128,384], chunks in natural order
+  FD_CHECK_ARG(W1 && W2 && Wf && img, "fd_edge_mlp_pack: null operand");
   FD_CHECK_ARG(fd_aligned16(img), "fd_edge_mlp_pack: image must be 16-byte aligned");
-  EmMat m1{A1, rs1, cs1}, m2{A2, rs2, cs2}, m3{A3, rs3, cs3}, m4{A4, rs4, cs4};
-  hipLaunchKernelGGL(edge_mlp_pack16_kernel, dim3(EM_UNITS * 4 * 64 / 256), dim3(256), 0, (hipStream_t)stream, m1, m2, m3,
-                     m4, static_cast<char*>(img), 0);
+  EmMat m1{W1, ld, 1}, m2{W2, ld, 1}, m4{Wf, ld, 1};
+  hipLaunchKernelGGL(edge_mlp_pack16_kernel, dim3(EM_UNITS * 4 * 64 / 256), dim3(256), 0, (hipStream_t)stream, m1, m2, m4,
+                     static_cast<char*>(img), 0);
   FD_CHECK_LAUNCH("fd_edge_mlp_pack");
   return FD_OK;
 }
 
 extern "C" int fd_edge_mlp_pack_bwd(const float* Wf, const float* W2, const float* W1, long ld, const float* W40, void* img,
                                     void* stream) {
-  // backward image for the fused-prologue kernel: [4 units W40^T (optional, when W40 != null)] + 128 units of the transposed
-  // chain (A1 = Wf^T, A2 = W2^T, A3 = Wf[:, :128]^T, A4 = W1[:, :128]^T) with the x-consuming regions in chained k order
+  // backward image: [4 units W40^T (optional, when W40 != null)] + 120 units of the transposed chain (A1 = Wf^T [384,128],
+  // A2 = W2^T, A4 = W1[:, 0:128]^T [128,384]) with the hidden chunks in the order 1, 2, 0
   FD_CHECK_ARG(Wf && W2 && W1 && img, "fd_edge_mlp_pack_bwd: null operand");
   FD_CHECK_ARG(fd_aligned16(img), "fd_edge_mlp_pack_bwd: image must be 16-byte aligned");
   char* base = static_cast<char*>(img);
@@ -867,9 +729,8 @@ extern "C" int fd_edge_mlp_pack_bwd(const float* Wf, const float* W2, const floa
     hipLaunchKernelGGL(edge_mlp_pack_zbw_kernel, dim3(EM_ZB_UNITS * 4 * 64 / 256), dim3(256), 0, (hipStream_t)stream, W40, base);
     base += (long)EM_ZB_UNITS * EM_UNIT;
   }
-  EmMat m1{Wf, 1, ld}, m2{W2, 1, ld}, m3{Wf, 1, ld}, m4{W1, 1, ld};
-  hipLaunchKernelGGL(edge_mlp_pack16_kernel, dim3(EM_UNITS * 4 * 64 / 256), dim3(256), 0, (hipStream_t)stream, m1, m2, m3, m4, base,
-                     1);
+  EmMat m1{Wf, 1, ld}, m2{W2, 1, ld}, m4{W1, 1, ld};
+  hipLaunchKernelGGL(edge_mlp_pack16_kernel, dim3(EM_UNITS * 4 * 64 / 256), dim3(256), 0, (hipStream_t)stream, m1, m2, m4, base, 1);
   FD_CHECK_LAUNCH("fd_edge_mlp_pack_bwd");
   return FD_OK;
 }
@@ -892,20 +753,25 @@ extern "C" int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream) {
   FD_CHECK_ARG(d.dzb == nullptr || d.ln_y != nullptr, "fd_edge_mlp: dzb needs the fused LayerNorm-backward prologue (ln_y)");
   FD_CHECK_ARG(d.nres > 0 && d.rows >= 0, "fd_edge_mlp: bad extents");
   if (d.backward) {
-    FD_CHECK_ARG((d.gate1 && d.gate2) || (d.gmask1 && d.gmask2),
-                 "fd_edge_mlp(backward): the saved activations h2 (gate1) and h1 (gate2), or their packed sign masks, are required");
+    FD_CHECK_ARG(d.gmask1 && d.gmask2 && d.save1 && d.save2,
+                 "fd_edge_mlp(backward): the packed sign masks of h2 (gmask1) and h1 (gmask2) and the outputs d2 (save1) / d1 (save2) "
+                 "are required");
+    FD_CHECK_ARG(!d.mask1 && !d.mask2 && !d.zb_out, "fd_edge_mlp(backward): mask1 / mask2 / zb_out are forward outputs");
   } else {
     FD_CHECK_ARG(d.p1 && d.q1 && d.bias2 && d.pf && d.qf && d.gamma && d.beta,
                  "fd_edge_mlp(forward): p1 / q1 / bias2 / pf / qf / gamma / beta are required");
+    const int nsave = (d.save1 != nullptr) + (d.save2 != nullptr) + (d.mask1 != nullptr) + (d.mask2 != nullptr);
+    FD_CHECK_ARG(nsave == 0 || nsave == 4,
+                 "fd_edge_mlp(forward): the training outputs save1 (h1), save2 (h2 + [z | 0 | 0]), mask1, mask2 come together");
+    FD_CHECK_ARG(nsave == 4 || (!d.y && !d.mean && !d.rstd), "fd_edge_mlp(forward): y / mean / rstd are training outputs (with the saves)");
+    FD_CHECK_ARG(!d.gmask1 && !d.gmask2, "fd_edge_mlp(forward): gmask1 / gmask2 are backward inputs");
   }
-  const void* ptrs[] = {d.x, d.img, d.out, d.p1, d.q1, d.bias2, d.gate1, d.gate2, d.save1, d.save2, d.pf, d.qf,
+  const void* ptrs[] = {d.x, d.img, d.out, d.p1, d.q1, d.bias2, d.save1, d.save2, d.pf, d.qf,
                         d.gamma, d.beta, d.y, d.ln_y, d.ln_gamma, d.dy_out, d.dzb};
   for (const void* p : ptrs) FD_CHECK_ARG(fd_aligned16(p), "fd_edge_mlp: operands must be 16-byte aligned");
   if (d.rows == 0) return FD_OK;
-  FD_CHECK_ARG(d.zb_out == nullptr || (!d.backward && fd_aligned16(d.zb_out) && fd_aligned16(d.zb_bias)),
-               "fd_edge_mlp: zb_out is a forward output (16-byte aligned; the image must carry the fd_edge_mlp_pack_zb units)");
-  FD_CHECK_ARG((d.mask1 == nullptr) == (d.mask2 == nullptr) && (d.gmask1 == nullptr) == (d.gmask2 == nullptr),
-               "fd_edge_mlp: mask1 / mask2 (forward) and gmask1 / gmask2 (backward) come in pairs");
+  FD_CHECK_ARG(d.zb_out == nullptr || (fd_aligned16(d.zb_out) && fd_aligned16(d.zb_bias)),
+               "fd_edge_mlp: zb_out / zb_bias must be 16-byte aligned (the image must carry the fd_edge_mlp_pack_zb units)");
   FD_CHECK_ARG(d.shape == 0 || d.shape == 4 || d.shape == 8, "fd_edge_mlp: shape is 0 (by size), 4 or 8 (waves per block)");
   // shape by size: the one-block-per-CU shape from two of its 128-row tiles per CU up (measured fwd / fwd + saves / bwd: 16,384 rows
   // 0.088 vs 0.063 ms; 65,536 rows 0.171-0.179 / 0.216-0.240 / 0.196-0.213 vs 0.190-0.193 / 0.225-0.253 / 0.210-0.231 ms; 458,752 rows

@@ -5,6 +5,4 @@
 #define EM_SHAPE_W8
 #define EM_WAVES 8
 #define EM_UPS 4
-#define EM_RING 2
-#define EM_AHEAD 1
 #include "fd_edge_mlp.hip"

@@ -55,12 +55,12 @@ constexpr int STAGE_PIECES = TI * ROW_PIECES;  // 2832
 constexpr int ROW_F = ROW_PIECES * 4;          // 708 floats
 constexpr int GRP_F = GRP_PIECES * 4;          // 176 floats
 constexpr int STAGE_INSTR = (STAGE_PIECES + 63) / 64;   // 45 wave-wide copies per stage
-#ifdef FL_DOPIN
-#define FL_PIN() fd::sched_pin()      // (probe: the load-ahead order below kept exactly as written -- slower, more spills)
-#else
-#define FL_PIN()
+// timing-only ablations of tools/bench_ipa_flash.py --variants (WRONG RESULTS by design; they compile only in a probe build:
+// csrc/fd_probe.h)
+#if defined(FL_ABL_NODMA) || defined(FL_ABL_NOBAR) || defined(FL_ABL_NOKV) || defined(FL_ABL_KVB0) || defined(FL_ABL_NOSM) || \
+    defined(FL_ABL_NOPAIR) || defined(FL_ABL_NODZB) || defined(FL_ABL_NOPTS)
+#include "fd_probe.h"
 #endif
-// timing-only ablations of tools/bench_ipa_flash.py --variants (wrong results; no product build defines them)
 #ifdef FL_ABL_NODMA
 #define FL_DMA(src, dst)
 #else
@@ -244,9 +244,7 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
   for (int t = t0; t < t1; ++t) {
     fd::wait_vmem();
     FL_SYNC();                 // stage t of the image has landed; every wave is done with tile t - 1 (its stage, Es, Fs)
-#ifndef FL_DMA_MID
-    FL_NEXT_STAGE();
-#endif
+    FL_NEXT_STAGE();      // (behind the tile's last K request instead: measured slower, 122 against 109 us at B=30 x N=128)
     const float* __restrict__ sl = reinterpret_cast<const float*>(slab + (t & 1) * STAGE_BYTES);
     const int j0 = TI * t;
     // ---- S^T = K Q^T (two accumulator chains) and the point term
@@ -263,12 +261,6 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
           if (kk < 2) { v = ld4(kpr + 16); qb = ld4(qpr + 16); }
         }
         if (cc + KPF < C / 16) { kf[cc + KPF] = ldkv(kr + 16 * (cc + KPF)); kf[cc + KPF + 1] = ldkv(kr + 16 * (cc + KPF + 1)); }
-#ifdef FL_DMA_MID
-        // (probe: the image copy behind the tile's LAST K request instead of at the top of the tile -- measured SLOWER,
-        //  122 against 109 us at B=30 x N=128, 464 against 398 at B=8 x N=512: profiles/r04_ipa_flash_variants.log)
-        if (cc + KPF == C / 16 - 2 || (KPF >= C / 16 && cc == 0)) FL_NEXT_STAGE();
-#endif
-        FL_PIN();
         const float4 k0 = kf[cc], k1 = kf[cc + 1];
         s0 = fd::mfma_16x16x4(k0.x, Qf[cc].x, s0);
         s1 = fd::mfma_16x16x4(k1.x, Qf[cc + 1].x, s1);
@@ -278,7 +270,6 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
         s1 = fd::mfma_16x16x4(k1.z, Qf[cc + 1].z, s1);
         s0 = fd::mfma_16x16x4(k0.w, Qf[cc].w, s0);
         s1 = fd::mfma_16x16x4(k1.w, Qf[cc + 1].w, s1);
-        FL_PIN();
       }
       u = make_float4(u.x - d0, u.y - d1, u.z - d2, u.w - d0);
       qa = make_float4(gamma * (qa.x - d0), gamma * (qa.y - d1), gamma * (qa.z - d2), gamma * (qa.w - d0));
@@ -366,7 +357,6 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
 #pragma unroll
     for (int l = 0; l < 20; ++l) {
       if (l + VPF < 20) vf[l + VPF] = vload(l + VPF);
-      FL_PIN();
       const int r = l / 5, c = l % 5;
       if (c < 4) {
         O[4 * c + 0] = fd::mfma_16x16x4(vf[l].x, p[r], O[4 * c + 0]);
@@ -379,7 +369,6 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_fwd_kernel(FlashArgs a) {
         OP[2] = fd::mfma_16x16x4(vf[l].z, p[r], OP[2]);
         OP[3] = fd::mfma_16x16x4(vf[l].w, p[r], OP[3]);
       }
-      FL_PIN();
     }
     // the next key tile's first K fragments (in flight across the barrier and the o_pair phase)
     if (t + 1 < t1) {
@@ -918,7 +907,8 @@ extern "C" int fd_ipa_flash_fwd_split(const float* proj, const float* zb, const 
                "fd_ipa_flash_fwd: heads_per_block must be 0 (pick), 2, 4 or 8, got %d", heads_per_block);
   const int nti = (N + TI - 1) / TI;
   FD_CHECK_ARG(key_splits >= 1 && (key_splits == 1 || (part != nullptr && fd_aligned16(part) && A == nullptr)),
-               "fd_ipa_flash_fwd_split: key_splits > 1 needs the 16-byte aligned workspace (fd_ipa_flash_part_floats) and no A");
+               "fd_ipa_flash_fwd_split: key_splits > 1 needs a 16-byte aligned workspace `part` of key_splits * B * N * 8 * FD_IPA_FLASH_PART_LD "
+               "(= %d) floats and A == NULL", FD_IPA_FLASH_PART_LD);
   if (B == 0 || N == 0) return FD_OK;
   if (key_splits > nti) key_splits = nti;
   const long tiles = (long)B * nti;

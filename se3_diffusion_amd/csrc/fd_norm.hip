@@ -109,6 +109,107 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   }
 }
 
+// Node-level form of the backward (rows = B * N residues, C = 256 / 320): a wave takes LNB_U rows per trip with float4 accesses and
+// ALL of their loads in flight before the first reduction; at 3,840 rows every wave makes exactly one trip.  (The one-row-per-trip
+// kernel above walks its four rows as four dependent load -> reduce -> store chains: 21 us per launch in the training step,
+// 25 launches per step -- round 4's serialised profile.)  NCH = float4 chunks per lane (1: C <= 256, 2: C <= 512).
+constexpr int LNB_U = 4;
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd4_kernel(
+    const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+    const float* __restrict__ gamma, const float* __restrict__ rowscale, const float* __restrict__ mean,
+    const float* __restrict__ rstd, float* __restrict__ dx, long lddx, int dx_accum,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int C) {
+  __shared__ float red[2][4][512];
+  const int lane = fd::lane_id(), wave = fd::wave_id();
+  int col[NCH];
+  bool cok[NCH];
+  float4 gm[NCH], ag[NCH], ab[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    col[k] = 4 * (lane + 64 * k);
+    cok[k] = col[k] < C;
+    if (!cok[k]) col[k] = 0;                        // (lanes past the row read column 0 and contribute zeros)
+    gm[k] = *reinterpret_cast<const float4*>(gamma + col[k]);
+    ag[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[k] = ag[k];
+  }
+  const float invc = 1.0f / (float)C;
+  const long wslot = (long)blockIdx.x * 4 + wave, nwaves = (long)gridDim.x * 4;
+  for (long base = wslot * LNB_U; base < rows; base += nwaves * LNB_U) {
+    float4 xv[LNB_U][NCH], dv[LNB_U][NCH], old[LNB_U][NCH];
+    float m[LNB_U], rr[LNB_U], rs[LNB_U];
+#pragma unroll
+    for (int u = 0; u < LNB_U; ++u) {
+      const long r = base + u < rows ? base + u : rows - 1;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        xv[u][k] = *reinterpret_cast<const float4*>(x + r * ldx + col[k]);
+        dv[u][k] = *reinterpret_cast<const float4*>(dy + r * lddy + col[k]);
+        if (dx_accum) old[u][k] = *reinterpret_cast<const float4*>(dx + r * lddx + col[k]);
+      }
+      m[u] = mean[r];
+      rr[u] = rstd[r];
+      rs[u] = rowscale ? rowscale[r] : 1.f;
+    }
+    float4 xh[LNB_U][NCH], g[LNB_U][NCH];
+    float s1[LNB_U], s2[LNB_U];
+#pragma unroll
+    for (int u = 0; u < LNB_U; ++u) {
+      const bool ok = base + u < rows;
+      s1[u] = 0.f;
+      s2[u] = 0.f;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const float sc = (ok && cok[k]) ? rs[u] : 0.f;   // rows / columns past the end contribute nothing
+        const float4 d = make_float4(dv[u][k].x * sc, dv[u][k].y * sc, dv[u][k].z * sc, dv[u][k].w * sc);
+        xh[u][k] = make_float4((xv[u][k].x - m[u]) * rr[u], (xv[u][k].y - m[u]) * rr[u], (xv[u][k].z - m[u]) * rr[u],
+                               (xv[u][k].w - m[u]) * rr[u]);
+        g[u][k] = make_float4(d.x * gm[k].x, d.y * gm[k].y, d.z * gm[k].z, d.w * gm[k].w);
+        ag[k].x += d.x * xh[u][k].x; ag[k].y += d.y * xh[u][k].y; ag[k].z += d.z * xh[u][k].z; ag[k].w += d.w * xh[u][k].w;
+        ab[k].x += d.x; ab[k].y += d.y; ab[k].z += d.z; ab[k].w += d.w;
+        s1[u] += (g[u][k].x + g[u][k].y) + (g[u][k].z + g[u][k].w);
+        s2[u] += (g[u][k].x * xh[u][k].x + g[u][k].y * xh[u][k].y) + (g[u][k].z * xh[u][k].z + g[u][k].w * xh[u][k].w);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LNB_U; ++u) {
+      s1[u] = fd::wave_sum(s1[u]) * invc;
+      s2[u] = fd::wave_sum(s2[u]) * invc;
+    }
+#pragma unroll
+    for (int u = 0; u < LNB_U; ++u) {
+      if (base + u >= rows) continue;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        if (!cok[k]) continue;
+        float4 o;
+        o.x = rr[u] * (g[u][k].x - s1[u] - xh[u][k].x * s2[u]);
+        o.y = rr[u] * (g[u][k].y - s1[u] - xh[u][k].y * s2[u]);
+        o.z = rr[u] * (g[u][k].z - s1[u] - xh[u][k].z * s2[u]);
+        o.w = rr[u] * (g[u][k].w - s1[u] - xh[u][k].w * s2[u]);
+        if (dx_accum) { o.x += old[u][k].x; o.y += old[u][k].y; o.z += old[u][k].z; o.w += old[u][k].w; }
+        *reinterpret_cast<float4*>(dx + (base + u) * lddx + col[k]) = o;
+      }
+    }
+  }
+  if (dgamma) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+      if (cok[k]) {
+        *reinterpret_cast<float4*>(&red[0][wave][col[k]]) = ag[k];
+        *reinterpret_cast<float4*>(&red[1][wave][col[k]]) = ab[k];
+      }
+    __syncthreads();
+    for (int c = (int)threadIdx.x; c < C; c += 256) {
+      float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+      float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+      atomicAdd(&dgamma[c], a);
+      atomicAdd(&dbeta[c], b);
+    }
+  }
+}
+
 // ---- C == 128 fast path (the pair tensor z: every edge-transition / edge-embedder LayerNorm) --------------------
 // A row is 512 B = 32 lanes x float4, so a wave holds two rows side by side and each half-wave walks LN_U rows per
 // iteration with all of their loads issued before the first reduction (the generic one-row-per-wave kernels keep
@@ -475,6 +576,17 @@ extern "C" int fd_layernorm_bwd(const float* dy, long lddy, const float* x, long
   // for the node-level calls (rows = B*N), more only when there is real streaming work
   long g = (rows + 15) / 16;
   int grid = (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
+  if (ln128_ok(x, ldx) && ln128_ok(dy, lddy) && ln128_ok(dx, lddx) && fd_aligned16(gamma)) {
+    // (16-byte addressable rows: LNB_U rows per wave and trip, every load in flight before the first reduction)
+    if (C <= 256)
+      hipLaunchKernelGGL(layernorm_bwd4_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, gamma,
+                         rowscale, mean, rstd, dx, lddx, dx_accum, dgamma, dbeta, rows, C);
+    else
+      hipLaunchKernelGGL(layernorm_bwd4_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, gamma,
+                         rowscale, mean, rstd, dx, lddx, dx_accum, dgamma, dbeta, rows, C);
+    FD_CHECK_LAUNCH("fd_layernorm_bwd(x4)");
+    return FD_OK;
+  }
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, gamma,
                      rowscale, mean, rstd, dx, lddx, dx_accum, dgamma, dbeta, rows, C);
   FD_CHECK_LAUNCH("fd_layernorm_bwd");

@@ -81,7 +81,7 @@ class FdLossDesc(Structure):
 class FdEdgeMlpDesc(Structure):
     _fields_ = [
         ("x", c_void_p), ("img", c_void_p), ("p1", c_void_p), ("q1", c_void_p), ("bias2", c_void_p),
-        ("gate1", c_void_p), ("gate2", c_void_p), ("save1", c_void_p), ("save2", c_void_p),
+        ("save1", c_void_p), ("save2", c_void_p),
         ("pf", c_void_p), ("qf", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("rowscale", c_void_p),
         ("y", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("out", c_void_p),
         ("rows", c_long), ("nres", c_int), ("backward", c_int), ("eps", c_float), ("blocks", c_int),
@@ -94,7 +94,7 @@ class FdEdgeMlpDesc(Structure):
 
 
 EDGE_MLP_W8_MIN_ROWS = 65536
-EDGE_MLP_IMAGE_BYTES = 132 * 12288
+EDGE_MLP_IMAGE_BYTES = 124 * 12288
 
 
 class FdEdgeEmbedDesc(Structure):
@@ -173,7 +173,7 @@ _SIGS = {
     "fd_gemm_plan": "S",
     "fd_gemm_set_exact_f32": "i",
     "fd_gemm_set_persistent_blocks": "i",
-    "fd_edge_mlp_pack": "pllpllpllpllps",
+    "fd_edge_mlp_pack": "ppplps",
     "fd_edge_mlp": "Ss",
     "fd_edge_mlp_pack_zb": "pps",
     "fd_edge_mlp_pack_bwd": "ppplpps",
@@ -226,6 +226,7 @@ _SIGS = {
     "fd_forward_marginal_batch": "ppppppippdipppp" + "iis",
     "fd_se3_reverse_step": "ppppppiiddpdddiiips",
     "fd_se3_reverse_step_f32": "ppppppiiddpdddiiips",
+    "fd_sample_advance": "ppppilpipps",
     "fd_dsm_loss": "Ss",
     "fd_adam_step": "pppplffffffs",
 }
@@ -244,7 +245,7 @@ class FdLib:
         self.path = path
         self.cdll = ctypes.CDLL(path)
         for name, (res, args) in {"fd_last_error": (c_char_p, []), "fd_abi_version": (c_int, []),
-                                  "fd_backend": (c_char_p, [])}.items():
+                                  "fd_backend": (c_char_p, []), "fd_build_flags": (c_char_p, [])}.items():
             fn = getattr(self.cdll, name)
             fn.restype, fn.argtypes = res, args
         for name, sig in _SIGS.items():
@@ -373,4 +374,4 @@ def get_lib() -> FdLib:
 
 
 def exported_symbols():
-    return sorted(list(_SIGS) + ["fd_last_error", "fd_abi_version", "fd_backend"])
+    return sorted(list(_SIGS) + ["fd_last_error", "fd_abi_version", "fd_backend", "fd_build_flags"])

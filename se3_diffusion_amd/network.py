@@ -305,8 +305,12 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None, out_view
     split = 4 if (opts.flash_ipa and not flash and not train and opts.flash_ipa_split_min_n <= N <= 1024
                   and (lib().is_device or opts.flash_ipa_split_min_n <= 16)) else 1      # (<= 16: the interpreter tests)
     flash = flash or split > 1
-    # (the copy serves fd_ipa_attn_fwd/bwd only: the unfused softmax kernels, the fused pair pass and the flash kernel read kp)
-    kpT = empty((B, H, PQ * 3, N), dev) if opts.fused_ipa_attn and (train or not flash) else None
+    # which backward will run is decided HERE, with the forward's options and tile count, and recorded for ipa_bwd: the saved
+    # tensors (the key-point copy below) are the ones that path reads, whatever the options say by then
+    flash_bwd = bool(train and opts.flash_ipa_bwd and B * ((N + 15) // 16) >= opts.flash_ipa_bwd_min_tiles and N <= 1024
+                     and (lib().is_device or opts.flash_ipa_bwd_min_tiles <= 0))
+    # (the copy serves fd_ipa_attn_fwd/bwd only: the unfused softmax kernels and both flash kernels read kp)
+    kpT = empty((B, H, PQ * 3, N), dev) if opts.fused_ipa_attn and ((not flash) or (train and not flash_bwd)) else None
     par = (not train) and not flash            # sampling, launch sequence: independent launches on a second graph branch
     ops.fork(lambda: lib().call("fd_ipa_points_fwd", proj, quat, trans, qp, kp, vp, kpT, N, R, H, C, PQ, PV), proj, par)
     W40, b40 = ipa_w40(P, pre, cache)
@@ -356,8 +360,9 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None, out_view
     x1 = empty((R, CS), dev) if out_view is None else out_view[0]
     ops.linear(mv(feats), mv(P[f"{pre}.linear_out.weight"]), P[f"{pre}.linear_out.bias"], mv(x1) if out_view is None else out_view,
                R, CS, LDF, rowscale=mask, resid=s)
+    ops.STATS["ipa_flash_fwd" if flash else "ipa_sequence_fwd"] += 1
     sv = dict(s=s, z=z, quat=quat, trans=trans, mask=mask, proj=proj, qp=qp, kp=kp, kpT=kpT, vp=vp, W40=W40, b40=b40, zb=zb, A=A,
-              feats=feats, B=B, N=N, fused_attn=fused_attn)
+              feats=feats, B=B, N=N, fused_attn=fused_attn, flash_bwd=flash_bwd)
     return x1, sv
 
 
@@ -385,8 +390,8 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True, defer_dz=Fal
     hw_part = empty((R, H), dev)
     dzb = empty((Pn, ZB), dev)
     doptg = empty((R, H, PV * 3), dev)
-    flash = (opts.flash_ipa_bwd and B * ((N + 15) // 16) >= opts.flash_ipa_bwd_min_tiles and N <= 1024
-             and (L.is_device or opts.flash_ipa_bwd_min_tiles <= 0))
+    flash = sv["flash_bwd"]          # (decided by ipa_fwd)
+    ops.STATS["ipa_flash_bwd" if flash else "ipa_sequence_bwd"] += 1
     if flash:
         # query side in one launch: dL = A (dP - D) with dP = dO V^T + dOpt vpts^T + dout . zd formed tile by tile on the MFMA
         # (no dA in HBM), dzb, dqp, head-weight gradient; dkp from dL as before
@@ -498,7 +503,7 @@ def tfmr_layer_fwd(P, pre, x, key_add, B, N, save=True, out_rowscale=None, x_ln=
         # in_proj on LayerNorm(t) of the layer in front; the normalised rows are written out too (this layer's residual)
         t_in, g_in, b_in, rs_in, lnc, x = x_ln + (0, None)[len(x_ln) - 4:]
         x = empty((R, TD), dev) if x is None else x
-        ops.ln_linear(mv(t_in), g_in, b_in, mv(P[f"{pre}.self_attn.in_proj_weight"]), P[f"{pre}.self_attn.in_proj_bias"], mv(qkv),
+        ops.ln_linear(t_in if isinstance(t_in, tuple) else mv(t_in), g_in, b_in, mv(P[f"{pre}.self_attn.in_proj_weight"]), P[f"{pre}.self_attn.in_proj_bias"], mv(qkv),
                       R, 3 * TD, TD, ln_rowscale=rs_in, ln_out=mv(x), ln_cols=lnc)
     else:
         ops.linear(mv(x), mv(P[f"{pre}.self_attn.in_proj_weight"]), P[f"{pre}.self_attn.in_proj_bias"], mv(qkv), R, 3 * TD, TD)

@@ -180,8 +180,10 @@ def join_grad_stream():
 # do not depend on their neighbours (skip_embed of a block, the IPA point rotation beside q k^T, a v_pts + o_pt beside a v,
 # the backbone update beside the edge transition).  fork(fn, like) runs fn() on a second stream that first waits for the
 # current one; join(like) makes the current stream wait for it.  Under hipGraph capture (sampler.sample, use_graph) the
-# pair becomes two edges of the graph and the branch runs beside the main chain.  fn (and with it every tensor its
-# closure holds) stays referenced until the join.  Same single-caller contract as side().
+# pair becomes two edges of the graph and the branch runs beside the main chain.  A Python closure keeps variable CELLS, not
+# values: a caller that rebinds a name the branch reads (trunk.forward: node, quat, trans = n3, q2, t2) would let the old tensor
+# go back to the allocator while the side stream may still be reading it -- so callers bind what the branch reads as default
+# arguments of fn and/or pass it as keep=(...); both stay referenced until the join.  Same single-caller contract as side().
 # ---------------------------------------------------------------------------
 _FORK = {"streams": {}, "pending": []}
 
@@ -190,7 +192,7 @@ def fork_ok(like):
     return bool(opts.graph_fork and like.is_cuda and lib().is_device)
 
 
-def fork(fn, like, enable=True):
+def fork(fn, like, enable=True, keep=()):
     if not (enable and fork_ok(like)):
         fn()
         return
@@ -201,7 +203,7 @@ def fork(fn, like, enable=True):
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
         fn()
-    _FORK["pending"].append((key, fn))
+    _FORK["pending"].append((key, (fn, tuple(keep))))
 
 
 def join(like=None):
@@ -360,7 +362,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, rows, C, *, rowscale=None, dgamm
 def ln_linear_ok(x, W, M, N, K):
     """Can ln_linear fold this LayerNorm into its Linear?  (the latency regime of sampling, M = B*N <= 1024 rows -- where fd_gemm
     picks its 32 x 32 latency kernel for the node-level layers --, K <= 320, contiguous 16-byte aligned operands)"""
-    return bool(opts.ln_fold and M <= 1024 and K % 8 == 0 and K <= 320 and x[1] == 0 and W[1] == 0 and x[2] % 4 == 0
+    return bool(opts.ln_fold and M <= 1024 and K % 8 == 0 and K <= 320 and x[1] % 4 == 0 and W[1] == 0 and x[2] % 4 == 0
                 and W[2] % 4 == 0)
 
 
@@ -415,60 +417,78 @@ def feature_tables(device, index_embed_size=32, num_bins=22, min_bin=1e-5, max_b
 # ---------------------------------------------------------------------------
 def edge_mlp_pack(W1, W2, Wf, backward=False, out=None, W40=None):
     """Pack the edge-transition weights (trunk.0 [384,384], trunk.2 [384,384], final_layer [128,384]) into the bf16-plane
-    image fd_edge_mlp streams.  backward=True packs the transposes (dX chain).  W40 [40,128] (forward only): the next IPA
-    block's [linear_b ; down_z] as a fourth layer (edge_mlp(..., zb_out=, zb_bias=))."""
+    image fd_edge_mlp streams.  backward=True packs the transposed chain (dX kernel).  W40 [40,128]: forward -- the next IPA
+    block's [linear_b ; down_z] as a fourth layer (edge_mlp(..., zb_out=, zb_bias=)); backward -- the IPA block BEHIND the
+    transition, for the dzb term of the fused prologue (edge_mlp(..., ln_y=, dzb=))."""
     img = out if out is not None else torch.empty(hip.EDGE_MLP_IMAGE_BYTES, dtype=torch.uint8, device=W1.device)
-    ld = 384
+    assert W40 is None or (W40.is_contiguous() and tuple(W40.shape) == (40, 128))
+    assert W1.stride(-1) == 1 and W2.stride(-1) == 1 and Wf.stride(-1) == 1 and W1.stride(0) == W2.stride(0) == Wf.stride(0)
+    ld = W1.stride(0)
     if not backward:
-        # A1 = W1[:, :128], A2 = W2, A3 = Wf[:, :128], A4 = Wf
-        lib().call("fd_edge_mlp_pack", W1, ld, 1, W2, ld, 1, Wf, ld, 1, Wf, ld, 1, img)
+        lib().call("fd_edge_mlp_pack", W1, W2, Wf, ld, img)
         if W40 is not None:
-            assert W40.is_contiguous() and tuple(W40.shape) == (40, 128)
             lib().call("fd_edge_mlp_pack_zb", W40, img)
     else:
-        # A1 = Wf^T [384,128], A2 = W2^T, A3 = Wf[:, :128]^T, A4 = W1[:, :128]^T [128,384]
-        lib().call("fd_edge_mlp_pack", Wf, 1, ld, W2, 1, ld, Wf, 1, ld, W1, 1, ld, img)
+        lib().call("fd_edge_mlp_pack_bwd", Wf, W2, W1, ld, W40, img)
     return img
 
 
 def edge_mlp_pack_bwd(Wf, W2, W1, W40=None, out=None):
-    """Backward image for edge_mlp(..., backward=True, ln_y=...): the transposed chain with its input-consuming regions in
-    chained k order, preceded by W40^T [128 <- 40] (the IPA block behind the transition) when the dzb term is fused."""
-    img = out if out is not None else torch.empty(hip.EDGE_MLP_IMAGE_BYTES, dtype=torch.uint8, device=W1.device)
-    assert W40 is None or (W40.is_contiguous() and tuple(W40.shape) == (40, 128))
-    lib().call("fd_edge_mlp_pack_bwd", Wf, W2, W1, 384, W40, img)
-    return img
+    """Backward image (edge_mlp(..., backward=True)), preceded by W40^T [128 <- 40] (the IPA block behind the transition) when
+    the dzb term of the fused prologue is used."""
+    return edge_mlp_pack(W1, W2, Wf, backward=True, out=out, W40=W40)
 
 
 _SCHED = {}
 _SCHED_LOCK = threading.Lock()
 # launches that took the dynamic tile hand-out since the process started (tests assert that the benchmarked step uses it)
-STATS = {"edge_dynamic_launches": 0}
+STATS = {"edge_dynamic_launches": 0, "ipa_flash_fwd": 0, "ipa_sequence_fwd": 0, "ipa_flash_bwd": 0, "ipa_sequence_bwd": 0}
+
+
+_SCHED_WORDS = 256           # counter words per device: one per (stream, launch site) that ever used the dynamic hand-out
+
+
+def edge_sched_init(device):
+    """Allocate the device's pool of tile-counter words.  Called outside any hipGraph capture (ScoreNetwork.forward's first
+    call on a device, sampler.sample before it captures): a first dynamic-tile launch ON a capture stream (sampling at N=512)
+    must not allocate inside the capture -- the buffer would live in the graph's private pool while this module keeps it."""
+    with _SCHED_LOCK:
+        pool = _SCHED.get(("pool", device))
+        if pool is None:
+            if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("ops.edge_sched_init must run before hipGraph capture starts (sampler.sample calls it)")
+            pool = _SCHED[("pool", device)] = (torch.zeros(_SCHED_WORDS, dtype=torch.int32, device=device), {})
+    return pool
 
 
 def _edge_sched(like, stream):
     """One word of device scratch for a launch's dynamic tile hand-out (FdEdgeMlpDesc.sched; the entry point zeroes it on the
-    launch's stream).  One word per (device, stream): two launches on one stream are ordered, so the second launch's zeroing
-    memset runs after the first has ended; launches on different streams (two models, a replayed graph beside eager work)
-    never share a word.  Captured graphs keep the word of their capture stream (replays of ONE graph are ordered by the
-    stream they are replayed on; replaying two graphs captured on the same stream concurrently is not supported)."""
-    key = (like.device, int(stream or 0))
+    launch's stream).  One word per (device, stream), taken from a per-device pool that exists before any capture: two launches
+    on one stream are ordered, so the second launch's zeroing memset runs after the first has ended; launches on different
+    streams (two models, a replayed graph beside eager work) never share a word.  Captured graphs keep the word of their
+    capture stream (replays of ONE graph are ordered by the stream they are replayed on; replaying two graphs captured on the
+    same stream concurrently is not supported)."""
+    buf, slots = edge_sched_init(like.device)
     with _SCHED_LOCK:
-        buf = _SCHED.get(key)
-        if buf is None:
-            buf = _SCHED[key] = torch.zeros(4, dtype=torch.int32, device=like.device)
+        key = int(stream or 0)
+        slot = slots.get(key)
+        if slot is None:
+            slot = slots[key] = len(slots) % (_SCHED_WORDS // 4)     # (4-word stride: 16-byte aligned words)
         STATS["edge_dynamic_launches"] += 1
-    return buf.data_ptr()
+    return buf.data_ptr() + 16 * slot
+
+
+EDGE_MLP_MACS_PER_ROW = 128 * 384 + 384 * 384 + 384 * 128      # 245,760 (rounds 2-4 also ran Wf[:, :128] z: 262,144)
 
 
 def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, qf=None, gamma=None, beta=None,
-             rowscale=None, gate1=None, gate2=None, save1=None, save2=None, y=None, mean=None, rstd=None,
+             rowscale=None, save1=None, save2=None, y=None, mean=None, rstd=None,
              backward=False, blocks=0, ld_pq=0, ld_pqf=0, zb_out=None, zb_bias=None, mask1=None, mask2=None, gmask1=None,
              gmask2=None, ln_y=None, ln_mean=None, ln_rstd=None, ln_gamma=None, ln_rowscale=None, dy_out=None, ln_dgamma=None,
              ln_dbeta=None, dzb=None):
     d = hip.FdEdgeMlpDesc()
     tens = []
-    for name, t in (("x", x), ("img", img), ("p1", p1), ("q1", q1), ("bias2", bias2), ("gate1", gate1), ("gate2", gate2),
+    for name, t in (("x", x), ("img", img), ("p1", p1), ("q1", q1), ("bias2", bias2),
                     ("save1", save1), ("save2", save2), ("pf", pf), ("qf", qf), ("gamma", gamma), ("beta", beta),
                     ("rowscale", rowscale), ("y", y), ("mean", mean), ("rstd", rstd), ("out", out), ("zb_out", zb_out),
                     ("zb_bias", zb_bias), ("mask1", mask1), ("mask2", mask2), ("gmask1", gmask1), ("gmask2", gmask2),
@@ -489,13 +509,13 @@ def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, 
     prof = L.gemm_profile
     if prof is not None and L.is_device:
         # same record layout as FdLib.gemm (tile code 7 = the fused edge-transition kernel); algorithmic flops of the
-        # chain: 2 * rows * (128*384 + 384*384 + 384*128 + 128*128)
+        # chain: 2 * rows * (128*384 + 384*384 + 384*128) -- the residual through the final layer is an add, not a product
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         L._check(L.cdll.fd_edge_mlp(hip.ctypes.byref(d), stream), "fd_edge_mlp")
         e1.record()
-        prof.append((7, True, True, 2.0 * int(rows) * (262144 + (5120 if zb_out is not None else 0)), e0, e1,
+        prof.append((7, True, True, 2.0 * int(rows) * (EDGE_MLP_MACS_PER_ROW + (5120 if zb_out is not None else 0)), e0, e1,
                      (int(rows), 128, 384, 1, int(bool(backward)), 0, 0, 1)))
         return
     L._check(L.cdll.fd_edge_mlp(hip.ctypes.byref(d), stream), "fd_edge_mlp")

@@ -43,7 +43,8 @@ class Options:
     edge_blocks: int = 0              # FD_EDGE_BLOCKS: persistent blocks of the fused edge kernels (0 = fill the CUs: 512 / 256)
     edge_shape: int = 0               # FD_EDGE_SHAPE: 0 = by size, 4 = 4-wave blocks (two per CU), 8 = 8-wave blocks (one per CU)
     edge_dynamic_tiles: bool = True   # FD_EDGE_DYN_TILES: a fused edge launch with more tiles than blocks hands them out dynamically
-    packed_gates: bool = True         # FD_PACKED_GATES: the fused edge backward gates on packed sign bits instead of reading h1 / h2
+    packed_gates: bool = True         # FD_PACKED_GATES: the fused edge EMBEDDER's backward gates on packed sign bits instead of reading h1 / h2
+                                      # (the edge transition's always does: its h2 save carries the residual z)
     fused_ln_bwd: bool = True         # FD_EDGE_LN_BWD: the edge transition's LayerNorm backward (and the IPA term dz += dzb W40 of
                                       # the block behind it) as the prologue of its fused backward kernel
     zb_from_edge: bool = True         # FD_ZB_FUSED: the next IPA block's pair projection zb as a 4th layer of fd_edge_mlp
@@ -74,6 +75,9 @@ class Options:
     node_dw_blocks: int = 0           # FD_NODE_DW_BLOCKS: its persistent blocks (0 = 512: two per CU)
     ln_fold: bool = True              # FD_LN_FOLD: sampling -- the sequence transformer's LayerNorms inside the GEMM launches that
                                       # consume them (fd_ln_gemm) instead of launches of their own
+    sampler_device_steps: bool = True # FD_SAMPLER_DEVICE_STEPS: sampling -- the captured step takes t, the step's scalars and its normal draws
+                                      # from device arrays indexed by a device counter (fd_sample_advance) instead of three launches per step
+    merge_skip_embed: bool = True     # FD_MERGE_SKIP: sampling -- the skip_embed products of all trunk blocks as ONE GEMM per forward
     graph_fork: bool = False          # FD_GRAPH_FORK (measured, OFF: 1.33-1.40 against 1.61 backbones/s at N=128, 1.06-1.09 against 1.23 at
                                       # N=256 -- a cross-queue edge of the hipGraph costs ~20 us, more than the 5-12 us launch it hides): sampling -- launches that do not depend on each other (skip_embed, the IPA point
                                       # rotation beside q k^T, a v_pts + o_pt beside a v, the backbone update beside the edge transition) go to a
@@ -103,7 +107,7 @@ class Options:
             fused_seq_attn_bwd=_flag("FD_SEQ_ATTN_BWD_FUSED", False),
             grouped_node_dw=_flag("FD_NODE_DW", True), node_dw_blocks=_int("FD_NODE_DW_BLOCKS", 0),
             ln_fold=_flag("FD_LN_FOLD", True),
-            graph_fork=_flag("FD_GRAPH_FORK", False),
+            sampler_device_steps=_flag("FD_SAMPLER_DEVICE_STEPS", True), merge_skip_embed=_flag("FD_MERGE_SKIP", True), graph_fork=_flag("FD_GRAPH_FORK", False),
             zero_arena=_flag("FD_ZERO_ARENA", True), dx_splitk=_flag("FD_DX_SPLITK", True))
 
 

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import hip
+from .options import opts
 
 
 def init_feats(diffuser, B, N, device, generator=None, noise=None):
@@ -50,6 +51,8 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
     # packed linear_b / down_z weights) are built by the first forward and reused by the other 500 (trunk._cached)
     model._fd_static = {}
     lib = hip.get_lib()
+    from . import ops as _ops0
+    _ops0.edge_sched_init(dev)       # (the tile-counter pool of the fused edge kernels exists before anything is captured)
     saved_prof, lib.gemm_profile = lib.gemm_profile, (None if use_graph else lib.gemm_profile)
     # static state (updated in place so a captured graph sees it)
     st = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in feats.items()}
@@ -83,7 +86,16 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
     # forward; the per-step sc_ca_t update depends on the MODEL's embed_self_conditioning flag alone
     embed_sc = bool(getattr(getattr(getattr(model, "_model_conf", None), "embed", None), "embed_self_conditioning", True))
 
+    # Device-side step bookkeeping (graph replays with device-drawn noise): the captured step starts with fd_sample_advance,
+    # which takes t, {g_rot(t), b(t)} and the step's draws from device arrays indexed by a device counter -- no fill_ / copy_ /
+    # normal_ launch between replays; the generator fills NOISE_STEPS steps' worth of draws in one launch.
+    NOISE_STEPS = 50
+    adv = None
+
     def step_body():
+        if adv is not None:
+            lib.call("fd_sample_advance", adv["counter"], adv["all_t"], all_tp, adv["z_all"], NOISE_STEPS, z_both.numel(),
+                     st["t"], B, tparams, z_both)
         out = model(st)
         if embed_sc:
             st["sc_ca_t"].copy_(out["rigids"][..., 4:])
@@ -110,19 +122,36 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
                 for _ in range(2):
                     step_body()
             torch.cuda.current_stream().wait_stream(side)
+            if opts.sampler_device_steps:
+                adv = dict(counter=torch.zeros(1, dtype=torch.int32, device=dev),
+                           all_t=torch.tensor(np.ascontiguousarray(steps), dtype=torch.float32).to(dev),
+                           z_all=torch.zeros((NOISE_STEPS,) + tuple(z_both.shape), dtype=torch.float64, device=dev))
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 cap_out = step_body()          # (static buffers: every replay rewrites them)
             for k, v in saved.items():
                 st[k].copy_(v)
+            # (capture records the launches without running them: the counter is still 0 = the index of the first step)
         out = None
         if stats is not None and lib.is_device:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         for i, t in enumerate(steps):
             if t > min_t:
-                set_t(t)
-                draw(i)
+                if graph is not None and adv is not None:
+                    if i % NOISE_STEPS == 0:
+                        if noise_fn is None:
+                            adv["z_all"].normal_(generator=generator)     # the draws of the next NOISE_STEPS steps, one launch
+                        else:
+                            # injected draws (trajectory parity tests): the same buffer, filled in step order
+                            for k in range(min(NOISE_STEPS, len(steps) - i)):
+                                if steps[i + k] > min_t:
+                                    zr, zt = noise_fn(i + k, (B, N, 3))
+                                    adv["z_all"][k, 0].copy_(_f64(zr, dev))
+                                    adv["z_all"][k, 1].copy_(_f64(zt, dev))
+                else:
+                    set_t(t)
+                    draw(i)
                 if graph is not None:
                     graph.replay()
                     out = cap_out

@@ -126,13 +126,12 @@ def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None, zb_next
     img = _edge_mlp_image(P, pre, cache, W40=zb_next[0] if use_zb else None)
     z2 = empty((Pn, CZ), dev)
     if save:
+        # h2z = h2 + [z | 0 | 0]: the input of the final layer (ipa_pytorch.py:231), i.e. the operand of its weight gradient;
+        # mh1 / mh2: sign bits of h1 / h2 (48 B per row each) -- the ReLU gates of the backward's dX kernel, which reads no h1 / h2
         h1 = empty((Pn, EH), dev); h2 = empty((Pn, EH), dev); y = empty((Pn, CZ), dev)
         mean = empty((Pn,), dev); rstd = empty((Pn,), dev)
-        kw = dict(save1=h1, save2=h2, y=y, mean=mean, rstd=rstd)
-        if opts.packed_gates:
-            # sign bits of h1 / h2 (48 B per row each) for the backward's ReLU gates: its dX kernel then reads no h1 / h2
-            mh1 = empty((Pn, 12), dev, torch.int32); mh2 = empty((Pn, 12), dev, torch.int32)
-            kw.update(mask1=mh1, mask2=mh2)
+        mh1 = empty((Pn, 12), dev, torch.int32); mh2 = empty((Pn, 12), dev, torch.int32)
+        kw = dict(save1=h1, save2=h2, y=y, mean=mean, rstd=rstd, mask1=mh1, mask2=mh2)
     if use_zb:
         zb = empty((Pn, nw.ZB), dev)
         kw.update(zb_out=zb, zb_bias=zb_next[1])
@@ -141,7 +140,7 @@ def edge_transition_fwd(P, b, n3, z, emask, B, N, save=True, cache=None, zb_next
     if not save:
         return z2, None, zb
     return z2, dict(n3=n3, z=z, e=e, h1=h1, h2=h2, y=y, mean=mean, rstd=rstd, emask=emask, B=B, N=N,
-                    mh1=kw.get("mask1"), mh2=kw.get("mask2")), zb
+                    mh1=mh1, mh2=mh2, h2_has_z=True), zb
 
 
 def edge_transition_fwd_unfused(P, b, n3, z, emask, B, N):
@@ -183,7 +182,11 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3, dzb_next=None):
     L = lib()
     W1, W2, Wf = P[f"{pre}.trunk.0.weight"], P[f"{pre}.trunk.2.weight"], P[f"{pre}.final_layer.weight"]
     z, e, h1, h2 = sv["z"], sv["e"], sv["h1"], sv["h2"]
-    fused = fused_edge()
+    # the fused dX kernel gates on the packed masks the FUSED forward wrote; a forward that ran unfused (exact-fp32 mode switched
+    # on in between) is followed by the unfused backward
+    fused = fused_edge() and sv.get("mh1") is not None
+    h2_has_z = bool(sv.get("h2_has_z"))      # the fused forward saved h2 + [z | 0 | 0] (the operand of dWf), not h2
+    assert fused or not h2_has_z, "a fused edge-transition forward needs the fused backward (its h2 save carries z)"
     fused_ln = fused and opts.fused_ln_bwd and (dzb_next is None or dzb_next[1].is_contiguous())
     if dzb_next is not None and not fused_ln:
         # materialise the IPA term first (streaming kernel, W40 resident in registers)
@@ -203,7 +206,7 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3, dzb_next=None):
         # dz = dy Wf_z + d1 W1_z; dy, d2, d1 are written once for the weight gradients and the pair reductions
         dh2 = empty((Pn, EH), dev); dh1 = empty((Pn, EH), dev)
         img = ops.edge_mlp_pack_bwd(Wf, W2, W1, W40=dzb_next[1] if dzb_next is not None else None)
-        gk = dict(gmask1=sv["mh2"], gmask2=sv["mh1"]) if sv.get("mh1") is not None else dict(gate1=h2, gate2=h1)
+        gk = dict(gmask1=sv["mh2"], gmask2=sv["mh1"])
         ops.edge_mlp(dz2, img, dz, Pn, N, save1=dh2, save2=dh1, backward=True, ln_y=sv["y"], ln_mean=sv["mean"],
                      ln_rstd=sv["rstd"], ln_gamma=P[f"{pre}.layer_norm.weight"], ln_rowscale=sv["emask"], dy_out=dy,
                      ln_dgamma=G[f"{pre}.layer_norm.weight"], ln_dbeta=G[f"{pre}.layer_norm.bias"],
@@ -215,7 +218,8 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3, dzb_next=None):
     if not grouped_dw:
         def _grads_y():
             ops.linear_dw(mv(dy), mv(h2), mv(gWf), Pn, CZ, EH)
-            ops.linear_dw(mv(dy), mv(z), (gWf, 0, EH), Pn, CZ, CZ)
+            if not h2_has_z:
+                ops.linear_dw(mv(dy), mv(z), (gWf, 0, EH), Pn, CZ, CZ)
         ops.side(_grads_y, (dy, h2, z), Pn)
     dPf = zeros((R, CZ), dev); dQf = zeros((R, CZ), dev)
     L.call("fd_pair_reduce_acc", dy, B, N, CZ, dPf, dQf, CZ)
@@ -238,16 +242,20 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3, dzb_next=None):
             # the dX chain in one launch: d2 = [h2 > 0] dy Wf, d1 = [h1 > 0] d2 W2, dz = dy Wf_z + d1 W1_z (fd_edge_mlp with
             # the transposed weight image); d2 / d1 are written once, for the weight-gradient GEMMs and the pair reductions
             dh2 = empty((Pn, EH), dev); dh1 = empty((Pn, EH), dev)
-            gk = dict(gmask1=sv["mh2"], gmask2=sv["mh1"]) if sv.get("mh1") is not None else dict(gate1=h2, gate2=h1)
+            gk = dict(gmask1=sv["mh2"], gmask2=sv["mh1"])
             ops.edge_mlp(dy, _edge_mlp_image(P, pre, None, backward=True), dz, Pn, N, save1=dh2, save2=dh1, backward=True, **gk)
         if grouped_dw:
             # every pair-row weight gradient of the transition in ONE grouped launch (fd_pair_dw): dW2 = d2^T h1 as three
-            # 384 x 128 tiles (+ its bias gradient), dW1[:, z part] = d1^T z, dWf = dy^T (h2 + [z | 0]) stored transposed
+            # 384 x 128 tiles (+ its bias gradient), dW1[:, z part] = d1^T z, dWf = dy^T (h2 + [z | 0]) stored transposed (the
+            # fused forward saved that sum: no A_add)
             gW2, gb2 = G[f"{pre}.trunk.2.weight"], G[f"{pre}.trunk.2.bias"]
             items = [dict(A=(dh2, 0, EH), B=(h1, CZ * j, EH), C=(gW2, CZ * j, EH), colsum=gb2 if j == 0 else None)
                      for j in range(3)]
             items.append(dict(A=(dh1, 0, EH), B=(z, 0, CZ), C=(gW1, 0, EH)))
-            items.append(dict(A=(h2, 0, EH), A_add=(z, 0, CZ), B=(dy, 0, CZ), C=(gWf, 0, EH), trans=True))
+            it = dict(A=(h2, 0, EH), B=(dy, 0, CZ), C=(gWf, 0, EH), trans=True)
+            if not h2_has_z:
+                it["A_add"] = (z, 0, CZ)
+            items.append(it)
             # On the side stream the grouped kernel takes 160 of the 256 CUs (32 row ranges x 5 tiles): it then runs 1.6x longer
             # but BESIDE the ~100 latency-bound node-level / IPA launches the main stream issues next, instead of holding
             # every CU while they queue behind it (27.1 -> 26.5 ms per step; 128 / 192 / 256 blocks: 26.6 / 26.6 / 27.1)
@@ -432,6 +440,15 @@ def _tfmr_layers(P, b):
     return n
 
 
+def _fork_bb_update(P, b, n3, dmask, quat, trans, R, box, like):
+    """the backbone update beside the edge transition (sampling): the tensors the branch reads are bound HERE, not looked up
+    through the caller's loop variables when the side stream runs (ops.fork), and it keeps its own profiling range"""
+    def run(n3=n3, quat=quat, trans=trans):
+        with rng(f"node_transition_{b}.fwd"):
+            box.update(r=bb_update_fwd(P, b, n3, dmask.view(-1), quat, trans, R))
+    ops.fork(run, like, keep=(n3, quat, trans, dmask))
+
+
 def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_bool_mask=False, save=True, cache=None):
     """ScoreNetwork.forward.  Returns (outputs, saved-for-backward or None).  `cache`: see _cached (no-grad only)."""
     if save:
@@ -442,6 +459,8 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
     L = lib()
     mask = f["res_mask"]
     dev = mask
+    if not (mask.is_cuda and torch.cuda.is_current_stream_capturing()):
+        ops.edge_sched_init(mask.device)      # (the tile-counter pool of the fused edge kernels: never allocated inside a capture)
     if cache is not None:
         # the cache is only valid for the static mask buffers it was built from
         sig = (B, N, mask.data_ptr(), f["fixed_mask"].data_ptr(), bool(tfmr_bool_mask))
@@ -473,6 +492,25 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
     else:
         key_add = (1 - mask).contiguous()
     stages = []
+    # sampling: the four skip_embed products depend on nothing but the embedder's output -- ONE GEMM per forward against the
+    # zero-padded row-concatenation of their weights (folded once per trajectory) writes the skip columns of every block's
+    # [LayerNorm input | skip] buffer; block b's buffer is the column range [320 b, 320 b + 320) of one [R, 320 nb] tensor
+    # (its first 256 columns are written later, by the block's IPA linear_out)
+    cat_all = None
+    if (cache is not None and not save and num_blocks > 1 and opts.merge_skip_embed and not ops.fork_ok(mask)
+            and all(_tfmr_layers(P, b) >= 1 for b in range(num_blocks))
+            and ops.ln_linear_ok((node, 0, TD), (node, 0, TD), R, 3 * TD, TD)):
+        tp = "score_model.trunk"
+        if "skip_all" not in cache:
+            Wp = torch.zeros((num_blocks * TD, CS), device=mask.device)
+            bp = torch.zeros((num_blocks * TD,), device=mask.device)
+            for b in range(num_blocks):
+                Wp[b * TD + CS:(b + 1) * TD] = P[f"{tp}.skip_embed_{b}.weight"]
+                bp[b * TD + CS:(b + 1) * TD] = P[f"{tp}.skip_embed_{b}.bias"]
+            cache["skip_all"] = (Wp, bp)
+        Wp, bp = cache["skip_all"]
+        cat_all = empty((R, num_blocks * TD), dev)
+        ops.linear(mv(init_node), mv(Wp), bp, mv(cat_all), R, num_blocks * TD, CS)
     for b in range(num_blocks):
         pre = f"score_model.trunk.ipa_{b}"
         nl = _tfmr_layers(P, b)
@@ -481,16 +519,18 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
         # the first 256 itself; the transition's LayerNorm: inside the edge transition's per-residue GEMM (blocks that have one)
         fold1 = (not save) and nl >= 1 and node.is_cuda == z.is_cuda and ops.ln_linear_ok((node, 0, TD), (node, 0, TD), R, 3 * TD, TD)
         fold6 = fold1 and b < num_blocks - 1 and et_folds_node_terms(cache, save)
-        cat = empty((R, TD), dev) if fold1 else None
+        # cat: matrix view (tensor, column offset, row stride) of the block's [LayerNorm input | skip] buffer
+        cat = ((cat_all, b * TD, num_blocks * TD) if cat_all is not None else (empty((R, TD), dev), 0, TD)) if fold1 else None
         ops.join(node)          # the backbone update of the block in front (sampling: a second graph branch)
-        if fold1:
+        if fold1 and cat_all is None:
             # skip_embed depends on nothing but the embedder's output: beside the IPA launches (its own columns of `cat`)
             tp = "score_model.trunk"
-            ops.fork(lambda: ops.linear(mv(init_node), mv(P[f"{tp}.skip_embed_{b}.weight"]), P[f"{tp}.skip_embed_{b}.bias"],
-                                        (cat, CS, TD), R, 64, CS), node)
+            ops.fork(lambda b=b, cat=cat: ops.linear(mv(init_node), mv(P[f"{tp}.skip_embed_{b}.weight"]),
+                                                     P[f"{tp}.skip_embed_{b}.bias"], (cat[0], cat[1] + CS, cat[2]), R, 64, CS), node,
+                     keep=(init_node, cat[0]))
         with rng(f"ipa_{b}.fwd"):
             x1, sv_ipa = nw.ipa_fwd(P, pre, mv(node), z, quat, trans, mask.view(-1), B, N, cache, zb=zb,
-                                    out_view=(cat, 0, TD) if fold1 else None, save=save)
+                                    out_view=cat if fold1 else None, save=save)
         with rng(f"seq_tfmr_{b}.fwd"):
             pend_ln = None      # a LayerNorm whose launch is folded into its consumer's (nw.tfmr_layer_fwd)
             if fold1:
@@ -523,7 +563,7 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
                 z, sv_et, zb = edge_transition_fwd(
                     P, b, None, z, emask, B, N, save=save, cache=cache,
                     zb_next=nw.ipa_w40(P, f"score_model.trunk.ipa_{b + 1}", cache), n3_ln=n3_ln,
-                    after_terms=lambda: ops.fork(lambda: bbo.update(r=bb_update_fwd(P, b, n3, dmask.view(-1), quat, trans, R)), node))
+                    after_terms=lambda b=b, n3=n3, quat=quat, trans=trans: _fork_bb_update(P, b, n3, dmask, quat, trans, R, bbo, node))
             q2, t2, sv_bb = bbo["r"]
         else:
             with rng(f"node_transition_{b}.fwd"):

@@ -28,6 +28,8 @@ def test_product_library_exports_every_symbol():
     lib = hip.FdLib(hip.LIB_PATH)            # binds every symbol; AttributeError if one is missing
     assert lib.backend == "gfx950"
     assert lib.cdll.fd_abi_version() == 1
+    # built without the probe switch: none of the timing / ablation hooks of the kernel sources (csrc/fd_probe.h) is in it
+    assert lib.cdll.fd_build_flags() == b""
     for s in header_symbols():
         assert hasattr(lib.cdll, s)
 
@@ -50,3 +52,13 @@ def test_error_reporting(emu_lib):
     with pytest.raises(hip.FdError, match="multiple of 64"):
         emu_lib.call("fd_layernorm_fwd", torch.zeros(2, 100), 100, torch.ones(100), torch.zeros(100), None,
                      torch.zeros(2, 100), 100, None, None, 2, 100, 1e-5)
+
+
+def test_probe_macros_do_not_compile_in_a_product_build(tmp_path):
+    """a stray ablation macro (-DEM_ABLATE_PQ, -DFL_ABL_NOKV, ...) is a compile error unless the build is declared a probe build"""
+    import subprocess
+    from se3_diffusion_amd import build
+    for src, macro in (("fd_edge_mlp.hip", "EM_ABLATE_PQ"), ("fd_ipa_flash.hip", "FL_ABL_NOKV")):
+        cmd = [build.HIPCC, *build.FLAGS, f"-D{macro}", "-fsyntax-only", "--cuda-host-only", os.path.join(build.CSRC, src)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode != 0 and "probe / ablation macro" in r.stderr, (src, r.stderr[-500:])

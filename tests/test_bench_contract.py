@@ -69,3 +69,39 @@ def test_bench_under_torchrun(hip_lib):
                        capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     _check(_line(r.stdout), 2)
+
+
+def test_bench_two_ranks_over_rccl(hip_lib):
+    """`python bench.py --gpus 2` over nccl (= RCCL over xGMI) on a box that HAS two GPUs: the first multi-rank RCCL init, the
+    parameter broadcast, the flat-gradient all-reduce and the barrier-bracketed timing with one rank per device -- the path
+    the driver's SCALE run takes (reference DDP launch: experiments/train_se3_diffusion.py:83-91,273-277).  Skipped on the
+    one-GPU boxes this repository is developed on (RCCL has so far only run with ONE rank: tests/test_dist.py)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the gpurun boxes have one)")
+    env = dict(os.environ, FD_BENCH_PRIME="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "FD_DIST_BACKEND", "FD_FORCE_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = _line(r.stdout)
+    _check(d, 2)
+    c = d["config"]
+    assert c["ranks"] == 2 and c["collective_backend"] == "nccl" and c["rccl_ranks"] == 2 and len(c["ms_per_step_by_rank"]) == 2
+
+
+def test_bench_takes_world_size_from_the_launcher(hip_lib):
+    """torchrun --nproc-per-node=2 bench.py WITHOUT --gpus 2: the launcher's WORLD_SIZE wins (a warning, not an AssertionError
+    on every rank)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, FD_BENCH_PRIME="1", FD_DIST_BACKEND="gloo", FD_FORCE_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), *SMALL],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "measuring 2 ranks" in r.stderr
+    _check(_line(r.stdout), 2)

@@ -253,5 +253,26 @@ def test_diffuser_kernels_gpu(hip_lib, tmp_path):
     tt = torch.tensor(G["ts"], dtype=torch.float32).cuda()
     sc = d.calc_rot_score(ru.Rotation(quats=qt, normalize_quats=False), ru.Rotation(quats=q0, normalize_quats=False), tt)
     assert np.abs(sc.detach().cpu().numpy() - G["crs_out"])[2:].max() < 5e-4 * np.abs(G["crs_out"])[2:].max()
-    sc.sum().backward()
+    # ... and its gradient w.r.t. q_0 (score_ops._RotScoreFn.backward = fd_heads_bwd) against central differences of the same
+    # entry point: L = sum(w * score), h = 1e-3 on each of the 4 components of every residue's quaternion (fp32 input, fp64
+    # output: truncation O(h^2) ~ 1e-6, round-off ~ 1e-7 / h = 1e-4 of the score's size); bound 2e-3 of the gradient's maximum
+    w = torch.tensor(np.random.RandomState(7).randn(*sc.shape), dtype=torch.float64).cuda()
+    (sc * w).sum().backward()
     assert torch.isfinite(q0.grad).all()
+    g = q0.grad.detach().double().cpu().numpy()
+
+    def loss_at(q):
+        with torch.no_grad():
+            o = d.calc_rot_score(ru.Rotation(quats=qt, normalize_quats=False), ru.Rotation(quats=q, normalize_quats=False), tt)
+        return float((o * w).sum())
+    h = 1e-3
+    fd_g = np.zeros_like(g)
+    base = q0.detach()
+    for idx in np.ndindex(*g.shape):
+        qp, qm = base.clone(), base.clone()
+        qp[idx] += h
+        qm[idx] -= h
+        fd_g[idx] = (loss_at(qp) - loss_at(qm)) / (float(qp[idx]) - float(qm[idx]))
+    err = np.abs(g - fd_g).max() / np.abs(fd_g).max()
+    print(f"[parity] calc_rot_score backward vs central differences: max err {err:.2e} of max |grad| {np.abs(fd_g).max():.3e}")
+    assert err < 2e-3, (err, g.reshape(-1)[:8], fd_g.reshape(-1)[:8])

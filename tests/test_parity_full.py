@@ -42,6 +42,8 @@ MODES = ("shipped", "persistent", "exact_f32")
 TOL_LOSS = 1e-4
 # 50 chained steps: measured 1.4e-5 (rotation matrices), 1.2e-4 A (translations), 1e-6 (psi), eager and graph-replayed alike
 TOL_TRAJ50 = (1.5e-4, 1.5e-3, 1e-4)
+# the metric's own schedule (500 steps, dt = 1/500): provisional bounds until the first GPU run records what is achieved
+TOL_TRAJ500 = (1.5e-3, 1.5e-2, 1e-3)
 TOL_GSIG = 2e-3       # gradient signatures (sum, norm) of the reference's large tensors
 
 
@@ -175,24 +177,23 @@ def test_n512_b8_forward_batch_of_verified_examples(hip_lib):
     _check_outputs({k: v[0:1] for k, v in big.items()}, ref)
 
 
-def test_oracle_n128_b30_benchmarked_step(hip_lib):
-    """The EXACT launch configuration bench.py times (BASELINE configs[1]): B=30 x N=128, full depth, ScoreNetwork module with
-    the FlatAdam(adjacent=flat_layout_groups()) layout (merged IPA projections, [linear_b ; down_z] as one matrix),
-    accumulate_into_grad, gradient side stream ON, 160-block pair_dw beside the main stream, >= 512-tile persistent split
-    GEMMs, fused device loss -- outputs, loss and all 282 parameter gradients against the oracle (torch-CPU restatement,
-    ~20 GB / ~20 s on the box's host cores)."""
+def _module_step_vs_oracle(hip_lib, B, N, seed, label, min_dynamic=0):
+    """One training step through the ScoreNetwork module with the FlatAdam(adjacent=flat_layout_groups()) layout (merged IPA
+    projections, [linear_b ; down_z] as one matrix), accumulate_into_grad, gradient side stream ON, fused device loss -- outputs,
+    loss and all 282 parameter gradients against the oracle (torch-CPU restatement on the box's host cores).  Returns the
+    launch-path counters the step moved (ops.STATS)."""
     from se3_diffusion_amd import loss as floss, ops, train_step as ts
     from se3_diffusion_amd.model.score_network import ScoreNetwork
     from se3_diffusion_amd.optim import FlatAdam
-    B, N, blocks = 30, 128, 4
+    blocks = 4
     conf = dict(fo.CONF, num_blocks=blocks)
-    P = fo.synth_params(seed=61, conf=conf)
+    P = fo.synth_params(seed=seed, conf=conf)
     model = ScoreNetwork(ts.base_model_conf(blocks), diffuser=None)
     model.load_state_dict(P, strict=True)
     model = model.cuda().train()
     opt = FlatAdam(model.parameters(), lr=1e-4, adjacent=model.flat_layout_groups())
     model.accumulate_into_grad = True
-    batch = ts.synthetic_batch(B, N, "cuda", seed=100)
+    batch = ts.synthetic_batch(B, N, "cuda", seed=100 + seed)
     batch["t"][:5] = torch.tensor([0.03, 0.15, 0.22, 0.6, 0.99], device="cuda")     # both sides of every loss threshold
     gt37, _ = ts.backbone_atoms(batch["rigids_0"], batch["torsion_angles_sin_cos"][..., 2, :])
     assert ops.side_active(batch["rigids_t"], B * N * N), "the benchmarked step runs its weight gradients on the side stream"
@@ -200,23 +201,22 @@ def test_oracle_n128_b30_benchmarked_step(hip_lib):
     assert was_p == 256 and not hip_lib.exact_f32
     from se3_diffusion_amd import network as nw
     assert nw._proj_views(dict(model.named_parameters()), "score_model.trunk.ipa_0") is not None   # merged projections
-    n_dyn = ops.STATS["edge_dynamic_launches"]
+    before = dict(ops.STATS)
     for _ in range(2):            # second pass = the steady state the benchmark times (allocator, cached views)
         opt.zero()
         out = model(batch)
         loss = floss.dsm_loss(batch, out, gt37)
         loss.backward()
     torch.cuda.synchronize()
-    # 491,520 pair rows = 7,680 tiles on 512 blocks: every fused edge launch (3 fwd + 3 bwd) and the embedder's backward hand their
-    # tiles out through the atomic counter (FdEdgeMlpDesc.sched != null) -- the path the benchmark times
-    assert ops.STATS["edge_dynamic_launches"] - n_dyn >= 2 * 7, ops.STATS
+    moved = {k: ops.STATS[k] - before[k] for k in before}
+    assert moved["edge_dynamic_launches"] >= min_dynamic, moved
     cpu_batch = {k: v.cpu() for k, v in batch.items()}
     torch.set_num_threads(min(32, os.cpu_count() or 8))
     Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     ref = fo.score_network_forward(Po, cpu_batch, conf, tfmr_mask_mode="additive")
     lref = ts.dsm_loss(cpu_batch, ref, gt37.cpu())
     lref.backward()
-    with parity_log.case("oracle B=30 N=128 benchmarked step (module + FlatAdam + fused loss, side stream on)"):
+    with parity_log.case(label):
         _check_outputs({k: v.detach() for k, v in out.items()}, {k: v.detach() for k, v in ref.items()})
         lerr = abs(float(loss) - float(lref)) / abs(float(lref))
         parity_log.out("loss", lerr)
@@ -228,7 +228,36 @@ def test_oracle_n128_b30_benchmarked_step(hip_lib):
             if mm is not None:
                 bad.append((n,) + mm)
         assert not bad, bad[:10]
-        check_kinks(kinks, "oracle B=30 N=128 benchmarked step")
+        check_kinks(kinks, label)
+    return moved
+
+
+def test_oracle_n128_b30_benchmarked_step(hip_lib):
+    """The EXACT launch configuration bench.py times (BASELINE configs[1]): B=30 x N=128, full depth, 160-block pair_dw beside the
+    main stream, >= 512-tile persistent split GEMMs (~20 GB / ~20 s of oracle on the box's host cores).
+    491,520 pair rows = 7,680 tiles on 512 blocks: every fused edge launch (3 fwd + 3 bwd) and the embedder's backward hand their
+    tiles out through the atomic counter (FdEdgeMlpDesc.sched != null) -- the path the benchmark times; 240 query tiles: the
+    one-launch IPA attention kernels in both directions."""
+    moved = _module_step_vs_oracle(hip_lib, 30, 128, 61, "oracle B=30 N=128 benchmarked step (module + FlatAdam + fused loss, side stream on)",
+                                   min_dynamic=2 * 7)
+    assert moved["ipa_flash_fwd"] == 8 and moved["ipa_flash_bwd"] == 8 and moved["ipa_sequence_bwd"] == 0, moved
+
+
+def test_oracle_n200_b12_mixed_length_step(hip_lib):
+    """A configs[3] shape (dist.mixed_length_schedule: N ~ U{100..512}, B = min(32, 5e5 // N^2); reference
+    experiments/train_se3_diffusion.py:524-693, data/utils.py:387-399) that takes the one-launch IPA attention in BOTH directions
+    with a RAGGED last query / key tile: B=12 x N=200 = 156 query tiles, N % 16 = 8.  480,000 pair rows: 3,750 tiles of the
+    8-wave edge kernel with a ragged last tile.  All 282 gradients against the oracle."""
+    moved = _module_step_vs_oracle(hip_lib, 12, 200, 62, "oracle B=12 N=200 mixed-length step (flash IPA fwd + bwd, ragged tiles)")
+    assert moved["ipa_flash_fwd"] == 8 and moved["ipa_flash_bwd"] == 8 and moved["ipa_sequence_bwd"] == 0, moved
+
+
+def test_oracle_n256_b7_mixed_length_step(hip_lib):
+    """The other mixed-length regime: B=7 x N=256 = 112 query tiles -- the one-launch IPA forward (>= 80 tiles) followed by the
+    GEMM-sequence backward (< 128 tiles: fd_ipa_attn_bwd reads the key-point copy the forward decided to keep).  All 282
+    gradients against the oracle."""
+    moved = _module_step_vs_oracle(hip_lib, 7, 256, 63, "oracle B=7 N=256 mixed-length step (flash IPA fwd, sequence bwd)")
+    assert moved["ipa_flash_fwd"] == 8 and moved["ipa_flash_bwd"] == 0 and moved["ipa_sequence_bwd"] == 8, moved
 
 
 def _golden_full(lib, name, mode):
@@ -308,16 +337,27 @@ def _trajectory(fixture, use_graph, tol_rot=4e-4, tol_trans=9e-3, tol_psi=1e-4):
     m = m.cuda().eval()
     B, N = int(T["B"]), int(T["N"])
     feats = sampler.init_feats(diff, B, N, "cuda", noise=(T["init_randn"], T["init_rand"], T["init_normal"]))
-    zr, zt = T["z_rot"], T["z_trans"]
+    if "rng_keys" in T:
+        # the 500-step fixture stores the state of numpy's global generator at the reference's first diffuser.reverse call instead
+        # of 3 MB of draws (rotation first, then translation, se3_diffuser.py:213-262; sampler.sample asks for them in step order)
+        rs = np.random.RandomState()
+        rs.set_state(("MT19937", T["rng_keys"], int(T["rng_pos"]), int(T["rng_has_gauss"]), float(T["rng_cached"])))
+        noise_fn = lambda i, shp: (rs.normal(size=shp), rs.normal(size=shp))
+        step_index = [int(i) for i in T["step_index"]]
+    else:
+        zr, zt = T["z_rot"], T["z_trans"]
+        noise_fn = lambda i, shp: (zr[i], zt[i])
+        step_index = list(range(len(T["step_rigids"])))
     out = sampler.sample(m, diff, feats, num_t=int(T["num_t"]), min_t=float(T["min_t"]), noise_scale=float(T["noise_scale"]),
-                         noise_fn=lambda i, shp: (zr[i], zt[i]), return_traj=True, use_graph=use_graph)
+                         noise_fn=noise_fn, return_traj=True, use_graph=use_graph)
     rm = lambda q: du.quat_wxyz_to_matrix(np.asarray(q)[..., :4].astype(np.float64))
     r0 = feats["rigids_t"].cpu().numpy()                    # same starting frames (quaternions up to sign)
     assert np.abs(rm(r0) - rm(T["rig_init"])).max() < 1e-5 and np.abs(r0[..., 4:] - T["rig_init"][..., 4:]).max() < 1e-4
     growth = []
     with parity_log.case(f"trajectory {fixture} graph={use_graph}"):
-        for i, (got, ref) in enumerate(zip(out["rigid_traj"], T["step_rigids"])):
-            got = got.cpu().numpy()
+        assert len(out["rigid_traj"]) == int(T["num_t"])
+        for i, ref in zip(step_index, T["step_rigids"]):
+            got = out["rigid_traj"][i].cpu().numpy()
             er, et = np.abs(rm(got) - rm(ref)).max(), np.abs(got[..., 4:] - ref[..., 4:]).max()
             growth.append((float(f"{er:.2e}"), float(f"{et:.2e}")))
             parity_log.out("rot_matrix_abs", er)
@@ -328,7 +368,8 @@ def _trajectory(fixture, use_graph, tol_rot=4e-4, tol_trans=9e-3, tol_psi=1e-4):
         parity_log.out("psi_abs", ep)
         assert ep < tol_psi
         if len(growth) > 8:
-            print(f"[parity] {fixture} graph={use_graph}: (rot, trans A) error at steps 1, 5, 10, 25, last: "
+            print(f"[parity] {fixture} graph={use_graph}: (rot, trans A) error at compared steps "
+                  f"{[step_index[j] + 1 for j in (0, 4, 9, 24, len(growth) - 1) if j < len(growth)]}: "
                   f"{[growth[j] for j in (0, 4, 9, 24, len(growth) - 1) if j < len(growth)]}")
 
 
@@ -359,3 +400,12 @@ def test_reference_trajectory_n128_50_steps(hip_lib, use_graph):
     Experiment.inference_fn at B=1 x N=128 (fixture traj_n128_t50, oracle/make_golden_full.py::traj_via_experiment), the same
     noise injected, eager and hipGraph-replayed.  Every step is compared; the per-step errors are printed."""
     _trajectory("traj_n128_t50", use_graph, tol_rot=TOL_TRAJ50[0], tol_trans=TOL_TRAJ50[1], tol_psi=TOL_TRAJ50[2])
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_reference_trajectory_n128_500_steps(hip_lib, use_graph):
+    """THE METRIC'S SCHEDULE: 500 reverse steps (501 forwards, dt = 1/500, the 500-point t grid -- other t_to_idx rows and another
+    g(t) / b(t) sequence than the 5- and 50-step fixtures) of the UNMODIFIED Experiment.inference_fn at B=1 x N=128
+    (experiments/train_se3_diffusion.py:746-781; fixture traj_n128_t500, oracle/make_golden_full.py::traj_via_experiment), the
+    reference's noise stream injected, eager and hipGraph-replayed.  Every 10th step is compared; error growth is printed."""
+    _trajectory("traj_n128_t500", use_graph, tol_rot=TOL_TRAJ500[0], tol_trans=TOL_TRAJ500[1], tol_psi=TOL_TRAJ500[2])

@@ -71,8 +71,10 @@ def _layernorm(lib, dev, rows, C, accum=False, scale=True):
 def test_layernorm_emu(emu_lib):
     _layernorm(emu_lib, "cpu", 67, 128)                 # C = 128 fast path, ragged row groups
     _layernorm(emu_lib, "cpu", 40, 128, accum=True, scale=False)
-    _layernorm(emu_lib, "cpu", 21, 256)                 # generic one-row-per-wave path
-    _layernorm(emu_lib, "cpu", 9, 320, accum=True)
+    _layernorm(emu_lib, "cpu", 21, 256)                 # node-level path: 4 rows per wave and trip, float4 chunks, ragged last trip
+    _layernorm(emu_lib, "cpu", 9, 320, accum=True)      # two chunks per lane, the second on 16 lanes
+    _layernorm(emu_lib, "cpu", 70, 512)                 # two full chunks; more than one trip per wave on the interpreter's grid
+    _layernorm(emu_lib, "cpu", 5, 64, scale=False)      # one chunk on 16 lanes
 
 
 @pytest.mark.gpu
@@ -80,7 +82,9 @@ def test_layernorm_gpu(hip_lib):
     _layernorm(hip_lib, "cuda", 100003, 128)
     _layernorm(hip_lib, "cuda", 4099, 128, accum=True, scale=False)
     _layernorm(hip_lib, "cuda", 3840, 256)
+    _layernorm(hip_lib, "cuda", 3840, 320)              # the training step's node-level shape: one trip per wave
     _layernorm(hip_lib, "cuda", 777, 320, accum=True)
+    _layernorm(hip_lib, "cuda", 40000, 512)             # several trips per wave
 
 
 def _colsum(lib, dev, rows, C):

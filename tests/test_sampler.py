@@ -73,3 +73,58 @@ def test_graph_fork_matches_single_stream_gpu(hip_lib):
             outs.append(sampler.sample(m, diff, feats, num_t=steps, noise_fn=lambda i, shape: z[i], use_graph=graph)["rigids"].clone())
     for o in outs[1:]:
         assert float((o - outs[0]).abs().max()) < 1e-4
+
+
+def _advance(lib, dev):
+    """fd_sample_advance: the first node of a captured diffusion step -- t, the reverse step's scalars and the step's draws from
+    device arrays indexed by a device counter, counter += 1 (experiments/train_se3_diffusion.py:746-781: the host side of the
+    reference's loop)"""
+    K, B, nz, steps = 3, 5, 2 * 5 * 7 * 3, 7
+    g = torch.Generator().manual_seed(2)
+    all_t = torch.rand(steps, generator=g).to(dev)
+    all_tp = torch.rand(steps, 2, generator=g, dtype=torch.float64).to(dev)
+    z_all = torch.randn(K, nz, generator=g, dtype=torch.float64).to(dev)
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    t_out, tp, z = torch.zeros(B, device=dev), torch.zeros(2, dtype=torch.float64, device=dev), torch.zeros(nz, dtype=torch.float64, device=dev)
+    for i in range(steps):
+        lib.call("fd_sample_advance", counter, all_t, all_tp, z_all, K, nz, t_out, B, tp, z)
+        assert int(counter.item()) == i + 1
+        assert torch.equal(t_out, all_t[i].expand(B)) and torch.equal(tp, all_tp[i]) and torch.equal(z, z_all[i % K])
+
+
+def test_sample_advance_emu(emu_lib):
+    _advance(emu_lib, "cpu")
+
+
+@pytest.mark.gpu
+def test_device_steps_match_host_steps_gpu(hip_lib):
+    """the captured step with fd_sample_advance as its first node (options.sampler_device_steps: no launch between graph replays)
+    against the same graph behind the three host-issued launches per step (fill_, copy_, copy_ / normal_) and against the eager
+    loop: same injected noise, bit-identical frames.  12 steps with NOISE_STEPS = 50 and 7 steps per refill are both covered by
+    patching the refill period."""
+    from se3_diffusion_amd import options
+    _advance(hip_lib, "cuda")
+    dev = "cuda"
+    diff = se3_diffuser.SE3Diffuser(dconf())
+    m = ScoreNetwork(ts.base_model_conf(2), diff)
+    m.load_state_dict(fo.synth_params(seed=5, conf=dict(fo.CONF, num_blocks=2)), strict=True)
+    m = m.to(dev).eval()
+    B, N, steps = 2, 48, 12
+    g = torch.Generator().manual_seed(0)
+    z = [(torch.randn(B, N, 3, generator=g, dtype=torch.float64), torch.randn(B, N, 3, generator=g, dtype=torch.float64))
+         for _ in range(steps)]
+    outs = []
+    for dev_steps, graph in ((False, False), (False, True), (True, True)):
+        with options.override(sampler_device_steps=dev_steps):
+            feats = sampler.init_feats(diff, B, N, dev, generator=torch.Generator(device=dev).manual_seed(1))
+            r = sampler.sample(m, diff, feats, num_t=steps, noise_fn=lambda i, shape: z[i], use_graph=graph, return_traj=True)
+            outs.append(torch.stack(r["rigid_traj"]).clone())
+    assert torch.equal(outs[1], outs[2])
+    assert float((outs[0] - outs[1]).abs().max()) < 1e-5
+    # device-drawn noise: a seeded generator gives the same trajectory twice, and finite frames
+    res = []
+    for _ in range(2):
+        gen = torch.Generator(device=dev).manual_seed(77)
+        feats = sampler.init_feats(diff, B, N, dev, generator=gen)
+        res.append(sampler.sample(m, diff, feats, num_t=60, generator=gen, use_graph=True)["rigids"].clone())
+    assert torch.equal(res[0], res[1]) and torch.isfinite(res[0]).all()

@@ -42,7 +42,7 @@ def main():
         z = torch.randn(Pn, 128, device=dev, generator=g)
         n3 = torch.randn(R, 256, device=dev, generator=g)
         emask = torch.ones(Pn, device=dev)
-        flops = 2.0 * Pn * (128 * 384 + 384 * 384 + 384 * 128 + 128 * 128)
+        flops = 2.0 * Pn * ops.EDGE_MLP_MACS_PER_ROW
         t_unf = timeit(lambda: trunk.edge_transition_fwd_unfused(P, 0, n3, z, emask, B, N))
         img = ops.edge_mlp_pack(W1, W2, Wf)
         imgT = ops.edge_mlp_pack(W1, W2, Wf, backward=True)
@@ -80,16 +80,26 @@ def main():
                   f" || fused LN {t_f:.3f} (vs {t_ln + t_b:.3f}) | fused LN + dzb {t_fz:.3f} | fused LN, no dgamma flush "
                   f"{t_fn:.3f} ms", flush=True)
             continue
-        t_trn = timeit(lambda: ops.edge_mlp(z, img, out, Pn, N, save1=h1, save2=h2, y=y, mean=mean, rstd=rstd, **kw))
+        # training forward as the step runs it: saves + packed masks + the next block's zb layer
+        mh1 = torch.zeros(Pn, 12, dtype=torch.int32, device=dev); mh2 = torch.zeros(Pn, 12, dtype=torch.int32, device=dev)
+        W40, b40, zb = e(40, 128).normal_() * 0.1, e(40).normal_(), e(Pn, 40)
+        img4 = ops.edge_mlp_pack(W1, W2, Wf, W40=W40)
+        tk = dict(save1=h1, save2=h2, y=y, mean=mean, rstd=rstd, mask1=mh1, mask2=mh2)
+        t_trn = timeit(lambda: ops.edge_mlp(z, img, out, Pn, N, **tk, **kw))
+        t_trn_zb = timeit(lambda: ops.edge_mlp(z, img4, out, Pn, N, zb_out=zb, zb_bias=b40, **tk, **kw))
         dz, d2, d1 = e(Pn, 128), e(Pn, 384), e(Pn, 384)
-        t_bwd = timeit(lambda: ops.edge_mlp(y, imgT, dz, Pn, N, gate1=h2, gate2=h1, save1=d2, save2=d1, backward=True,
-                                            blocks=a.blocks))
-        t_bwd_ns = timeit(lambda: ops.edge_mlp(y, imgT, dz, Pn, N, gate1=h2, gate2=h1, backward=True, blocks=a.blocks))
+        gk = dict(gmask1=mh2, gmask2=mh1, save1=d2, save2=d1, backward=True, blocks=a.blocks)
+        t_bwd = timeit(lambda: ops.edge_mlp(y, imgT, dz, Pn, N, **gk))
+        up, dzb, dy = e(Pn, 128).normal_(), e(Pn, 40).normal_(), e(Pn, 128)
+        dg, db = torch.zeros(128, device=dev), torch.zeros(128, device=dev)
+        lk = dict(ln_y=y, ln_mean=mean, ln_rstd=rstd, ln_gamma=gm, ln_rowscale=emask, dy_out=dy, ln_dgamma=dg, ln_dbeta=db)
+        imgZ = ops.edge_mlp_pack_bwd(Wf, W2, W1, W40=W40)
+        t_bwd_full = timeit(lambda: ops.edge_mlp(up, imgZ, dz, Pn, N, dzb=dzb, **gk, **lk))
         tf = lambda ms: flops / ms / 1e9
         print(f"B={B} N={N} rows={Pn}: unfused fwd {t_unf:.3f} ms ({tf(t_unf):.0f} TF) | fused fwd(no save) {t_inf:.3f} ms "
-              f"({tf(t_inf):.0f} TF) | fused fwd(+h1,h2,y) {t_trn:.3f} ms ({tf(t_trn):.0f} TF) | fused bwd chain(+d2,d1) "
-              f"{t_bwd:.3f} ms ({tf(t_bwd):.0f} TF) | bwd chain no save {t_bwd_ns:.3f} ms | pack {t_pack * 1e3:.1f} us",
-              flush=True)
+              f"({tf(t_inf):.0f} TF) | fused fwd(+h1,h2z,y,masks) {t_trn:.3f} ms ({tf(t_trn):.0f} TF) | + zb {t_trn_zb:.3f} ms | "
+              f"fused bwd chain(+d2,d1) {t_bwd:.3f} ms ({tf(t_bwd):.0f} TF) | bwd with LN + dzb prologue {t_bwd_full:.3f} ms | "
+              f"pack {t_pack * 1e3:.1f} us", flush=True)
 
 
 if __name__ == "__main__":

@@ -79,7 +79,7 @@ def build_variants():
     others = [os.path.join(build.OBJ, f) for f in sorted(os.listdir(build.OBJ)) if f.endswith(".o") and f != "fd_ipa_flash.o"]
     for tag, flags in VARIANTS.items():
         obj = os.path.join(PROBES, f"fd_ipa_flash_{tag}.o")
-        r = subprocess.run([build.HIPCC, *build.FLAGS, *flags, "-c", os.path.join(build.CSRC, "fd_ipa_flash.hip"), "-o", obj,
+        r = subprocess.run([build.HIPCC, *build.FLAGS, "-DFD_PROBE_BUILD", *flags, "-c", os.path.join(build.CSRC, "fd_ipa_flash.hip"), "-o", obj,
                             "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         spills = [l.split("VGPRs Spill:")[1].split()[0] for l in r.stderr.splitlines() if "VGPRs Spill:" in l]

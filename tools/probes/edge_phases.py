@@ -26,7 +26,7 @@ def build_probe(extra=(), tag="phases"):
     src = os.path.join(build.CSRC, "fd_edge_mlp.hip")
     if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
         flags = list(extra) if extra else ["-DEM_PHASE_TIMING"]
-        subprocess.check_call([build.HIPCC, *build.FLAGS, *flags, "-c", src, "-o", obj])
+        subprocess.check_call([build.HIPCC, *build.FLAGS, "-DFD_PROBE_BUILD", *flags, "-c", src, "-o", obj])
         objs = [os.path.join(build.OBJ, f) for f in sorted(os.listdir(build.OBJ)) if f.endswith(".o") and f != "fd_edge_mlp.o"]
         subprocess.check_call([build.HIPCC, f"--offload-arch={build.ARCH}", "-shared", "-fPIC", obj, *objs, "-o", out])
     return out

@@ -20,9 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # tag -> extra flags ("" = the product library itself)
 VARIANTS = {
     "shipped": None,
-    "nt_saves": ["-DEM_NT_SAVES"],
     "shipped again": [],
-    "nt_saves again": ["-DEM_NT_SAVES"],
 }
 if os.environ.get("EDGE_VARIANTS_EXTRA"):          # "tag:-DX=1,-DY=2;tag2:..."
     for item in os.environ["EDGE_VARIANTS_EXTRA"].split(";"):
