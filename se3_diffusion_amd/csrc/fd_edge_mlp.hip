@@ -61,6 +61,8 @@ namespace {
 
 #include "fd_chain.h"
 
+__device__ __forceinline__ float fd_f4(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
 constexpr int EM_UNITS = 120;              // units per tile
 constexpr int EM_ZB_UNITS = 4;             // + the next IPA block's [linear_b ; down_z] (40 <- 128: 4 k-steps x one n-group)
 constexpr int EM_ZB = 40;
@@ -286,12 +288,28 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
 
     // the kernel's input row in layer-output layout: lane (m, g) holds columns 16 nb + 4 g + r -- two consecutive blocks are the
     // B operand of a 32-k step in chained k order
-    f32x4 X[8];
+    // forward: the input row is NOT held in registers (32 of them, beside the 96-register accumulator of layer 2, the 32 of layer 1
+    // and 48 of weight fragments: the compiler answered with 80 - 140 spilled VGPRs and a scratch round trip of the accumulator
+    // in every chunk) -- the two 16-blocks of a k-step of layer 1 are fetched one k-step ahead (L1 / L2 hits after the first
+    // chunk), and the residual add of epilogue 2 fetches the row once more.  backward: the row (dy) is held: with the fused
+    // prologue it exists only in registers.
+    f32x4 X[BWD ? 8 : 1], Xk[2][2];
+    auto load_xk = [&](int buf, int ks) __attribute__((always_inline)) {
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!LNB || d.x != nullptr) v = *reinterpret_cast<const float4*>(d.x + rc * EM_C + 16 * nb + 4 * g);
-      X[nb][0] = v.x; X[nb][1] = v.y; X[nb][2] = v.z; X[nb][3] = v.w;
+      for (int i = 0; i < 2; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(d.x + rc * EM_C + 16 * (2 * ks + i) + 4 * g);
+        Xk[buf][i][0] = v.x; Xk[buf][i][1] = v.y; Xk[buf][i][2] = v.z; Xk[buf][i][3] = v.w;
+      }
+    };
+    if (BWD) {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!LNB || d.x != nullptr) v = *reinterpret_cast<const float4*>(d.x + rc * EM_C + 16 * nb + 4 * g);
+        X[nb][0] = v.x; X[nb][1] = v.y; X[nb][2] = v.z; X[nb][3] = v.w;
+      }
+    } else {
+      load_xk(0, 0);
     }
     if (LNB) {
       // ---- fused prologue of the backward: dz (upstream) [+ dzb W40]  ->  LayerNorm backward  ->  dy ----
@@ -401,7 +419,9 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
       acc2[nb][0] = a.x; acc2[nb][1] = a.y; acc2[nb][2] = a.z; acc2[nb][3] = a.w;
     }
 
-    f32x4 acc1[8];
+    f32x4 acc1[8], acc1g[2];
+    float4 zres[8];          // forward: the input row once more, for the residual into the final layer (requested under the last
+                             // k-step of layer 2, when the layer-1 accumulator has freed its registers)
 #pragma clang loop unroll(full)
     for (int c = 0; c < 3; ++c) {
       // hidden chunk of this pass: the backward walks 1, 2, 0 so that the UNGATED layer-1 accumulator of hidden units 0..127 -- the
@@ -421,7 +441,15 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
           const int r = EM_UPS * sg + (hh >> 1), g2 = r & 1, a = 4 * g2 + 2 * (hh & 1);
           EM_PIN_TOP();
           if (hh + 1 < 2 * EM_UPS) em16_read_half(H[(hh + 1) & 1], st + (hh + 1) * (EM_UNIT / 2));
-          if (g2 == 0 && (hh & 1) == 0) em16_split2(X[2 * (r >> 1)], X[2 * (r >> 1) + 1], b[0], b[1], b[2]);
+          if (g2 == 0 && (hh & 1) == 0) {
+            const int ks = r >> 1;
+            if (BWD) {
+              em16_split2(X[BWD ? 2 * ks : 0], X[BWD ? 2 * ks + 1 : 0], b[0], b[1], b[2]);
+            } else {
+              em16_split2(Xk[ks & 1][0], Xk[ks & 1][1], b[0], b[1], b[2]);
+              if (!(c == 2 && ks == 3)) load_xk((ks + 1) & 1, (ks + 1) & 3);     // (the next chunk's first k-step behind the last)
+            }
+          }
           em16_mma_half(acc1[a], acc1[a + 1], H[hh & 1], b);
           EM_GROUPS(hh + 1 < 2 * EM_UPS);
           if (hh == 1) stage_prefetch();
@@ -430,6 +458,9 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
       // epilogue 1, forward: h1 = relu(acc + P1_i + Q1_j)   (backward: the gate is applied where layer 2 splits the blocks)
       EM_BODY_TO(2);
       if (!BWD) {
+        // (the sixteen per-residue fetches stay behind the chunk's last MFMAs: hoisted above them -- 64 registers in flight beside
+        //  the fragments of the last half-unit -- they cost the inference variants 90 - 140 spilled VGPRs)
+        fd::sched_pin();
         unsigned bits1 = 0u;
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) {
@@ -464,15 +495,21 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
           if (g6 == 0 && (hh & 1) == 0) {
             // the two 16-blocks this k-step consumes: (backward) gated, split, and (training) saved HERE -- two stores per six
             // units of MFMAs instead of eight back to back in an epilogue
-            f32x4 t[2];
+            if (BWD) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+              for (int i = 0; i < 2; ++i)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float v = acc1[2 * ks + i][e];
-                t[i][e] = BWD ? (((gm1[hc] >> (4 * (2 * ks + i) + e)) & 1u) ? v : 0.f) : v;
-              }
-            em16_split2(t[0], t[1], b[0], b[1], b[2]);
+                for (int e = 0; e < 4; ++e)
+                  acc1g[i][e] = ((gm1[hc] >> (4 * (2 * ks + i) + e)) & 1u) ? acc1[2 * ks + i][e] : 0.f;
+              em16_split2(acc1g[0], acc1g[1], b[0], b[1], b[2]);
+            } else {
+              em16_split2(acc1[2 * ks], acc1[2 * ks + 1], b[0], b[1], b[2]);
+            }
+            const f32x4 (&t)[2] = BWD ? acc1g : reinterpret_cast<const f32x4 (&)[2]>(acc1[2 * ks]);
+            if (!BWD && c == 2 && ks == 3) {
+#pragma unroll
+              for (int nb = 0; nb < 8; ++nb) zres[nb] = *reinterpret_cast<const float4*>(d.x + rc * EM_C + 16 * nb + 4 * g);
+            }
             if (TRAIN && rok) {
 #pragma unroll
               for (int i = 0; i < 2; ++i)
@@ -498,7 +535,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
         const float v = acc2[nb][e];
         if (!BWD) {
           if (TRAIN) bits2 |= (v > 0.f ? 1u : 0u) << (4 * (nb & 7) + e);
-          acc2[nb][e] = (v > 0.f ? v : 0.f) + (nb < 8 ? X[nb & 7][e] : 0.f);
+          acc2[nb][e] = (v > 0.f ? v : 0.f) + (nb < 8 ? fd_f4(zres[nb & 7], e) : 0.f);
         } else {
           acc2[nb][e] = ((gm2[nb >> 3] >> (4 * (nb & 7) + e)) & 1u) ? v : 0.f;
         }
