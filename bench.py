@@ -209,9 +209,10 @@ _PMC_NAMES = {7: ("edge_mlp16_kernel<false", "edge_mlp16_kernel<true"), 9: ("pai
 # fused LayerNorm-backward / dzb W40 prologue (template arguments 4, 5) reads the upstream gradient (512), dzb (160), y (512),
 # mean / rstd (8) and the gates (96), writes dy (512), d2, d1 (3072) and dz (512)
 _EDGE_ALGO_BYTES = {"edge_mlp16_kernel<false": 512 + 512 + 3072 + 512 + 8 + 96 + 160,
-                    "edge_mlp16_kernel<true, false, false, true": 512 + 160 + 512 + 8 + 96 + 512 + 3072 + 512,
-                    "edge_mlp16_kernel<true, false, false, false": 512 + 96 + 3072 + 512,
-                    "edge_mlp16_kernel<true, false, false>": 512 + 96 + 3072 + 512}
+                    # (template arguments: BWD, ZB, TRAIN, LNB, ZBW)
+                    "edge_mlp16_kernel<true, false, true, true, true": 512 + 160 + 512 + 8 + 96 + 512 + 3072 + 512,
+                    "edge_mlp16_kernel<true, false, true, true, false": 512 + 512 + 8 + 96 + 512 + 3072 + 512,
+                    "edge_mlp16_kernel<true, false, true, false": 512 + 96 + 3072 + 512}
 
 
 def pmc_traffic(tile, rows):
