@@ -476,7 +476,10 @@ typedef struct FdHeadConst {
 int fd_heads_fwd(const float* rig0, const float* quatF, const float* transF, const float* upsi,
                  const float* gt_psi, long gt_stride, const float* fixed, const float* mask, const float* t,
                  const double* sigma_grid, int ng, const FdHeadConst* c, double* rot_score, float* trans_score,
-                 float* rigids, float* psi_out, float* atom37, float* atom14, int B, int N, void* stream);
+                 float* rigids, float* psi_out, float* atom37, float* atom14,
+                 float* sc_ca_out /* optional [R,3]: the predicted CA positions (= rigids[..., 4:7]) once more, where the sampling
+                 loop keeps its self-conditioning input (experiments/train_se3_diffusion.py:763-765) */,
+                 int B, int N, void* stream);
 /* data/all_atom.py:152-174 compute_backbone as one kernel: rigids [R,7] (A), psi [R,2] (sin,cos) */
 int fd_backbone_atoms(const float* rigids, const float* psi, const FdHeadConst* c, float* atom37, float* atom14,
                       long R, void* stream);
@@ -520,6 +523,11 @@ int fd_se3_reverse_step_f32(const float* rig_t, const float* rot_score, const fl
                         const double* z_rot, const double* z_trans, const float* mask, int B, int N, double g_rot,
                         double b_t, const double* tparams /* optional device {g_rot, b_t}: overrides the scalars,
                         lets one captured hipGraph serve every t */, double dt, double noise_scale,
+                        double coord_scale, int center, int diffuse_rot, int diffuse_trans, float* out, void* stream);
+/* ... and as ScoreNetwork.forward returns them: rot_score float64, trans_score float32 */
+int fd_se3_reverse_step_net(const float* rig_t, const double* rot_score, const float* trans_score,
+                        const double* z_rot, const double* z_trans, const float* mask, int B, int N, double g_rot,
+                        double b_t, const double* tparams, double dt, double noise_scale,
                         double coord_scale, int center, int diffuse_rot, int diffuse_trans, float* out, void* stream);
 /* The per-step host glue of the reverse loop (experiments/train_se3_diffusion.py:746-781: t = reverse_steps[i], the draws of
  * diffuser.reverse) as the FIRST NODE of a captured step: idx = *counter; t_out[0..B) = all_t[idx]; tparams[0..2) =

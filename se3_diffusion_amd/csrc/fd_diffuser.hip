@@ -208,9 +208,9 @@ __global__ __launch_bounds__(256) void forward_marginal_batch_kernel(
 // float32, the reference widens them to float64 before the step -- a float32 argument widened in registers is the same number
 // and saves the two conversion launches of every reverse step.  out may alias rig_t (in place): every read of a row's
 // translation for the mean happens before the barrier, after it each thread reads and writes only its own rows.
-template <typename ST>
+template <typename RT, typename TT>
 __global__ __launch_bounds__(256) void reverse_step_kernel(
-    const float* rig_t, const ST* __restrict__ rot_score, const ST* __restrict__ trans_score,
+    const float* rig_t, const RT* __restrict__ rot_score, const TT* __restrict__ trans_score,
     const double* __restrict__ z_rot, const double* __restrict__ z_trans, const float* __restrict__ mask, int N,
     double g_rot, double b_t, const double* __restrict__ tparams, double dt, double noise_scale, double cs, int center,
     int diffuse_rot, int diffuse_trans, float* out) {
@@ -359,10 +359,25 @@ extern "C" int fd_se3_reverse_step(const float* rig_t, const double* rot_score, 
                                    double coord_scale, int center, int diffuse_rot, int diffuse_trans, float* out,
                                    void* stream) {
   if (B == 0 || N == 0) return FD_OK;
-  hipLaunchKernelGGL(reverse_step_kernel<double>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, rig_t, rot_score,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(reverse_step_kernel<double, double>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, rig_t, rot_score,
                      trans_score, z_rot, z_trans, mask, N, g_rot, b_t, tparams, dt, noise_scale, coord_scale, center,
                      diffuse_rot, diffuse_trans, out);
   FD_CHECK_LAUNCH("fd_se3_reverse_step");
+  return FD_OK;
+}
+
+// the scores exactly as ScoreNetwork.forward returns them (rot_score float64, trans_score float32: score_network.py:199-214 after
+// the heads of this package): no conversion launch in front of the step
+extern "C" int fd_se3_reverse_step_net(const float* rig_t, const double* rot_score, const float* trans_score,
+                                       const double* z_rot, const double* z_trans, const float* mask, int B, int N,
+                                       double g_rot, double b_t, const double* tparams, double dt, double noise_scale,
+                                       double coord_scale, int center, int diffuse_rot, int diffuse_trans, float* out,
+                                       void* stream) {
+  if (B == 0 || N == 0) return FD_OK;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(reverse_step_kernel<double, float>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, rig_t,
+                     rot_score, trans_score, z_rot, z_trans, mask, N, g_rot, b_t, tparams, dt, noise_scale, coord_scale, center,
+                     diffuse_rot, diffuse_trans, out);
+  FD_CHECK_LAUNCH("fd_se3_reverse_step_net");
   return FD_OK;
 }
 
@@ -372,7 +387,7 @@ extern "C" int fd_se3_reverse_step_f32(const float* rig_t, const float* rot_scor
                                        double coord_scale, int center, int diffuse_rot, int diffuse_trans, float* out,
                                        void* stream) {
   if (B == 0 || N == 0) return FD_OK;
-  hipLaunchKernelGGL(reverse_step_kernel<float>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, rig_t, rot_score,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(reverse_step_kernel<float, float>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, rig_t, rot_score,
                      trans_score, z_rot, z_trans, mask, N, g_rot, b_t, tparams, dt, noise_scale, coord_scale, center,
                      diffuse_rot, diffuse_trans, out);
   FD_CHECK_LAUNCH("fd_se3_reverse_step_f32");

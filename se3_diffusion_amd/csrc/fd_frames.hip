@@ -278,7 +278,8 @@ __global__ __launch_bounds__(128) void heads_fwd_kernel(
     const float* __restrict__ gt_psi, long gt_stride, const float* __restrict__ fixed,
     const float* __restrict__ mask, const float* __restrict__ t, const double* __restrict__ sigma_grid, int ng,
     HeadConst hc, double* __restrict__ rot_score, float* __restrict__ trans_score, float* __restrict__ rigids,
-    float* __restrict__ psi_out, float* __restrict__ atom37, float* __restrict__ atom14, int N, long R_) {
+    float* __restrict__ psi_out, float* __restrict__ atom37, float* __restrict__ atom14, float* __restrict__ sc_ca_out,
+    int N, long R_) {
   for (long r = (long)blockIdx.x * 128 + threadIdx.x; r < R_; r += (long)gridDim.x * 128) {
     const int b = (int)(r / N);
     const float m = mask[r];
@@ -315,6 +316,8 @@ __global__ __launch_bounds__(128) void heads_fwd_kernel(
       const float xt = q0[4 + k] * cs, x0 = ta * cs;
       trans_score[r * 3 + k] = (-(xt - e1 * x0) / cv) * m;
       rigids[r * 7 + 4 + k] = ta;
+      // sampling: the predicted CA position is the next forward's self-conditioning input (train_se3_diffusion.py:763-765)
+      if (sc_ca_out != nullptr) sc_ca_out[r * 3 + k] = ta;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) rigids[r * 7 + k] = qf[k];
@@ -606,7 +609,7 @@ extern "C" int fd_heads_fwd(const float* rig0, const float* quatF, const float* 
                             const float* gt_psi, long gt_stride, const float* fixed, const float* mask,
                             const float* t, const double* sigma_grid, int ng, const FdHeadConst* c,
                             double* rot_score, float* trans_score, float* rigids, float* psi_out, float* atom37,
-                            float* atom14, int B, int N, void* stream) {
+                            float* atom14, float* sc_ca_out, int B, int N, void* stream) {
   FD_CHECK_ARG(c != nullptr, "fd_heads_fwd: null constants");
   FD_CHECK_ARG(!c->score_norms || (c->omega_grid && c->n_omega > 1), "fd_heads_fwd: cached score table without its grid");
   const long R_ = (long)B * N;
@@ -614,7 +617,7 @@ extern "C" int fd_heads_fwd(const float* rig0, const float* quatF, const float* 
   long g = (R_ + 127) / 128;
   hipLaunchKernelGGL(heads_fwd_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(128), 0, (hipStream_t)stream, rig0,
                      quatF, transF, upsi, gt_psi, gt_stride, fixed, mask, t, sigma_grid, ng, make_hc(c), rot_score,
-                     trans_score, rigids, psi_out, atom37, atom14, N, R_);
+                     trans_score, rigids, psi_out, atom37, atom14, sc_ca_out, N, R_);
   FD_CHECK_LAUNCH("fd_heads_fwd");
   return FD_OK;
 }

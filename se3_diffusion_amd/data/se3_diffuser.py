@@ -229,10 +229,12 @@ class SE3Diffuser:
         if out is None:
             out = torch.empty((B, N, 7), dtype=torch.float32, device=dev)
         # float32 scores on the device (what the network returns) go in as they are: the kernel widens them in registers
-        f32 = all(torch.is_tensor(s_) and s_.dtype == torch.float32 and s_.device == dev and s_.is_contiguous()
-                  for s_ in (rot_score, trans_score))
-        scores = (rot_score, trans_score) if f32 else (_f64(rot_score, dev), _f64(trans_score, dev))
-        hip.get_lib().call("fd_se3_reverse_step_f32" if f32 else "fd_se3_reverse_step", rigids_t7.to(torch.float32).contiguous(),
+        ok = lambda s_, dt_: torch.is_tensor(s_) and s_.dtype == dt_ and s_.device == dev and s_.is_contiguous()
+        f32 = ok(rot_score, torch.float32) and ok(trans_score, torch.float32)
+        net = ok(rot_score, torch.float64) and ok(trans_score, torch.float32)     # (as ScoreNetwork.forward returns them)
+        scores = (rot_score, trans_score) if (f32 or net) else (_f64(rot_score, dev), _f64(trans_score, dev))
+        entry = "fd_se3_reverse_step_f32" if f32 else "fd_se3_reverse_step_net" if net else "fd_se3_reverse_step"
+        hip.get_lib().call(entry, rigids_t7.to(torch.float32).contiguous(),
                            scores[0], scores[1], z_rot, z_trans, mask, B, N, float(self._so3_diffuser.diffusion_coef(t)),
                            float(self._r3_diffuser.b_t(t)), tparams, float(dt), float(noise_scale),
                            float(self._r3_diffuser._r3_conf.coordinate_scaling), int(center), int(self._diffuse_rot),

@@ -217,7 +217,7 @@ _SIGS = {
     "fd_split_rigids": "pfpfppplis",
     "fd_bb_update_fwd": "plipppppppp" + "ls",
     "fd_bb_update_bwd": "pppppppppp" + "ls",
-    "fd_heads_fwd": "pppp" + "pl" + "ppp" + "pi" + "S" + "pppppp" + "iis",
+    "fd_heads_fwd": "pppp" + "pl" + "ppp" + "pi" + "S" + "ppppppp" + "iis",
     "fd_heads_bwd": "ppppp" + "ppp" + "pi" + "S" + "ppppp" + "ppp" + "iis",
     "fd_backbone_atoms": "ppSppls",
     "fd_igso3_tables": "ppiiippps",
@@ -226,6 +226,7 @@ _SIGS = {
     "fd_forward_marginal_batch": "ppppppippdipppp" + "iis",
     "fd_se3_reverse_step": "ppppppiiddpdddiiips",
     "fd_se3_reverse_step_f32": "ppppppiiddpdddiiips",
+    "fd_se3_reverse_step_net": "ppppppiiddpdddiiips",
     "fd_sample_advance": "ppppilpipps",
     "fd_dsm_loss": "Ss",
     "fd_adam_step": "pppplffffffs",

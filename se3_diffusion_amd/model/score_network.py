@@ -73,7 +73,8 @@ class _ScoreNetFn(torch.autograd.Function):
         P = dict(zip(names, params))
         bool_mask = (not module.training) and not need_grad       # nn.TransformerEncoder fast-path semantics
         out, sv = trunk.forward(P, feats, module._num_blocks, module._dconf, tfmr_bool_mask=bool_mask,
-                                save=need_grad, cache=getattr(module, "_fd_static", None))
+                                save=need_grad, cache=getattr(module, "_fd_static", None),
+                                sc_ca_out=None if need_grad else getattr(module, "_fd_sc_ca_out", None))
         ctx.sv, ctx.P, ctx.names, ctx.module = sv, P, names, module
         res = tuple(out[k] for k in _OUT_KEYS)
         ctx.mark_non_differentiable(res[5])

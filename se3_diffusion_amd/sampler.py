@@ -96,9 +96,7 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
         if adv is not None:
             lib.call("fd_sample_advance", adv["counter"], adv["all_t"], all_tp, adv["z_all"], NOISE_STEPS, z_both.numel(),
                      st["t"], B, tparams, z_both)
-        out = model(st)
-        if embed_sc:
-            st["sc_ca_t"].copy_(out["rigids"][..., 4:])
+        out = model(st)      # (embed_sc: the heads kernel writes the predicted CA positions into st["sc_ca_t"] itself: _fd_sc_ca_out)
         # (in place: fd_se3_reverse_step reads every row it needs for the centring mean before it writes any)
         diffuser.reverse_device(st["rigids_t"], out["rot_score"], out["trans_score"], 0.5, dt, diffuse_mask=diffuse_mask,
                                 center=center, noise_scale=noise_scale, noise=(z_rot, z_trans), tparams=tparams,
@@ -110,6 +108,11 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
         if embed_sc and self_condition:
             set_t(steps[0])
             st["sc_ca_t"].copy_(model(st)["rigids"][..., 4:])
+        if embed_sc:
+            # from here on every forward leaves its predicted CA positions in st["sc_ca_t"] (an input of the NEXT forward; this
+            # forward's own readers -- the edge embedder's distogram -- are launched before the heads kernel that writes it)
+            st["sc_ca_t"] = st["sc_ca_t"].to(torch.float32).contiguous()
+            model._fd_sc_ca_out = st["sc_ca_t"]
         graph = None
         n_rev = int(np.sum(steps > min_t))
         if use_graph and lib.is_device and n_rev > 3:
@@ -172,6 +175,7 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
     finally:
         # an exception mid-trajectory must not leave the weight-derived cache, eval mode or the profiling switch behind
         model.__dict__.pop("_fd_static", None)
+        model.__dict__.pop("_fd_sc_ca_out", None)
         from . import ops as _ops
         _ops.join()                      # (options.graph_fork: nothing of an interrupted forward stays referenced on the branch)
         if was_training:

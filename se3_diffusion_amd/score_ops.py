@@ -43,7 +43,7 @@ class _RotScoreFn(torch.autograd.Function):
         rot = torch.empty((B, N, 3), device=dev.device, dtype=torch.float64)
         junk = [torch.empty((R, k), device=dev.device) for k in (3, 7, 2, 111, 42)]
         hip.get_lib().call("fd_heads_fwd", rig0, qf, z3, u, (gt, 4), 14, zeros, ones, tt, sg, sg.numel(), hc,
-                           rot, junk[0], junk[1], junk[2], junk[3], junk[4], B, N)
+                           rot, junk[0], junk[1], junk[2], junk[3], junk[4], None, B, N)
         ctx.saved = (rig0, qf, z3, u, junk[2], zeros, ones, tt, sg, hc, B, N)
         return rot
 

@@ -360,7 +360,7 @@ def sigma_grid(device, min_sigma=0.1, max_sigma=1.5, num_sigma=1000):
     return _SG[key]
 
 
-def heads_fwd(P, node, quat, trans, feats, B, N, dconf):
+def heads_fwd(P, node, quat, trans, feats, B, N, dconf, sc_ca_out=None):
     """Score heads, psi head, backbone atoms (ipa_pytorch.py:650-672, score_network.py:199-214)."""
     tp = "score_model.torsion_pred"
     dev = node
@@ -375,7 +375,7 @@ def heads_fwd(P, node, quat, trans, feats, B, N, dconf):
     gt = feats["torsion_angles_sin_cos"]
     tt = feats["t"].float().contiguous()
     lib().call("fd_heads_fwd", feats["rigids_t"], quat, trans, u, (gt, 4), 14, feats["fixed_mask"], feats["res_mask"],
-               tt, sg, sg.numel(), hc, rot, ts, rig, psi, a37, a14, B, N)
+               tt, sg, sg.numel(), hc, rot, ts, rig, psi, a37, a14, sc_ca_out, B, N)
     out = dict(psi=psi, rot_score=rot, trans_score=ts, rigids=rig, atom37=a37, atom14=a14)
     return out, dict(node=node, h1=h1, h2=h2, u=u, quat=quat, trans=trans, psi=psi, t=tt, hc=hc, sg=sg, B=B, N=N)
 
@@ -449,7 +449,8 @@ def _fork_bb_update(P, b, n3, dmask, quat, trans, R, box, like):
     ops.fork(run, like, keep=(n3, quat, trans, dmask))
 
 
-def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_bool_mask=False, save=True, cache=None):
+def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_bool_mask=False, save=True, cache=None,
+            sc_ca_out=None):
     """ScoreNetwork.forward.  Returns (outputs, saved-for-backward or None).  `cache`: see _cached (no-grad only)."""
     if save:
         cache = None
@@ -578,7 +579,11 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
             stages[-1] = None
     ops.join(node)
     with rng("heads.fwd"):
-        out, sv_h = heads_fwd(P, node, quat, trans, f, B, N, dconf)
+        # sampling: the heads also write the predicted CA positions where the loop keeps its self-conditioning input (sc_ca_out,
+        # handed down by sampler.sample through the module): no copy launch between the forward and the reverse step
+        sc_out = sc_ca_out if not save else None
+        assert sc_out is None or (sc_out.is_contiguous() and sc_out.dtype == torch.float32 and tuple(sc_out.shape) == (B, N, 3))
+        out, sv_h = heads_fwd(P, node, quat, trans, f, B, N, dconf, sc_ca_out=sc_out)
     if not save:
         return out, None
     return out, dict(feats=f, embed=sv_embed, stages=stages, heads=sv_h, B=B, N=N, num_blocks=num_blocks,
