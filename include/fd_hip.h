@@ -342,12 +342,6 @@ int fd_group_dw(const FdGroupDwDesc* desc, void* stream);
  * key mask or null; out [B*N, 320]; A_out [B, 4, N, N] optional (the probabilities, for the backward).  N <= 1024. */
 int fd_seq_attn_fwd(const float* qkv, const float* key_add, float* out, float* A_out, float scale, int B, int N,
                     void* stream);
-/* Its backward in two launches (query side: dS = A (dO V^T - D) with D = dO . out, dQ; key side: dV, dK) instead of four batched
- * GEMMs + a row-softmax backward.  A [B, 4, N, N]: the probabilities fd_seq_attn_fwd wrote; dout / out [B*N, 320]: the gradient
- * and the value of the attention output; dS [B, 4, N, N]: scratch (receives the score gradient); dqkv [B*N, 960] = [dq | dk | dv]
- * (every column written).  16-byte aligned operands, N <= 1024. */
-int fd_seq_attn_bwd(const float* qkv, const float* A, const float* dout, const float* out, float* dS, float* dqkv,
-                    float scale, int B, int N, void* stream);
 
 /* ---- embedder features: score_network.py:14-47,97-148; data/utils.py:570-580 ----
  * tscaled = (t*1e4) as fp32 [B]; tfreq[16], idenom[16], dg_lower[22], dg_upper[22] are the

@@ -203,7 +203,6 @@ _SIGS = {
     "fd_ipa_flash_bwd": "pppppppppppp" + "pppppp" + "iis",
     "fd_ipa_opt_bwd_dot": "ppppppp" + "ls",
     "fd_seq_attn_fwd": "ppppfiis",
-    "fd_seq_attn_bwd": "ppppppfiis",
     "fd_ipa_attn_bwd": "pppppppppppppiis",
     "fd_ipa_softmax_bwd": "ppppppppppiis",
     "fd_ipa_kpts_bwd": "pppppiis",

@@ -567,14 +567,6 @@ def tfmr_layer_bwd(P, G, pre, sv, dy2):
     qkv, A = sv["qkv"], sv["A"]
     dqkv = empty((R, 3 * TD), dev)
     dA = empty((B, TH, N, N), dev)
-    if opts.fused_seq_attn_bwd:
-        # query side (dS = A (dO V^T - dO . o), dQ) and key side (dV, dK) in two launches instead of four batched GEMMs + a
-        # row-softmax backward
-        L.call("fd_seq_attn_bwd", qkv, A, do, sv["o"], dA, dqkv, 1.0 / math.sqrt(THD), B, N)
-        _lin_grads(G, f"{pre}.self_attn.in_proj_weight", f"{pre}.self_attn.in_proj_bias", mv(dqkv), mv(sv["x"]), R, 3 * TD, TD)
-        dx = empty((R, TD), dev)  # dx = dt1 (residual) + dqkv W_in
-        ops.linear_dx(mv(dqkv), mv(P[f"{pre}.self_attn.in_proj_weight"]), mv(dx), R, 3 * TD, TD, resid=mv(dt1))
-        return dx
     # dA = do V^T ; dV = A^T do
     L.gemm(do, qkv, dA, N, N, THD, (TD, 1), (1, 3 * TD), N, b_off=2 * TD, batch=B * TH, bdiv=TH,
            a_bs=(N * TD, THD), b_bs=(N * 3 * TD, THD), c_bs=(TH * N * N, N * N))

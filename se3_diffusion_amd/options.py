@@ -68,9 +68,6 @@ class Options:
     # -- node level
     fused_seq_attn: bool = True       # FD_SEQ_ATTN_FUSED: sequence-transformer attention in one launch ...
     seq_attn_min_rows: int = 1024     # FD_SEQ_ATTN_MIN_ROWS: ... from this many residue rows up
-    fused_seq_attn_bwd: bool = False  # FD_SEQ_ATTN_BWD_FUSED (measured, OFF): its backward in two launches (fd_seq_attn_bwd: a wave per 16-row
-                                      # tile walks the other side's tiles) instead of four batched GEMMs + a row-softmax backward -- 58 against
-                                      # 54 us per layer at B=30 x N=128, 99 against 52 at B=7 x N=256: one wave per SIMD, a dependent load chain per tile
     grouped_node_dw: bool = True      # FD_NODE_DW: the node-level weight gradients of a trunk block in one grouped launch
     node_dw_blocks: int = 0           # FD_NODE_DW_BLOCKS: its persistent blocks (0 = 512: two per CU)
     ln_fold: bool = True              # FD_LN_FOLD: sampling -- the sequence transformer's LayerNorms inside the GEMM launches that
@@ -104,7 +101,6 @@ class Options:
             flash_ipa_hpb=_int("FD_IPA_FLASH_HPB", 0), flash_ipa_bwd=_flag("FD_IPA_FLASH_BWD", True),
             proj_merge=_flag("FD_PROJ_MERGE", True),
             fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),
-            fused_seq_attn_bwd=_flag("FD_SEQ_ATTN_BWD_FUSED", False),
             grouped_node_dw=_flag("FD_NODE_DW", True), node_dw_blocks=_int("FD_NODE_DW_BLOCKS", 0),
             ln_fold=_flag("FD_LN_FOLD", True),
             sampler_device_steps=_flag("FD_SAMPLER_DEVICE_STEPS", True), merge_skip_embed=_flag("FD_MERGE_SKIP", True), graph_fork=_flag("FD_GRAPH_FORK", False),

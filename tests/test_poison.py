@@ -21,7 +21,7 @@ def _run(dev, B, N, monkeypatch):
     ts.perturb_final_layers(model, seed=0)
     batch = ts.synthetic_batch(B, N, dev, seed=1)
     gt37, _ = ts.backbone_atoms(batch["rigids_0"], batch["torsion_angles_sin_cos"][..., 2, :])
-    for kw in (dict(), dict(flash_ipa_min_tiles=0, flash_ipa_bwd_min_tiles=0, fused_seq_attn_bwd=True)):
+    for kw in (dict(), dict(flash_ipa_min_tiles=0, flash_ipa_bwd_min_tiles=0)):
         with options.override(**kw):
             model.zero_grad()
             loss = floss.dsm_loss(batch, model(batch), gt37)

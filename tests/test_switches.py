@@ -55,7 +55,6 @@ GROUPS = [
     (dict(flash_ipa=False), 1e-4),            # fd_ipa_flash_fwd (probabilities written for the backward) vs the launch sequence
     (dict(flash_ipa_hpb=2), 1e-4),            # (its 2-heads-per-block shape against the default pick)
     (dict(flash_ipa_bwd=False), 1e-4),        # fd_ipa_flash_bwd vs dA GEMMs + fd_ipa_attn_bwd
-    (dict(fused_seq_attn_bwd=True), 1e-4),    # fd_seq_attn_bwd (off by default: slower) vs four batched GEMMs + row-softmax backward
     (dict(zero_arena=False, dx_splitk=False, grad_stream=False), 1e-4),
     (dict(grouped_pair_dw=False), 1e-4),
     (dict(grouped_node_dw=False), 1e-4),
@@ -68,6 +67,11 @@ GROUPS = [
     (dict(fused_ln_bwd=False, packed_gates=False), 1e-4),
     (dict(fused_edge=False, fused_embed=False), 2e-4),
 ]
+
+
+def _group(key):
+    """the first comparison group that switches `key` alone"""
+    return next(g for g in GROUPS if set(g[0]) == {key})
 
 
 def _compare(dev, B, N, blocks, groups=GROUPS):
@@ -86,13 +90,14 @@ def _compare(dev, B, N, blocks, groups=GROUPS):
 
 def test_switches_emu(use_emu):
     # (the heads-per-block shapes of the IPA kernel and the sequence-attention backward have kernel-level interpreter tests of
-    #  their own -- tests/test_ipa_flash.py, tests/test_seq_attn.py -- and run inside a step on the GPU tier)
-    _compare("cpu", B=2, N=8, blocks=1, groups=[g for g in GROUPS if not ({"flash_ipa_hpb", "fused_seq_attn_bwd"} & set(g[0]))])
+    #  their own -- tests/test_ipa_flash.py -- and run inside a step on the GPU tier)
+    _compare("cpu", B=2, N=8, blocks=1, groups=[g for g in GROUPS if not ({"flash_ipa_hpb"} & set(g[0]))])
 
 
 def test_switches_two_blocks_emu(use_emu):
     # with an edge transition between the blocks: the fused LayerNorm-backward / dzb W40 prologue against the separate kernels
-    _compare("cpu", B=1, N=8, blocks=2, groups=[GROUPS[4], GROUPS[11], GROUPS[12], GROUPS[13], GROUPS[14]])
+    _compare("cpu", B=1, N=8, blocks=2, groups=[_group("flash_ipa_bwd"), _group("packed_gates"), _group("edge_dynamic_tiles"),
+                                                _group("edge_shape"), _group("fused_ln_bwd")])
 
 
 def _dynamic_vs_static(dev, B, N, blocks):
@@ -136,4 +141,5 @@ def test_options_override_restores():
 @pytest.mark.gpu
 def test_switches_gpu(hip_lib):
     _compare("cuda", B=2, N=24, blocks=2)
-    _compare("cuda", B=4, N=128, blocks=1, groups=GROUPS[:7] + GROUPS[8:16])
+    # (B=4 x N=128, one block: everything but the unfused-edge groups, which need an edge transition)
+    _compare("cuda", B=4, N=128, blocks=1, groups=[g for g in GROUPS if not ({"grouped_pair_dw", "fused_edge"} & set(g[0]))])
