@@ -69,6 +69,8 @@ class Options:
     fused_seq_attn: bool = True       # FD_SEQ_ATTN_FUSED: sequence-transformer attention in one launch ...
     seq_attn_min_rows: int = 1024     # FD_SEQ_ATTN_MIN_ROWS: ... from this many residue rows up
     grouped_node_dw: bool = True      # FD_NODE_DW: the node-level weight gradients of a trunk block in one grouped launch
+    defer_node_dw: bool = True        # FD_DEFER_NODE_DW: ... launched behind the NEXT edge transition's fused backward (beside that block's
+                                      # node-level phase) instead of at the end of its own block (in front of that full-chip kernel)
     node_dw_blocks: int = 0           # FD_NODE_DW_BLOCKS: its persistent blocks (0 = 512: two per CU)
     ln_fold: bool = True              # FD_LN_FOLD: sampling -- the sequence transformer's LayerNorms inside the GEMM launches that
                                       # consume them (fd_ln_gemm) instead of launches of their own
@@ -101,7 +103,7 @@ class Options:
             flash_ipa_hpb=_int("FD_IPA_FLASH_HPB", 0), flash_ipa_bwd=_flag("FD_IPA_FLASH_BWD", True),
             proj_merge=_flag("FD_PROJ_MERGE", True),
             fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),
-            grouped_node_dw=_flag("FD_NODE_DW", True), node_dw_blocks=_int("FD_NODE_DW_BLOCKS", 0),
+            grouped_node_dw=_flag("FD_NODE_DW", True), defer_node_dw=_flag("FD_DEFER_NODE_DW", True), node_dw_blocks=_int("FD_NODE_DW_BLOCKS", 0),
             ln_fold=_flag("FD_LN_FOLD", True),
             sampler_device_steps=_flag("FD_SAMPLER_DEVICE_STEPS", True), merge_skip_embed=_flag("FD_MERGE_SKIP", True), graph_fork=_flag("FD_GRAPH_FORK", False),
             zero_arena=_flag("FD_ZERO_ARENA", True), dx_splitk=_flag("FD_DX_SPLITK", True))

@@ -171,7 +171,7 @@ def edge_transition_fwd_unfused(P, b, n3, z, emask, B, N):
     return z2, dict(n3=n3, z=z, e=e, h1=h1, h2=h2, y=y, mean=mean, rstd=rstd, emask=emask, B=B, N=N)
 
 
-def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3, dzb_next=None):
+def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3, dzb_next=None, flush_behind_launch=False):
     """dz2 [P,128] (gradient of the transition's output; None when dzb_next carries all of it) -> dz [P,128] (=), dn3 (+=).
     dzb_next = (dzb [P,40], W40 [40,128]) of the IPA block BEHIND this transition: its pair-projection term dzb W40 still has
     to be added to dz2 (the fused backward kernel does it in its prologue; the other paths through fd_ipa_dz_acc here)."""
@@ -211,7 +211,16 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3, dzb_next=None):
                      ln_rstd=sv["rstd"], ln_gamma=P[f"{pre}.layer_norm.weight"], ln_rowscale=sv["emask"], dy_out=dy,
                      ln_dgamma=G[f"{pre}.layer_norm.weight"], ln_dbeta=G[f"{pre}.layer_norm.bias"],
                      dzb=dzb_next[0] if dzb_next is not None else None, **gk)
+        if flush_behind_launch:
+            # the grouped node-level weight gradients of the block BEHIND this transition (queued by the previous iteration of
+            # trunk._backward) go to the side stream HERE, behind the full-chip kernel just issued: their launch then shares the
+            # chip with this block's latency-bound node-level kernels -- flushed at the end of their own block they stood, on
+            # every CU, in front of this kernel (0.2-0.25 ms per block in profiles/r05_step_gap.txt: the 4-byte memset that
+            # zeroes the tile counter waited 200 us for a CU)
+            ops.flush_dw()
     else:
+        if flush_behind_launch:
+            ops.flush_dw()
         ops.layernorm_bwd(mv(dz2), mv(sv["y"]), P[f"{pre}.layer_norm.weight"], sv["mean"], sv["rstd"], mv(dy), Pn, CZ,
                           rowscale=sv["emask"], dgamma=G[f"{pre}.layer_norm.weight"], dbeta=G[f"{pre}.layer_norm.bias"])
     # y = Wf h2 + Wf[:, :128] z + Pf_i + Qf_j (+bf inside Qf)
@@ -596,6 +605,7 @@ def backward(P, G, sv, d_out, on_done=None):
     nb-1 ... 0, then "embed" -- so a data-parallel caller can start that group's all-reduce under the rest of the
     backward pass (dist.OverlapAllReduce)."""
     notify = on_done if on_done is not None else (lambda tag: None)
+    hooked = on_done is not None
     B, N, nb = sv["B"], sv["N"], sv["num_blocks"]
     R, Pn = B * N, B * N * N
     f = sv["feats"]
@@ -607,13 +617,13 @@ def backward(P, G, sv, d_out, on_done=None):
     ops.reset_dw_queue()        # nothing an interrupted earlier pass queued may leak into this one's gradients
     try:
         with ops.zero_arena(R * (nb * 2048 + 1024) + 65536 if opts.zero_arena else 0, dev):
-            _backward(P, G, sv, d_out, notify)
+            _backward(P, G, sv, d_out, notify, hooked)
     except BaseException:
         ops.reset_dw_queue()
         raise
 
 
-def _backward(P, G, sv, d_out, notify):
+def _backward(P, G, sv, d_out, notify, hooked=False):
     B, N, nb = sv["B"], sv["N"], sv["num_blocks"]
     R, Pn = B * N, B * N * N
     f = sv["feats"]
@@ -626,6 +636,8 @@ def _backward(P, G, sv, d_out, notify):
     notify("heads")
     dinit = zeros((R, CS), dev)
     dz = None
+    # (a data-parallel caller's on_done hook needs every gradient launch of a group ISSUED when it fires: no deferral then)
+    defer_dw = bool(opts.defer_node_dw and not hooked)
     pend = None     # (dzb, W40) of the IPA block just processed whose term dz += dzb W40 the next consumer still has to add
     for b in reversed(range(nb)):
         st = sv["stages"][b]
@@ -634,7 +646,7 @@ def _backward(P, G, sv, d_out, notify):
         if st["et"] is not None:
             dz_in = empty((Pn, CZ), dev)
             with rng(f"edge_transition_{b}.bwd"):
-                edge_transition_bwd(P, G, b, st["et"], dz, dz_in, dn3, dzb_next=pend)
+                edge_transition_bwd(P, G, b, st["et"], dz, dz_in, dn3, dzb_next=pend, flush_behind_launch=defer_dw)
             pend = None
         dframe = zeros((R, 12), dev)
         # IPA backward needs dx1, which needs dn3 complete (incl. bb_update's contribution), but bb_update's
@@ -664,7 +676,10 @@ def _backward(P, G, sv, d_out, notify):
         # fold the IPA frame gradients (dL/dR, dL/dt of the block's input frame) into (dq, dt)
         _frame_grad_fold(st["bb"]["quat"], dframe, dq_in, dt_in, R)
         dq, dt, dnode, dz = dq_in, dt_in, ds, dz_in
-        ops.flush_dw()           # every node-level weight gradient of the block in one launch on the side stream
+        # every node-level weight gradient of the block in one launch on the side stream: now -- or (defer_dw) behind the fused
+        # backward of the NEXT edge transition, i.e. beside that block's node-level phase instead of in front of its full-chip kernel
+        if not (defer_dw and b > 0 and sv["stages"][b - 1]["et"] is not None):
+            ops.flush_dw()
         notify(b)
     # node = init_node at block 0 input; both carry gradient into the node embedder
     ops.add_view(mv(dnode), mv(dinit), R, CS)

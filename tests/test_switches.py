@@ -58,6 +58,7 @@ GROUPS = [
     (dict(zero_arena=False, dx_splitk=False, grad_stream=False), 1e-4),
     (dict(grouped_pair_dw=False), 1e-4),
     (dict(grouped_node_dw=False), 1e-4),
+    (dict(defer_node_dw=False), 1e-4),        # the grouped launch at the end of its own block instead of behind the next fused backward
     (dict(fused_embed_bwd=False), 1e-4),
     (dict(zb_from_edge=False), 1e-4),
     (dict(packed_gates=False), 1e-4),
@@ -97,7 +98,7 @@ def test_switches_emu(use_emu):
 def test_switches_two_blocks_emu(use_emu):
     # with an edge transition between the blocks: the fused LayerNorm-backward / dzb W40 prologue against the separate kernels
     _compare("cpu", B=1, N=8, blocks=2, groups=[_group("flash_ipa_bwd"), _group("packed_gates"), _group("edge_dynamic_tiles"),
-                                                _group("edge_shape"), _group("fused_ln_bwd")])
+                                                _group("edge_shape"), _group("fused_ln_bwd"), _group("defer_node_dw")])
 
 
 def _dynamic_vs_static(dev, B, N, blocks):

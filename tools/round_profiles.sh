@@ -3,7 +3,7 @@
 #   whole-step HBM traffic, full 500-step sampling runs.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/${1:-r04}
+O=gpurun_out/${1:-r05}
 rm -rf $O; mkdir -p $O
 timeout 120 python -m pytest tests/test_switches.py -x -q -m gpu > $O/test_switches.log 2>&1
 python bench.py > $O/bench_train.json 2> $O/bench_train.err
@@ -28,7 +28,7 @@ python tools/kernel_stats_md.py $O/ks/p_kernel_stats.csv "sampling N=128 B=1, 10
 rocprofv3 --kernel-trace --stats -d $O/ks5 -o p --output-format csv -- python bench.py --mode sample --n-res 512 --batch 8 --num-t 12 --steps 1 --warmup 0 --no-graph > $O/ks5.log 2>&1
 python tools/kernel_stats_md.py $O/ks5/p_kernel_stats.csv "sampling N=512 B=8, 12 steps, eager launches" > $O/sample_n512_b8_kernel_stats.md
 if [ -z "$LITE" ]; then   # (LITE=1: the counter passes are skipped -- kernels unchanged since the last full run)
-bash tools/pmc_roofline.sh ${1:-r04} > $O/pmc_roofline.txt 2>&1      # HBM bytes per kernel of the step, calibrated -> bench.py
+bash tools/pmc_roofline.sh ${1:-r05} > $O/pmc_roofline.txt 2>&1      # HBM bytes per kernel of the step, calibrated -> bench.py
 bash tools/pmc_step_sq.sh > $O/pmc_step_sq.txt 2>&1                   # SQ / LDS / clock counters of the big kernels IN the step
 fi
 bash tools/prof_gap.sh > $O/step_gap.txt 2>&1
