@@ -219,6 +219,55 @@ def test_forward_marginal_batch_emu(diff, use_emu):
     _fm_batch(diff, "cpu")
 
 
+GL = np.load(os.path.join(ROOT, "tests", "golden", "diffuser_large.npz"))
+
+
+def _large(diff, dev):
+    """The diffuser kernels at shipped sizes against the unmodified reference (fixture diffuser_large.npz, written by
+    oracle/make_golden_diffuser_large.py: B=3 x N=300 reverse steps with fixed residues at dt = 1/500, a 700-residue prior draw,
+    an N=300 forward marginal); the reference's numpy draws are re-created from the stored seeds in its call order (rotation
+    first, then translation: se3_diffuser.py:213-262)."""
+    from se3_diffusion_amd import hip
+    from oracle.make_golden_diffuser_large import inputs
+    x = inputs()
+    B, N = x["B"], x["N"]
+    for tag in ("a", "b"):
+        np.random.seed(int(GL[f"rev_{tag}_seed"]))
+        z_rot, z_trans = np.random.normal(size=(B, N, 3)), np.random.normal(size=(B, N, 3))
+        out = diff.reverse_device(x["rig"].to(dev), x["rot_score"], x["trans_score"], float(GL[f"rev_{tag}_t"]), 1 / 500,
+                                  diffuse_mask=x["dmask"], center=True, noise_scale=float(GL[f"rev_{tag}_ns"]),
+                                  noise=(z_rot, z_trans)).cpu().numpy()
+        ref = GL[f"rev_{tag}_out_t7"]
+        assert np.abs(rotmats(out) - rotmats(ref)).max() < 3e-6 and np.abs(out[..., 4:] - ref[..., 4:]).max() < 5e-5, tag
+    n = int(GL["sr_n"])
+    np.random.seed(int(GL["sr_seed"]))
+    draws = (np.random.randn(n, 3), np.random.rand(n), np.random.normal(size=(n, 3)))
+    t7 = diff.sample_ref_device(n, dev, noise=draws).cpu().numpy()
+    assert np.abs(rotmats(t7) - rotmats(GL["sr_out_t7"])).max() < 3e-6 and np.abs(t7[..., 4:] - GL["sr_out_t7"][..., 4:]).max() < 5e-5
+    so3, r3 = diff._so3_diffuser, diff._r3_diffuser
+    t = float(GL["fm_t"])
+    np.random.seed(int(GL["fm_seed"]))
+    fz = (np.random.randn(N, 3), np.random.rand(N), np.random.normal(size=(N, 3)))
+    cdf, omega = so3.device_tables(dev)
+    idx = int(so3.t_to_idx(t))
+    r0 = x["rig0"].to(dev)
+    rt = torch.empty_like(r0)
+    rs = torch.empty((N, 3), dtype=torch.float64, device=dev)
+    tsc = torch.empty((N, 3), dtype=torch.float64, device=dev)
+    f64 = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
+    hip.get_lib().call("fd_forward_marginal", r0, f64(fz[0]), f64(fz[1]), f64(fz[2]), (cdf, idx * cdf.shape[1]), omega,
+                       omega.numel(), None, float(so3.discrete_sigma[idx]), float(r3.marginal_b_t(t)), 0.1, 1000, None, rt, rs, tsc, N)
+    got = rt.cpu().numpy()
+    assert np.abs(rotmats(got) - rotmats(GL["fm_rigids_t"])).max() < 3e-6
+    assert np.abs(got[..., 4:] - GL["fm_rigids_t"][..., 4:]).max() < 5e-5
+    assert np.allclose(tsc.cpu().numpy(), GL["fm_trans_score"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(rs.cpu().numpy(), GL["fm_rot_score"], rtol=1e-6, atol=1e-8)
+
+
+def test_diffuser_kernels_large_emu(diff, use_emu):
+    _large(diff, "cpu")
+
+
 def test_igso3_tables_kernel_emu(diff, use_emu):
     """fd_igso3_tables on a sub-grid vs the cached full tables."""
     from se3_diffusion_amd import hip
@@ -241,6 +290,7 @@ def test_diffuser_kernels_gpu(hip_lib, tmp_path):
     _check_sample_ref(d.sample_ref_device(11, "cuda", noise=(G["sr_randn"], G["sr_rand"], G["sr_normal"])).cpu().numpy())
     _fm_kernel(d, "cuda")
     _fm_batch(d, "cuda")
+    _large(d, "cuda")
     np.random.seed(55)
     _check_fm(d.forward_marginal(ru.Rigid.from_tensor_7(torch.tensor(G["fm_rigids0"]).cuda()), float(G["fm_t"])))
     np.random.seed(123)
