@@ -42,8 +42,11 @@ MODES = ("shipped", "persistent", "exact_f32")
 TOL_LOSS = 1e-4
 # 50 chained steps: measured 1.4e-5 (rotation matrices), 1.2e-4 A (translations), 1e-6 (psi), eager and graph-replayed alike
 TOL_TRAJ50 = (1.5e-4, 1.5e-3, 1e-4)
-# the metric's own schedule (500 steps, dt = 1/500): provisional bounds until the first GPU run records what is achieved
-TOL_TRAJ500 = (1.5e-3, 1.5e-2, 1e-3)
+# the metric's own schedule (500 steps, dt = 1/500): 499 chained reverse steps stay within 1.6e-5 (rotation matrices) / 1.4e-4 A
+# (translations); the LAST step is the network's own frame prediction (train_se3_diffusion.py:778-780), a forward that amplifies a
+# perturbation of its input frames 6-8 x: measured 1.4e-3 / 1.6e-3 A there (6 of 128 residues above 1e-4, median 1e-5), psi 6.4e-5;
+# eager = graph-replayed (profiles/r05_traj500_error_growth.txt, tools/probes/traj500_probe.py)
+TOL_TRAJ500 = (5e-3, 1.5e-2, 6e-4)
 TOL_GSIG = 2e-3       # gradient signatures (sum, norm) of the reference's large tensors
 
 
@@ -368,9 +371,9 @@ def _trajectory(fixture, use_graph, tol_rot=4e-4, tol_trans=9e-3, tol_psi=1e-4):
         parity_log.out("psi_abs", ep)
         assert ep < tol_psi
         if len(growth) > 8:
+            pick = sorted({0, 4, 9, 24, len(growth) // 2, (3 * len(growth)) // 4, (9 * len(growth)) // 10, len(growth) - 2, len(growth) - 1})
             print(f"[parity] {fixture} graph={use_graph}: (rot, trans A) error at compared steps "
-                  f"{[step_index[j] + 1 for j in (0, 4, 9, 24, len(growth) - 1) if j < len(growth)]}: "
-                  f"{[growth[j] for j in (0, 4, 9, 24, len(growth) - 1) if j < len(growth)]}")
+                  f"{[step_index[j] + 1 for j in pick if j < len(growth)]}: {[growth[j] for j in pick if j < len(growth)]}")
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
