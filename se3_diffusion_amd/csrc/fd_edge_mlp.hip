@@ -41,9 +41,9 @@
 //                               per MFMA and one weight stream per CU instead of two (half the L2 -> LDS traffic): -5 ... -8 % per
 //                               launch from 65,536 pair rows up (profiles/r04_edge_variants_*.log)
 // (that file defines EM_SHAPE_W8 + the shape macros and includes this one; the pack kernels and the C entry points live here only)
-// Shape history (4 waves x 32 rows on 32x32x16, deeper rings, stepped per-residue terms, non-temporal saves, lumped saves): DESIGN.md
+// Shape history (4 waves x 32 rows on 32x32x16, deeper rings, stepped per-residue terms, lumped saves): DESIGN.md
 // section 6 -- the variants that lost are no longer in this source.
-#if defined(EM_PHASE_TIMING) || defined(EM_ABLATE_PQ)
+#if defined(EM_PHASE_TIMING) || defined(EM_ABLATE_PQ) || defined(EM_PLAIN_SAVES)
 #include "fd_probe.h"      // timing / ablation hooks: tools/probes builds only (-DFD_PROBE_BUILD)
 #endif
 #include "fd_common.h"
@@ -70,6 +70,17 @@ constexpr int EM_ZB = 40;
 // in rounds 2 and 4: no gain on the one-block-per-CU shape, and 144 KB per CU cost the step its overlap with the gradient stream)
 constexpr int EM_RING = 2;
 constexpr int EM_H = 384, EM_C = 128;
+// The training saves (h1 / h2z forward, d2 / d1 backward: 3 KB per pair row that only the weight-gradient launch reads, much later)
+// are stored with the NON-TEMPORAL hint (round 5): plain stores pushed the input rows that the forward re-reads per k-step out of the
+// XCD's L2.  Same box, variant libraries swapped (profiles/r05_ab.txt): training forward launch 1.60-1.62 against 1.69-1.80 ms,
+// average fused launch of the step 1.310 against 1.346 ms, training step 21.65 against 21.85 ms.  The other outputs (y, dy, z', dz)
+// measured the same with either policy and keep plain stores.  (Rounds 2 and 4 tried the hint when nothing was re-read: neutral.)
+// -DEM_PLAIN_SAVES (probe build) restores the plain stores for that A/B.
+#ifdef EM_PLAIN_SAVES
+#define EM_SAVE4(p, a, b, c, e) (*reinterpret_cast<float4*>(p) = make_float4((a), (b), (c), (e)))
+#else
+#define EM_SAVE4(p, a, b, c, e) fd::store_nt4((p), (a), (b), (c), (e))
+#endif
 
 // Probe build only (tools/probes/edge_phases.py compiles this file with -DEM_PHASE_TIMING into its own library): wave-level
 // cycle counts per phase of a tile, read with s_memtime at stage boundaries (where no LDS read is outstanding) and summed over
@@ -513,8 +524,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
             if (TRAIN && rok) {
 #pragma unroll
               for (int i = 0; i < 2; ++i)
-                *reinterpret_cast<float4*>(d.save1 + row * EM_H + 128 * hc + 16 * (2 * ks + i) + 4 * g) =
-                    make_float4(t[i][0], t[i][1], t[i][2], t[i][3]);
+                EM_SAVE4(d.save1 + row * EM_H + 128 * hc + 16 * (2 * ks + i) + 4 * g, t[i][0], t[i][1], t[i][2], t[i][3]);
             }
           }
           em16_mma_half(acc2[a], acc2[a + 1], H[hh & 1], b);
@@ -567,8 +577,8 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_mlp16_kernel(FdEdgeMlpD
           if (TRAIN && rok) {      // the save of h2 + [z | 0 | 0] / d1, two blocks per k-step of layer 3
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-              *reinterpret_cast<float4*>(d.save2 + row * EM_H + 16 * (2 * ks + i) + 4 * g) =
-                  make_float4(acc2[2 * ks + i][0], acc2[2 * ks + i][1], acc2[2 * ks + i][2], acc2[2 * ks + i][3]);
+              EM_SAVE4(d.save2 + row * EM_H + 16 * (2 * ks + i) + 4 * g, acc2[2 * ks + i][0], acc2[2 * ks + i][1], acc2[2 * ks + i][2],
+                       acc2[2 * ks + i][3]);
           }
         }
         em16_mma_half(acc3[a], acc3[a + 1], H[hh & 1], b);

@@ -1,4 +1,4 @@
-// Gate for the timing / ablation hooks of the product kernel sources (EM_PHASE_TIMING, EM_ABLATE_PQ in fd_edge_mlp.hip; the FL_ABL_*
+// Gate for the timing / ablation hooks of the product kernel sources (EM_PHASE_TIMING, EM_ABLATE_PQ, EM_PLAIN_SAVES in fd_edge_mlp.hip; the FL_ABL_*
 // hooks of fd_ipa_flash.hip).  Several of them produce WRONG RESULTS BY DESIGN (a fetch replaced by a constant, a phase skipped) so
 // that its cost can be read off a timing: they exist for tools/probes/* only.  A source that sees one of those macros includes this
 // header, and this header refuses to compile unless the build says explicitly that it is a probe build -- a stray or mistyped -D in a
