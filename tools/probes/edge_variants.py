@@ -35,7 +35,8 @@ def lib_path(tag):
 def build_all():
     build.build(verbose=False)
     # both shapes of the kernel (fd_edge_mlp.hip = 4 waves, fd_edge_mlp_w8.hip = 8 waves) are recompiled under the variant's flags
-    names = ("fd_edge_mlp", "fd_edge_mlp_w8")
+    # (EDGE_VARIANTS_SOURCES="fd_pair_dw,...": the variant's flags go to those sources instead -- step-level A/Bs of other kernels)
+    names = tuple(os.environ.get("EDGE_VARIANTS_SOURCES", "fd_edge_mlp,fd_edge_mlp_w8").split(","))
     others = [os.path.join(build.OBJ, f) for f in sorted(os.listdir(build.OBJ)) if f.endswith(".o") and f[:-2] not in names]
     for tag, flags in VARIANTS.items():
         if not flags:
