@@ -176,10 +176,13 @@ typedef struct FdEdgeMlpDesc {
   unsigned* sched;          /* optional: one word of device scratch -- a launch whose blocks walk four or more 64-row tiles each then
                                hands the tiles out dynamically (one atomic per tile and block); fd_edge_mlp zeroes the word on
                                the launch's stream; the words of launches that may run at the same time must differ */
-  int shape;                /* 0 = by size (8 from FD_EDGE_MLP_W8_MIN_ROWS rows up), 4 = 4 waves x 64-row tiles on two blocks per CU,
-                               8 = 8 waves x 128-row tiles on one block per CU (same results bit for bit) */
+  int shape;                /* 0 = by size (8 from FD_EDGE_MLP_W8_MIN_ROWS rows up; 2 for an inference forward of at most
+                               FD_EDGE_MLP_PAIR_MAX_ROWS rows), 4 = 4 waves x 64-row tiles on two blocks per CU, 8 = 8 waves x 128-row
+                               tiles on one block per CU (4 and 8: same results bit for bit), 2 = two waves per 16-row group, 64-row
+                               tiles on one block per CU (inference forward only; equal to fp32 rounding) */
 } FdEdgeMlpDesc;
 #define FD_EDGE_MLP_W8_MIN_ROWS 65536L
+#define FD_EDGE_MLP_PAIR_MAX_ROWS 16384L   /* 256 CUs x 4 SIMDs x 16 rows: at most one 16-row group per SIMD */
 int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream);
 
 /* ---- edge embedder, fused (model/score_network.py:97-101,129-153 Embedder edge path, data/utils.py:570-580) ----

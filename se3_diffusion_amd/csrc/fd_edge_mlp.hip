@@ -56,6 +56,7 @@
 #endif
 int fd_edge_mlp_launch_w4(const FdEdgeMlpDesc& d, hipStream_t st);
 int fd_edge_mlp_launch_w8(const FdEdgeMlpDesc& d, hipStream_t st);
+int fd_edge_mlp_launch_pair(const FdEdgeMlpDesc& d, hipStream_t st);      // csrc/fd_edge_mlp_pair.hip
 
 namespace {
 
@@ -819,12 +820,18 @@ extern "C" int fd_edge_mlp(const FdEdgeMlpDesc* desc, void* stream) {
   if (d.rows == 0) return FD_OK;
   FD_CHECK_ARG(d.zb_out == nullptr || (fd_aligned16(d.zb_out) && fd_aligned16(d.zb_bias)),
                "fd_edge_mlp: zb_out / zb_bias must be 16-byte aligned (the image must carry the fd_edge_mlp_pack_zb units)");
-  FD_CHECK_ARG(d.shape == 0 || d.shape == 4 || d.shape == 8, "fd_edge_mlp: shape is 0 (by size), 4 or 8 (waves per block)");
+  FD_CHECK_ARG(d.shape == 0 || d.shape == 2 || d.shape == 4 || d.shape == 8,
+               "fd_edge_mlp: shape is 0 (by size), 2 (two waves per 16 rows: inference forward), 4 or 8 (waves per block)");
   // shape by size: the one-block-per-CU shape from two of its 128-row tiles per CU up (measured fwd / fwd + saves / bwd: 16,384 rows
   // 0.088 vs 0.063 ms; 65,536 rows 0.171-0.179 / 0.216-0.240 / 0.196-0.213 vs 0.190-0.193 / 0.225-0.253 / 0.210-0.231 ms; 458,752 rows
-  // 1.21 / 1.42 / 1.33 vs 1.23 / 1.66 / 1.47 ms; profiles/r04_edge_variants_*)
-  const int shape = d.shape != 0 ? d.shape : (d.rows >= FD_EDGE_MLP_W8_MIN_ROWS ? 8 : 4);
+  // 1.21 / 1.42 / 1.33 vs 1.23 / 1.66 / 1.47 ms; profiles/r04_edge_variants_*); an inference forward that gives a SIMD at most one
+  // 16-row group (a lone backbone of N <= 128) takes the column-split kernel: two waves per group (fd_edge_mlp_pair.hip)
+  const bool pair_ok = !d.backward && d.save1 == nullptr;
+  FD_CHECK_ARG(d.shape != 2 || pair_ok, "fd_edge_mlp: shape 2 is an inference forward (no backward, no training saves)");
+  const int shape = d.shape != 0 ? d.shape
+                                 : (d.rows >= FD_EDGE_MLP_W8_MIN_ROWS ? 8 : (pair_ok && d.rows <= FD_EDGE_MLP_PAIR_MAX_ROWS ? 2 : 4));
   hipStream_t st = (hipStream_t)stream;
+  if (shape == 2) return fd_edge_mlp_launch_pair(d, st);
   return shape == 8 ? fd_edge_mlp_launch_w8(d, st) : fd_edge_mlp_launch_w4(d, st);
 }
 #endif  // !EM_SHAPE_W8

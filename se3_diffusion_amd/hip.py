@@ -94,6 +94,7 @@ class FdEdgeMlpDesc(Structure):
 
 
 EDGE_MLP_W8_MIN_ROWS = 65536
+EDGE_MLP_PAIR_MAX_ROWS = 16384      # include/fd_hip.h FD_EDGE_MLP_PAIR_MAX_ROWS
 EDGE_MLP_IMAGE_BYTES = 124 * 12288
 
 

@@ -500,6 +500,13 @@ def edge_mlp(x, img, out, rows, nres, *, p1=None, q1=None, bias2=None, pf=None, 
     d.rows, d.nres, d.backward, d.eps, d.blocks = int(rows), int(nres), int(bool(backward)), 1e-5, int(blocks or opts.edge_blocks)
     d.ld_pq, d.ld_pqf = int(ld_pq), int(ld_pqf)
     d.shape = int(opts.edge_shape)
+    # shape 2 (two waves per 16-row group, csrc/fd_edge_mlp_pair.hip) exists for the inference forward only: a forced 2 applies to
+    # those launches and leaves the others to the size rule; edge_pair=False keeps the size rule from picking it
+    infer_fwd = not backward and save1 is None
+    if d.shape == 2 and not infer_fwd:
+        d.shape = 0
+    if d.shape == 0 and infer_fwd and not opts.edge_pair and rows <= hip.EDGE_MLP_PAIR_MAX_ROWS:
+        d.shape = 4
     L = lib()
     stream = L._stream(tens)
     # tiles of the shape the entry point will pick: 128 rows on 256 blocks (8 waves, >= EDGE_MLP_W8_MIN_ROWS rows) or 64 rows on 512

@@ -41,7 +41,10 @@ class Options:
     grouped_pair_dw: bool = True      # FD_PAIR_DW: the edge transition's pair-row weight gradients in one grouped launch
     pair_dw_blocks: int = 160         # FD_PAIR_DW_BLOCKS: blocks of fd_pair_dw when it runs beside the main stream (0 = 256)
     edge_blocks: int = 0              # FD_EDGE_BLOCKS: persistent blocks of the fused edge kernels (0 = fill the CUs: 512 / 256)
-    edge_shape: int = 0               # FD_EDGE_SHAPE: 0 = by size, 4 = 4-wave blocks (two per CU), 8 = 8-wave blocks (one per CU)
+    edge_shape: int = 0               # FD_EDGE_SHAPE: 0 = by size, 4 = 4-wave blocks (two per CU), 8 = 8-wave blocks (one per CU),
+                                      # 2 = two waves per 16-row group (inference forward launches only; the others keep the size rule)
+    edge_pair: bool = True            # FD_EDGE_PAIR: sampling -- an edge transition of at most 16,384 pair rows (a lone N <= 128 backbone:
+                                      # one 16-row group per SIMD) on the column-split kernel, two waves per group (fd_edge_mlp_pair.hip)
     edge_dynamic_tiles: bool = True   # FD_EDGE_DYN_TILES: a fused edge launch with more tiles than blocks hands them out dynamically
     packed_gates: bool = True         # FD_PACKED_GATES: the fused edge EMBEDDER's backward gates on packed sign bits instead of reading h1 / h2
                                       # (the edge transition's always does: its h2 save carries the residual z)
@@ -93,7 +96,7 @@ class Options:
             fused_edge=_flag("FD_EDGE_FUSED", True), fused_embed=_flag("FD_EMBED_FUSED", True),
             fused_embed_bwd=_flag("FD_EMBED_BWD_FUSED", True),
             grouped_pair_dw=_flag("FD_PAIR_DW", True), pair_dw_blocks=_int("FD_PAIR_DW_BLOCKS", 160),
-            edge_blocks=_int("FD_EDGE_BLOCKS", 0), edge_shape=_int("FD_EDGE_SHAPE", 0), zb_from_edge=_flag("FD_ZB_FUSED", True),
+            edge_blocks=_int("FD_EDGE_BLOCKS", 0), edge_shape=_int("FD_EDGE_SHAPE", 0), edge_pair=_flag("FD_EDGE_PAIR", True), zb_from_edge=_flag("FD_ZB_FUSED", True),
             fused_ln_bwd=_flag("FD_EDGE_LN_BWD", True), edge_dynamic_tiles=_flag("FD_EDGE_DYN_TILES", True), packed_gates=_flag("FD_PACKED_GATES", True),
             fold_node_terms=_flag("FD_FOLD_NODE_TERMS", True),
             fused_ipa_attn=_flag("FD_IPA_ATTN_FUSED", True),

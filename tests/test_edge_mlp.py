@@ -41,6 +41,13 @@ def rel(a, b):
 
 
 def _run(dev, B, N, seed=0, blocks=0):
+    # (the checks below compare the inference forward with the training forward bit for bit: the 16-rows-per-wave shapes; the
+    #  column-split kernel small inference launches take by default has its own test, _pair)
+    with options.override(edge_pair=False):
+        _run_16(dev, B, N, seed, blocks)
+
+
+def _run_16(dev, B, N, seed=0, blocks=0):
     t = _case(dev, B, N, seed)
     P = B * N * N
     img = ops.edge_mlp_pack(t["W1"], t["W2"], t["Wf"])
@@ -149,6 +156,53 @@ def _same_in_both_shapes(dev, B, N, seed, blocks):
         res.append(o)
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]), k
+
+
+def _pair(dev, B, N, seed, blocks=0):
+    """the column-split kernel (csrc/fd_edge_mlp_pair.hip: two waves per 16-row group, inference forward): z' and zb against the
+    float64 restatement (the tolerances of the 16-row kernels) and against the 4-wave shape (same products, the halves of layer 3 /
+    LayerNorm / zb added in another order: fp32 rounding); what the size rule picks, and edge_pair=False"""
+    t = _case(dev, B, N, seed)
+    P = B * N * N
+    gz = torch.Generator().manual_seed(seed + 100)
+    W40, b40 = (torch.randn(40, 128, generator=gz) * 0.1).to(dev), torch.randn(40, generator=gz).to(dev)
+    imgs = {False: ops.edge_mlp_pack(t["W1"], t["W2"], t["Wf"]), True: ops.edge_mlp_pack(t["W1"], t["W2"], t["Wf"], W40=W40)}
+    rout = _ref_fwd(t, B, N)[3]
+    rzb = rout @ W40.double().cpu().T + b40.double().cpu()
+
+    def go(zbv, **ov):
+        out, zb = torch.full((P, 128), float("nan"), device=dev), torch.full((P, 40), float("nan"), device=dev)
+        with options.override(**ov):
+            ops.edge_mlp(t["z"], imgs[zbv], out, P, N, p1=t["P1"], q1=t["Q1"], bias2=t["b2"], pf=t["Pf"], qf=t["Qf"],
+                         gamma=t["gamma"], beta=t["beta"], rowscale=t["emask"], blocks=blocks,
+                         **(dict(zb_out=zb, zb_bias=b40) if zbv else {}))
+        return out, zb
+
+    for zbv in (False, True):
+        o2, z2 = go(zbv, edge_shape=2)
+        o4, z4 = go(zbv, edge_shape=4)
+        assert rel(o2, rout) < 2e-5, rel(o2, rout)
+        assert rel(o2, o4.double().cpu()) < 3e-6, rel(o2, o4.double().cpu())
+        if zbv:
+            assert rel(z2, rzb) < 2e-5 and rel(z2, z4.double().cpu()) < 3e-6
+        if P <= 16384:
+            oa, za = go(zbv)                      # the size rule: at most one 16-row group per SIMD -> the column-split kernel
+            assert torch.equal(oa, o2) and (not zbv or torch.equal(za, z2))
+            ob, zbb = go(zbv, edge_pair=False)
+            assert torch.equal(ob, o4) and (not zbv or torch.equal(zbb, z4))
+
+
+def test_edge_mlp_pair_emu(use_emu):
+    _pair("cpu", B=1, N=12, seed=11)               # 144 rows: two full 64-row tiles + a ragged one
+    _pair("cpu", B=1, N=17, seed=12, blocks=1)     # 289 rows: five tiles walked by one block
+
+
+@pytest.mark.gpu
+def test_edge_mlp_pair_gpu(hip_lib):
+    _pair("cuda", B=1, N=12, seed=11)
+    _pair("cuda", B=1, N=128, seed=13)             # 16,384 rows: the lone backbone the kernel exists for, one tile per block
+    _pair("cuda", B=1, N=67, seed=14, blocks=5)    # ragged tail, several tiles per block
+    _pair("cuda", B=2, N=128, seed=15)             # above the size rule's bound: forced, two tiles per block
 
 
 def test_edge_mlp_emu(use_emu):

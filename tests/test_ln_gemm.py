@@ -101,6 +101,11 @@ def _fold_vs_launches(dev, B, N, blocks):
     for k in a:
         assert float((c[k] - d[k]).abs().max()) <= 2e-6 * float(d[k].abs().max() + 1e-3), k
         assert float((c[k] - b[k]).abs().max()) <= 2e-5 * float(b[k].abs().max() + 1e-3), k
+    # the edge transitions of a lone backbone (<= 16,384 pair rows) run on the column-split kernel (options.edge_pair,
+    # csrc/fd_edge_mlp_pair.hip): the network's outputs against the 4-wave shape it replaces
+    e = _infer(dev, B, N, blocks, static_cache=True, edge_pair=False)
+    for k in a:
+        assert float((c[k] - e[k]).abs().max()) <= 2e-5 * float(e[k].abs().max() + 1e-3), k
 
 
 def test_inference_fold_vs_layernorm_launches_emu(use_emu):

@@ -41,7 +41,9 @@ def main():
     else:
         L = ctypes.CDLL(build_probe())
     dev = "cuda"
-    B, N = 30, 128
+    # (--b / --n: the launch's size; below 65,536 pair rows the 4-wave shape -- the instrumented source -- runs, e.g. --b 1: a lone backbone)
+    B = int(sys.argv[sys.argv.index("--b") + 1]) if "--b" in sys.argv else 30
+    N = int(sys.argv[sys.argv.index("--n") + 1]) if "--n" in sys.argv else 128
     R, P = B * N, B * N * N
     g = torch.Generator(device=dev).manual_seed(0)
     rn = lambda *s, sc=1.0: torch.randn(*s, device=dev, generator=g) * sc
@@ -72,10 +74,11 @@ def main():
     cases = {
         "forward, inference (no saves)": desc(x=z, img=img, out=out, p1=P1, q1=Q1, bias2=b2, pf=Pf, qf=Qf, gamma=gm, beta=bt,
                                                rowscale=emask),
-        # (the variant that also writes the packed gate masks is not instrumented: see EM_TICK_TO)
+        "forward, inference + zb (sampling)": desc(x=z, img=img, out=out, p1=P1, q1=Q1, bias2=b2, pf=Pf, qf=Qf, gamma=gm, beta=bt,
+                                                    rowscale=emask, zb_out=zb, zb_bias=b40),
         "forward, training (saves + zb)": desc(x=z, img=img, out=out, p1=P1, q1=Q1, bias2=b2, pf=Pf, qf=Qf, gamma=gm, beta=bt,
                                                rowscale=emask, save1=h1, save2=h2, y=y, mean=mean, rstd=rstd, zb_out=zb,
-                                               zb_bias=b40),
+                                               zb_bias=b40, mask1=mh1, mask2=mh2),
         "backward (packed gates, saves)": desc(x=y, img=imgT, out=dz, gmask1=mh2, gmask2=mh1, save1=d2, save2=d1, backward=1),
         "backward, fused LN + dzb prologue": desc(x=up, img=imgB, out=dz, gmask1=mh2, gmask2=mh1, save1=d2, save2=d1, backward=1,
                                                   ln_y=y, ln_mean=mean, ln_rstd=rstd, ln_gamma=gm, ln_rowscale=emask, dy_out=dy,
