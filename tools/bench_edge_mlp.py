@@ -54,7 +54,11 @@ def main():
         kw = dict(p1=P1, q1=Q1, bias2=b2, pf=Pf, qf=Qf, gamma=gm, beta=bt, rowscale=emask, blocks=a.blocks)
         t_inf = timeit(lambda: ops.edge_mlp(z, img, out, Pn, N, **kw))
         if a.fwd_only:
-            print(f"B={B} N={N}: fused fwd(no save) {t_inf:.3f} ms ({flops / t_inf / 1e9:.0f} TF)")
+            # + the sampling variant: with the next IPA block's zb as a fourth layer
+            W40s, b40s = torch.randn(40, 128, device=dev, generator=g) * 0.1, torch.randn(40, device=dev, generator=g)
+            img4s, zbs = ops.edge_mlp_pack(W1, W2, Wf, W40=W40s), e(Pn, 40)
+            t_zb = timeit(lambda: ops.edge_mlp(z, img4s, out, Pn, N, zb_out=zbs, zb_bias=b40s, **kw))
+            print(f"B={B} N={N}: fused fwd(no save) {t_inf:.3f} ms ({flops / t_inf / 1e9:.0f} TF)   with zb {t_zb:.3f} ms")
             continue
         if a.lnb:
             mh1 = torch.zeros(Pn, 12, dtype=torch.int32, device=dev); mh2 = torch.zeros(Pn, 12, dtype=torch.int32, device=dev)
