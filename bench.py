@@ -635,7 +635,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    if os.environ.get("FD_BENCH_STEP_TRACE"):
+        sys.stderr.write("per-step ms (HIP events, in order): " + " ".join(f"{x:.2f}" for x in per_step) + "\n")
+    per_step = sorted(per_step)
     if os.environ.get("FD_BENCH_ENQUEUE"):
         # host-side cost of a step: time inside step() with the GPU running asynchronously behind it.  If it is close to
         # ms_per_step the launch stream, not the GPU, bounds the step.
