@@ -25,6 +25,24 @@ def _run(dev):
     C = nan(384, 128)
     ops.pair_dw([dict(A=(z(1, 384), 0, 384), B=(z(1, 128), 0, 128), C=(C, 0, 128))], 0)
     assert torch.isnan(C).all()
+    # fused edge transition: rows = 0 in every shape (2 = the column-split inference kernel, 4, 8), and the shapes' argument errors
+    from se3_diffusion_amd import hip, options
+    img = ops.edge_mlp_pack(z(384, 384), z(384, 384), z(128, 384))
+    for shape in (0, 2, 4, 8):
+        eo = nan(1, 128)
+        with options.override(edge_shape=shape):
+            ops.edge_mlp(z(1, 128), img, eo, 0, 1, p1=z(1, 384), q1=z(1, 384), bias2=z(384), pf=z(1, 128), qf=z(1, 128), gamma=z(128),
+                         beta=z(128))
+        assert torch.isnan(eo).all()
+    d = hip.FdEdgeMlpDesc()
+    for k, t in dict(x=z(1, 128), img=img, out=nan(1, 128), gmask1=z(1, 12).int(), gmask2=z(1, 12).int(), save1=nan(1, 384),
+                     save2=nan(1, 384)).items():
+        setattr(d, k, t.data_ptr())
+    d.rows, d.nres, d.backward, d.eps, d.shape = 1, 1, 1, 1e-5, 2
+    assert L.cdll.fd_edge_mlp(hip.ctypes.byref(d), None) != 0          # shape 2 is an inference forward
+    assert "shape 2" in L.cdll.fd_last_error().decode()
+    d.shape = 3
+    assert L.cdll.fd_edge_mlp(hip.ctypes.byref(d), None) != 0 and "shape is 0" in L.cdll.fd_last_error().decode()
     # IPA attention / sequence attention: B = 0
     S, feats = nan(1, 8, 1, 1), nan(1, 2688)
     L.call("fd_ipa_attn_fwd", S, z(1, 40), z(1, 8, 24), z(1, 8, 24), None, z(8), z(1), feats, 0, 1)
