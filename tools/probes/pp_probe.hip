@@ -58,7 +58,9 @@ __device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
 
 // MODE 0: MFMA only.  MODE 1: lockstep (other(u); barrier; mfma(u); barrier -- all 8 waves the same).  MODE 2: ping-pong (second
 // wave of every SIMD delayed by one interval).  MODE 3: free-running -- the shipped structure's order (reads of the next unit in
-// front of the current unit's MFMAs, one barrier per unit) with 8 waves in one block.
+// front of the current unit's MFMAs, one barrier per unit) with 8 waves in one block.  MODE 4 (round 5): mode 3 with the COLUMN SPLIT at full
+// size -- a wave owns 32 rows x half the columns: per unit it reads its half-unit (6 ds_read_b128 instead of 12) and feeds every
+// fragment to two MFMAs (two 16-row tiles), two activation splits every sixth unit: what halving the fragment reads per MFMA buys.
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void k(const char* __restrict__ img, float* __restrict__ out, int tiles) {
   __shared__ __attribute__((aligned(16))) char ring[RING * UNIT];
@@ -71,8 +73,9 @@ __global__ __launch_bounds__(512, 2) void k(const char* __restrict__ img, float*
   float x[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) x[e] = 0.01f * (lane + e) + 0.5f;
-  uint4 b[3], H[12];
+  uint4 b[3], b2[3], H[12];
   split8(x, b[0], b[1], b[2]);
+  split8(x, b2[0], b2[1], b2[2]);
   const int total = tiles * NUNITS;
   // pieces of unit u issued by this wave: piece p by wave p % 8 (waves 0..3: two pieces, waves 4..7: one)
   int iu = 0, islot = 0, isrc = 0;        // next unit to copy, its ring slot, its index in the image
@@ -101,6 +104,22 @@ __global__ __launch_bounds__(512, 2) void k(const char* __restrict__ img, float*
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) acc[a0 + nb] = mfma(H[3 * nb + PW[p]], b[PX[p]], acc[a0 + nb]);
   };
+  auto read_half = [&]() __attribute__((always_inline)) {
+    const char* s = ring + rslot * UNIT + ((wave & 1) * 6) * PIECE + lane * 16;
+    rslot = rslot + 1 == RING ? 0 : rslot + 1;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) H[i] = *reinterpret_cast<const uint4*>(s + i * PIECE);
+  };
+  auto mma_half2 = [&](int a0) __attribute__((always_inline)) {
+    constexpr int PW[6] = {2, 1, 0, 1, 0, 0}, PX[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        acc[a0 + 2 * nb] = mfma(H[3 * nb + PW[p]], b[PX[p]], acc[a0 + 2 * nb]);
+        acc[a0 + 2 * nb + 1] = mfma(H[3 * nb + PW[p]], b2[PX[p]], acc[a0 + 2 * nb + 1]);
+      }
+  };
   if (MODE == 0) {
     issue();
     wait_vm<0>();
@@ -120,11 +139,16 @@ __global__ __launch_bounds__(512, 2) void k(const char* __restrict__ img, float*
       for (int g = 0; g < 6; ++g) {
         // ---- other(u) ----
         pin();
-        read_unit();
+        if (MODE == 4) read_half(); else read_unit();
         if (g == 0) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = acc[e >> 2][e & 3] * 0.5f + x[e] * 0.25f;
           split8(x, b[0], b[1], b[2]);
+          if (MODE == 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = acc[2 + (e >> 2)][e & 3] * 0.5f + x[e] * 0.25f;
+            split8(x, b2[0], b2[1], b2[2]);
+          }
         }
         issue();
         // pieces of unit u + 1 (issued AHEAD - 1 segments ago) have landed; the younger ones stay in flight
@@ -133,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void k(const char* __restrict__ img, float*
         if (MODE == 1 || MODE == 2) __builtin_amdgcn_s_barrier();
         // ---- mfma(u) ----
         pin();
-        mma_unit(4 * g);
+        if (MODE == 4) mma_half2(4 * g); else mma_unit(4 * g);
         pin();
         __builtin_amdgcn_s_barrier();
       }
@@ -155,15 +179,16 @@ int main() {
   for (auto& w : h) { unsigned lo = 0x3c00 | (rand() & 0x80ff), hi = 0x3c00 | (rand() & 0x80ff); w = lo | (hi << 16); }
   hipMemcpy(img, h.data(), NUNITS * UNIT, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const char* names[4] = {"mfma only          ", "lockstep (2 barr)  ", "ping-pong          ", "one barrier / unit "};
+  const char* names[5] = {"mfma only          ", "lockstep (2 barr)  ", "ping-pong          ", "one barrier / unit ", "column split x 2 rt"};
   float ref = 0.f;
-  for (int mode = 0; mode < 4; ++mode) {
+  for (int mode = 0; mode < 5; ++mode) {
     for (int rep = 0; rep < 3; ++rep) {
       hipEventRecord(e0);
       if (mode == 0) k<0><<<blocks, 512>>>(img, out, tiles);
       if (mode == 1) k<1><<<blocks, 512>>>(img, out, tiles);
       if (mode == 2) k<2><<<blocks, 512>>>(img, out, tiles);
       if (mode == 3) k<3><<<blocks, 512>>>(img, out, tiles);
+      if (mode == 4) k<4><<<blocks, 512>>>(img, out, tiles);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); return 1; }
