@@ -21,6 +21,21 @@ def test_binding_covers_header():
     assert header_symbols() == hip.exported_symbols()
 
 
+def test_binding_constants_match_header():
+    """the numeric constants hip.py mirrors (image sizes, item limits, the shape rule's row bounds) are the header's"""
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fd_hip.h")).read()
+    defs = {m.group(1): m.group(2) for m in re.finditer(r"#define (FD_[A-Z0-9_]+)\s+\(?([0-9 *L]+?)\)?\s*(?:/\*.*)?$", hdr, re.M)}
+    val = lambda e: eval(e.replace("L", ""))           # "124 * 12288", "65536L"
+    pairs = {"FD_EDGE_MLP_IMAGE_BYTES": hip.EDGE_MLP_IMAGE_BYTES, "FD_EDGE_MLP_W8_MIN_ROWS": hip.EDGE_MLP_W8_MIN_ROWS,
+             "FD_EDGE_MLP_PAIR_MAX_ROWS": hip.EDGE_MLP_PAIR_MAX_ROWS, "FD_EDGE_EMBED_IMAGE_BYTES": hip.EDGE_EMBED_IMAGE_BYTES,
+             "FD_EDGE_EMBED_BWD_IMAGE_BYTES": hip.EDGE_EMBED_BWD_IMAGE_BYTES, "FD_PAIR_DW_MAX_ITEMS": hip.PAIR_DW_MAX_ITEMS,
+             "FD_GROUP_DW_MAX_ITEMS": hip.GROUP_DW_MAX_ITEMS}
+    for name, py in pairs.items():
+        assert name in defs, name
+        assert val(defs[name]) == py, (name, defs[name], py)
+
+
 def test_product_library_exports_every_symbol():
     if not os.path.exists(hip.LIB_PATH):
         from se3_diffusion_amd import build
