@@ -8,6 +8,11 @@
 // four coalesced dwords (row-contiguous operand); four v_mfma_f32_32x32x2_f32 consume it.  Two groups are kept in
 // flight.  The four partial tiles meet in LDS and every thread finishes one float4 of the tile with the full fused
 // epilogue.  fp32 MFMA: exact fp32 products and sums (the k order differs from the 64x64 kernel's).
+// gemm_direct16_kernel (round 5): the same kernel on 16 x 16 tiles (v_mfma_f32_16x16x4_f32, 16-k groups) for LONG-K products with few
+// tiles.  A 32 x 32 tile of IPA's linear_out on a lone backbone (128 x 256 x 2688: 32 tiles on 256 CUs) is 5.5 MFLOP on one CU's fp32
+// matrix pipe (256 flop/cycle: 9 us) behind a load path in which every float4 instruction touches 32 cache lines -- 22 us per launch,
+// four per forward, and neither a K split over blocks (device-scope fences) nor more waves per tile (same pipe) helped
+// (profiles/r05_gemm_direct_splitk_experiment.txt).  A quarter of the tile per block puts four times as many CUs on the product.
 constexpr int DG = 8;   // k per group
 constexpr int DPF = 8;  // groups in flight per wave
 
@@ -131,6 +136,92 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(GemmArgs g) {
   }
 }
 
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_direct16_kernel(GemmArgs g) {
+  constexpr int NW = 4;                      // waves sharing the tile's K range (eight measured the same or slower: 12.6 / 9.1 / 7.7 us
+                                             // against 12.6 / 7.4 / 6.0 at 128 x 256 x 2688, 128 x 320 x 1280, 128 x 320 x 960)
+  constexpr int G16 = 16;                    // k per group: lane (i = l & 15, q = l >> 4) holds k = 16 grp + 4 q .. + 3 of row i
+  __shared__ float part[NW][16][17];
+  const FdGemmDesc& d = g.d;
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, l15 = lane & 15;
+  const int bm = (int)blockIdx.x / g.nblk_n, bn = (int)blockIdx.x % g.nblk_n;
+  const int m0 = bm * 16, n0 = bn * 16;
+  const int z = (int)blockIdx.y;
+  const int zo = z / d.bdiv, zi = z % d.bdiv;
+  const float* __restrict__ A = d.A + zo * d.a_so + zi * d.a_si;
+  const float* __restrict__ B = d.B + zo * d.b_so + zi * d.b_si;
+  float* __restrict__ C = d.C + zo * d.c_so + zi * d.c_si;
+  const int ra = (m0 + l15 < d.M) ? m0 + l15 : d.M - 1;
+  const int rb = (n0 + l15 < d.N) ? n0 + l15 : d.N - 1;
+  const float* pa = A + (long)ra * d.a_rs + (long)(4 * q) * d.a_cs;
+  const float* pb = B + (long)rb * d.b_cs + (long)(4 * q) * d.b_rs;
+  const long ag = (long)G16 * d.a_cs, bg = (long)G16 * d.b_rs;
+
+  // epilogue operands of this thread's output (row tid >> 4, column tid & 15), requested in front of the K loop
+  const int erow = tid >> 4, ecol = tid & 15;
+  const int em = m0 + erow, en = n0 + ecol;
+  const bool eok = em < d.M && en < d.N;
+  float e_bias = 0.f, e_res = 0.f, e_old = 0.f, e_gate = 1.f, e_rs = 1.f;
+  if (eok) {
+    if (d.rowscale) e_rs = d.rowscale[em];
+    if (d.bias) e_bias = d.bias[en];
+    if (d.gate) e_gate = d.gate[(long)em * d.ld_gate + en];
+    if (d.resid) e_res = d.resid[(long)em * d.ld_resid + en];
+    if (d.beta) e_old = C[(long)em * d.ldc + en];
+  }
+
+  f32x4 acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = 0.f;
+  const int ngroups = d.K / G16;             // K % 16 == 0 (checked by the host)
+  const int nmine = wave < ngroups ? (ngroups - wave + NW - 1) / NW : 0;
+  if (nmine > 0) {
+    const int lastg = nmine - 1;
+    float av[DPF][4], bv[DPF][4];
+#pragma unroll
+    for (int u = 0; u < DPF; ++u) {
+      const int gq = wave + NW * (u < lastg ? u : lastg);
+      direct_load<A_KC>(av[u], pa + (long)gq * ag, d.a_cs);
+      direct_load<B_KC>(bv[u], pb + (long)gq * bg, d.b_rs);
+    }
+    int t0 = 0;
+    for (; t0 + DPF <= nmine; t0 += DPF) {
+#pragma unroll
+      for (int u = 0; u < DPF; ++u) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fd::mfma_16x16x4(av[u][e], bv[u][e], acc);
+        const int tn = t0 + u + DPF;
+        const int gq = wave + NW * (tn < lastg ? tn : lastg);
+        direct_load<A_KC>(av[u], pa + (long)gq * ag, d.a_cs);
+        direct_load<B_KC>(bv[u], pb + (long)gq * bg, d.b_rs);
+      }
+    }
+    const int rem = nmine - t0;
+#pragma unroll
+    for (int u = 0; u < DPF - 1; ++u)
+      if (u < rem) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fd::mfma_16x16x4(av[u][e], bv[u][e], acc);
+      }
+  }
+  // D: lane (column l15, g = q): register r <-> row 4 q + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[wave][4 * q + r][l15] = acc[r];
+  __syncthreads();
+  if (!eok) return;
+  float x = d.alpha * ((part[0][erow][ecol] + part[1][erow][ecol]) + (part[2][erow][ecol] + part[3][erow][ecol]));
+  if (d.bias) x += e_bias;
+  if (d.relu) x = x > 0.f ? x : 0.f;
+  if (d.gate) x = e_gate > 0.f ? x : 0.f;
+  x *= e_rs;
+  if (d.resid) x += e_res;
+  if (d.beta) x += e_old;
+  C[(long)em * d.ldc + en] = x;
+}
+
 bool direct_ok(const FdGemmDesc& d) {
   // unit-stride operands with 16-byte aligned k groups where they are read as float4; no pair epilogue, no split-K
   if (d.K <= 0 || (d.K % DG) != 0 || d.pair_p || d.ksplit > 1 || d.a_rowsum) return false;
@@ -152,8 +243,29 @@ int launch_direct(const FdGemmDesc& d, hipStream_t stream) {
   g.mtiles = 1;
   g.epi_vec = 0;
   const int nb = d.batch > 0 ? d.batch : 1;
-  dim3 grid(g.nblk_m * g.nblk_n, nb, 1), block(256, 1, 1);
   const bool a_kc = (d.a_cs == 1), b_kc = (d.b_rs == 1);
+  // 16 x 16 tiles for a long K on few tiles (see the top; FD_GEMM_DIRECT_T16 = 0 / 1 forces it off / on where it applies: measurements)
+  static const int t16_env = getenv("FD_GEMM_DIRECT_T16") ? atoi(getenv("FD_GEMM_DIRECT_T16")) : -1;
+  const long tiles32 = (long)g.nblk_m * g.nblk_n * nb;
+  const bool t16_ok = (d.K % 16) == 0;
+  // (measured, profiles/r05_gemm_direct_t16.txt: wins for K >= 640 up to 40 tiles of 32 x 32 -- M = 128 --, for K >= 960 up to 80 -- M = 256)
+  const bool t16 = t16_ok && (t16_env >= 0 ? t16_env != 0 : ((d.K >= 640 && tiles32 <= 40) || (d.K >= 960 && tiles32 <= 80)));
+  if (t16) {
+    g.nblk_m = fd_cdiv(d.M, 16);
+    g.nblk_n = fd_cdiv(d.N, 16);
+    dim3 grid16(g.nblk_m * g.nblk_n, nb, 1), block16(256, 1, 1);
+    if (a_kc && b_kc)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_direct16_kernel<true, true>), grid16, block16, 0, stream, g);
+    else if (a_kc && !b_kc)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_direct16_kernel<true, false>), grid16, block16, 0, stream, g);
+    else if (!a_kc && b_kc)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_direct16_kernel<false, true>), grid16, block16, 0, stream, g);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_direct16_kernel<false, false>), grid16, block16, 0, stream, g);
+    FD_CHECK_LAUNCH("fd_gemm(direct, 16 x 16)");
+    return FD_OK;
+  }
+  dim3 grid(g.nblk_m * g.nblk_n, nb, 1), block(256, 1, 1);
   if (a_kc && b_kc)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_direct_kernel<true, true>), grid, block, 0, stream, g);
   else if (a_kc && !b_kc)

@@ -8,7 +8,7 @@ from test_gemm import _run
 
 
 LAYOUTS = [(True, True), (True, False), (False, True), (False, False)]
-CASES = [(32, 32, 8), (128, 320, 320), (100, 72, 40), (33, 40, 64), (7, 6, 16), (128, 256, 2688)]
+CASES = [(32, 32, 8), (128, 320, 320), (100, 72, 40), (33, 40, 64), (7, 6, 16), (128, 256, 2688), (128, 320, 1280), (50, 72, 968)]
 
 
 @pytest.mark.parametrize("layout", LAYOUTS)
@@ -20,6 +20,14 @@ def test_direct_layouts_emu(emu_lib, layout):
 def test_direct_epilogue_emu(emu_lib):
     assert _run(emu_lib, "cpu", 100, 72, 40, True, True, 5, epi=True) < 2e-6
     assert _run(emu_lib, "cpu", 36, 44, 24, True, False, 5, epi=True) < 2e-6
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_direct_long_k_emu(emu_lib, layout):
+    """long K on few tiles: the 16 x 16-tile form (K >= 640, K % 16 == 0), ragged M / N, the full epilogue; K % 16 != 0 keeps 32 x 32"""
+    assert _run(emu_lib, "cpu", 33, 40, 640, layout[0], layout[1], 5, epi=True, seed=3) < 3e-6
+    assert _run(emu_lib, "cpu", 20, 21 if not layout[1] else 36, 1296, layout[0], layout[1], 5, seed=4) < 3e-6
+    assert _run(emu_lib, "cpu", 33, 40, 648, layout[0], layout[1], 5, epi=True, seed=5) < 3e-6
 
 
 def _batched(lib, dev):
