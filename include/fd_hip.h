@@ -66,7 +66,8 @@ typedef struct FdGemmDesc {
                             large pair-level GEMMs unless FD_GEMM_EXACT_F32=1 is set in the environment.
                             5: latency kernel (fp32 MFMA, 32x32 tiles, K split over the waves of a block) that auto
                             picks when the problem has fewer 64x64 tiles than CUs (node-level GEMMs of sampling);
-                            needs K % 8 == 0 and unit-stride 16-byte aligned operands.
+                            needs K % 8 == 0 and unit-stride 16-byte aligned operands.  A long K on few tiles (K >= 640 up
+                            to 40 tiles, K >= 960 up to 80; K % 16 == 0) runs on 16x16 tiles: four times the blocks.
                             6: the split-bf16 kernel with a 128x128 block tile (two blocks per CU); never picked
                             automatically by fd_gemm (slower than 4 except for 128-row outputs), the host uses it
                             for the N_out = 128 weight gradients. */
