@@ -225,6 +225,7 @@ typedef struct FdEdgeEmbedDesc {
   const float* zb_bias;   /* optional [40] */
   unsigned* mask1;        /* optional [rows,4]: packed signs of h1 (bit 4 nb + e of word g <-> unit 16 nb + 4 g + e) */
   unsigned* mask2;        /* optional [rows,4]: packed signs of h2 */
+  long ld_pq;             /* row stride of p / q (0 = 128): both as column blocks of one GEMM's output */
 } FdEdgeEmbedDesc;
 int fd_edge_embed(const FdEdgeEmbedDesc* desc, void* stream);
 
@@ -352,6 +353,9 @@ int fd_seq_attn_fwd(const float* qkv, const float* key_add, float* out, float* A
  * host-computed tables of the reference's own op sequence. */
 int fd_node_feats(const long* seq_idx, const float* tscaled, const float* fixed, const float* tfreq,
                   const float* idenom, float* out /*[B*N,65]*/, int B, int N, void* stream);
+/* the same features with a row stride ld >= 65, columns 65 .. ld-1 written as zeros: K padded for the consumers' latency GEMM */
+int fd_node_feats_ld(const long* seq_idx, const float* tscaled, const float* fixed, const float* tfreq,
+                     const float* idenom, float* out /*[B*N,ld]*/, long ld, int B, int N, void* stream);
 int fd_edge_feats(const long* seq_idx, const float* tscaled, const float* fixed, const float* sc_ca,
                   const float* tfreq, const float* idenom, const float* dg_lower, const float* dg_upper,
                   float* out /*[B*N*N,120]*/, int B, int N, void* stream);

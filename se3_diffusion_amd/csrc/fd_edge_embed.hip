@@ -83,6 +83,7 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_kernel(FdEdgeEmbe
   const int lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
   const long rows = d.rows;
+  const long ld_pq = d.ld_pq > 0 ? d.ld_pq : EE_C;      // row stride of p / q (a caller that forms both with one GEMM passes its width)
   const int ntiles = (int)((rows + EM_ROWS - 1) / EM_ROWS);
   const int G = (int)gridDim.x, first = (int)blockIdx.x;
   if (first >= ntiles) return;
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(64 * EM_WAVES, 2) void edge_embed_kernel(FdEdgeEmbe
     f32x4 acc1[8];
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) {
-      const float4 pa = *reinterpret_cast<const float4*>(d.p + qi * EE_C + 16 * nb + 4 * g);
-      const float4 qa = *reinterpret_cast<const float4*>(d.q + qj * EE_C + 16 * nb + 4 * g);
+      const float4 pa = *reinterpret_cast<const float4*>(d.p + qi * ld_pq + 16 * nb + 4 * g);
+      const float4 qa = *reinterpret_cast<const float4*>(d.q + qj * ld_pq + 16 * nb + 4 * g);
       acc1[nb][0] = pa.x + qa.x; acc1[nb][1] = pa.y + qa.y; acc1[nb][2] = pa.z + qa.z; acc1[nb][3] = pa.w + qa.w;
     }
 #pragma clang loop unroll(full)
@@ -351,6 +352,7 @@ extern "C" int fd_edge_embed(const FdEdgeEmbedDesc* desc, void* stream) {
   FD_CHECK_ARG(d.nres > 0 && d.rows >= 0, "fd_edge_embed: bad extents");
   const void* ptrs[] = {d.img, d.p, d.q, d.bias2, d.bias3, d.gamma, d.beta, d.h1, d.h2, d.h3, d.out};
   for (const void* p : ptrs) FD_CHECK_ARG(fd_aligned16(p), "fd_edge_embed: operands must be 16-byte aligned");
+  FD_CHECK_ARG(d.ld_pq == 0 || (d.ld_pq >= 128 && (d.ld_pq & 3) == 0), "fd_edge_embed: ld_pq must be 0 or a multiple of 4 >= 128");
   if (d.rows == 0) return FD_OK;
   const long ntiles = (d.rows + EM_ROWS - 1) / EM_ROWS;
   const int blocks = d.blocks > 0 ? d.blocks : 256 * EM_BLOCKS_PER_CU;   // MI355X: persistent blocks fill the 256 CUs

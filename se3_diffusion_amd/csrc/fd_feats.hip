@@ -22,14 +22,18 @@ __global__ __launch_bounds__(256) void node_feats_kernel(const long* __restrict_
                                                          const float* __restrict__ fixed,
                                                          const float* __restrict__ tfreq,
                                                          const float* __restrict__ idenom, float* __restrict__ out,
-                                                         int B, int N) {
-  const long total = (long)B * N * 65;
+                                                         int B, int N, int ld) {
+  // ld >= 65: row stride of out; the columns 65 .. ld-1 are written as zeros (fd_node_feats_ld: a K padded to a multiple of 8 for
+  // the consumers' latency GEMM)
+  const long total = (long)B * N * ld;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const long r = e / 65;
-    const int c = (int)(e % 65);
+    const long r = e / ld;
+    const int c = (int)(e % ld);
     const int b = (int)(r / N);
     float v;
-    if (c < 32) {
+    if (c >= 65) {
+      v = 0.f;
+    } else if (c < 32) {
       const float arg = tscaled[b] * tfreq[c & 15];
       v = c < 16 ? sinf(arg) : cosf(arg);
     } else if (c == 32) {
@@ -94,14 +98,20 @@ __global__ __launch_bounds__(256) void edge_feats_kernel(const long* __restrict_
 
 }  // namespace
 
-extern "C" int fd_node_feats(const long* seq_idx, const float* tscaled, const float* fixed, const float* tfreq,
-                             const float* idenom, float* out, int B, int N, void* stream) {
+extern "C" int fd_node_feats_ld(const long* seq_idx, const float* tscaled, const float* fixed, const float* tfreq,
+                                const float* idenom, float* out, long ld, int B, int N, void* stream) {
+  FD_CHECK_ARG(ld >= 65 && ld <= 4096, "fd_node_feats_ld: the row stride must be >= 65 (got %ld)", ld);
   if (B == 0 || N == 0) return FD_OK;
-  long g = ((long)B * N * 65 + 255) / 256;
+  long g = ((long)B * N * ld + 255) / 256;
   hipLaunchKernelGGL(node_feats_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)stream,
-                     seq_idx, tscaled, fixed, tfreq, idenom, out, B, N);
+                     seq_idx, tscaled, fixed, tfreq, idenom, out, B, N, (int)ld);
   FD_CHECK_LAUNCH("fd_node_feats");
   return FD_OK;
+}
+
+extern "C" int fd_node_feats(const long* seq_idx, const float* tscaled, const float* fixed, const float* tfreq,
+                             const float* idenom, float* out, int B, int N, void* stream) {
+  return fd_node_feats_ld(seq_idx, tscaled, fixed, tfreq, idenom, out, 65, B, N, stream);
 }
 
 extern "C" int fd_edge_feats(const long* seq_idx, const float* tscaled, const float* fixed, const float* sc_ca,

@@ -105,7 +105,7 @@ class FdEdgeEmbedDesc(Structure):
         ("gamma", c_void_p), ("beta", c_void_p), ("rowscale", c_void_p),
         ("h1", c_void_p), ("h2", c_void_p), ("h3", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("out", c_void_p),
         ("rows", c_long), ("nres", c_int), ("eps", c_float), ("blocks", c_int), ("zb_out", c_void_p), ("zb_bias", c_void_p),
-        ("mask1", c_void_p), ("mask2", c_void_p),
+        ("mask1", c_void_p), ("mask2", c_void_p), ("ld_pq", c_long),
     ]
 
 
@@ -194,6 +194,7 @@ _SIGS = {
     "fd_rowscale": "plppllis",
     "fd_add2d": "plpllifs",
     "fd_node_feats": "ppppppiis",
+    "fd_node_feats_ld": "ppppppliis",
     "fd_edge_feats": "pppppppppiis",
     "fd_ipa_points_fwd": "pppppppiliiiis",
     "fd_ipa_points_bwd": "pppppppliiiis",

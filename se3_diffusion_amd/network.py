@@ -72,12 +72,13 @@ def _lin_grads(G, wname, bname, dy, x, M, N, K, w_off=0, w_ld=None):
 
 
 # --------------------------------------------------------------------------- embedder
-def mlp3_ln_fwd(P, pre, x, M, K0, Cc, rowscale):
-    """Linear-ReLU-Linear-ReLU-Linear-LayerNorm (* rowscale) -- score_network.py:67-86,194-195."""
+def mlp3_ln_fwd(P, pre, x, M, K0, Cc, rowscale, W0=None):
+    """Linear-ReLU-Linear-ReLU-Linear-LayerNorm (* rowscale) -- score_network.py:67-86,194-195.  W0: the first layer's weight
+    zero-padded to the K0 columns of a padded x (inference)."""
     dev = x[0]
     h1 = empty((M, Cc), dev); h2 = empty((M, Cc), dev); h3 = empty((M, Cc), dev); y = empty((M, Cc), dev)
     mean = empty((M,), dev); rstd = empty((M,), dev)
-    ops.linear(x, mv(P[f"{pre}.0.weight"]), P[f"{pre}.0.bias"], mv(h1), M, Cc, K0, relu=True)
+    ops.linear(x, mv(P[f"{pre}.0.weight"] if W0 is None else W0), P[f"{pre}.0.bias"], mv(h1), M, Cc, K0, relu=True)
     ops.linear(mv(h1), mv(P[f"{pre}.2.weight"]), P[f"{pre}.2.bias"], mv(h2), M, Cc, Cc, relu=True)
     ops.linear(mv(h2), mv(P[f"{pre}.4.weight"]), P[f"{pre}.4.bias"], mv(h3), M, Cc, Cc)
     ops.layernorm(mv(h3), P[f"{pre}.5.weight"], P[f"{pre}.5.bias"], mv(y), M, Cc, rowscale=rowscale, save=(mean, rstd))
@@ -114,13 +115,31 @@ def embed_fwd(P, feats, B, N, cache=None, save=True, zb_next=None):
     fixed = feats["fixed_mask"]
     seq = feats["seq_idx"]
     R, Pn = B * N, B * N * N
-    nf = empty((R, 65), dev)
-    lib().call("fd_node_feats", seq, tscaled, fixed, tfreq, idenom, nf, B, N)
-    node, sv_n = mlp3_ln_fwd(P, "embedding_layer.node_embedder", mv(nf), R, 65, CS, mask)
+    pre = "embedding_layer.edge_embedder"
+    # sampling (static weights, fused edge embedder, opts.embed_first_padded): the three first-layer products of the per-residue
+    # features -- node embedder 65 -> 256, the edge embedder's p and q halves 33 -> 128 each -- are K = 65 / 33 launches on the
+    # unaligned fp32 tile (9.5 us each on a lone backbone).  With the features written at a row stride of 72 (zero columns behind
+    # the 65) and the weights zero-padded once per trajectory they are two launches of the latency GEMM: the node layer, and p | q
+    # as the two column halves of ONE [R, 256] product that the fused edge kernel reads through its row stride.
+    padded = cache is not None and not save and opts.embed_first_padded and fused_embed()
+    NFL = 72 if padded else 65
+    nf = empty((R, NFL), dev)
+    if padded:
+        lib().call("fd_node_feats_ld", seq, tscaled, fixed, tfreq, idenom, nf, NFL, B, N)
+        if "embed_first" not in cache:
+            Wn, W0e = P["embedding_layer.node_embedder.0.weight"], P[f"{pre}.0.weight"]
+            Wn72 = torch.zeros((CS, NFL), device=Wn.device); Wn72[:, :65] = Wn
+            Wpq = torch.zeros((2 * CZ, NFL), device=Wn.device); Wpq[:CZ, :33] = W0e[:, :33]; Wpq[CZ:, :33] = W0e[:, 33:66]
+            bpq = torch.cat([P[f"{pre}.0.bias"], torch.zeros_like(P[f"{pre}.0.bias"])]).contiguous()
+            cache["embed_first"] = (Wn72, Wpq, bpq)
+        Wn72, Wpq, bpq = cache["embed_first"]
+        node, sv_n = mlp3_ln_fwd(P, "embedding_layer.node_embedder", mv(nf), R, NFL, CS, mask, W0=Wn72)
+    else:
+        lib().call("fd_node_feats", seq, tscaled, fixed, tfreq, idenom, nf, B, N)
+        node, sv_n = mlp3_ln_fwd(P, "embedding_layer.node_embedder", mv(nf), R, 65, CS, mask)
     emask = pair_mask(mask, B, N) if cache is None else cache.setdefault("emask", None)
     if emask is None:
         emask = cache["emask"] = pair_mask(mask, B, N)
-    pre = "embedding_layer.edge_embedder"
     if not fused_embed():
         ef = empty((Pn, 120), dev)
         lib().call("fd_edge_feats", seq, tscaled, fixed, feats["sc_ca_t"], tfreq, idenom, lower, upper, ef, B, N)
@@ -130,9 +149,15 @@ def embed_fwd(P, feats, B, N, cache=None, save=True, zb_next=None):
     # (t-embedding + fixed flag of i and of j = the first 33 columns of the node feature) is node-level:
     # p = W0[:, 0:33] pt + b0, q = W0[:, 33:66] pt
     W0 = P[f"{pre}.0.weight"]
-    p_ = empty((R, CZ), dev); q_ = empty((R, CZ), dev)
-    ops.linear((nf, 0, 65), (W0, 0, 120), P[f"{pre}.0.bias"], mv(p_), R, CZ, 33)
-    ops.linear((nf, 0, 65), (W0, 33, 120), None, mv(q_), R, CZ, 33)
+    ld_pq = 0
+    if padded:
+        pq = empty((R, 2 * CZ), dev)
+        ops.linear(mv(nf), mv(Wpq), bpq, mv(pq), R, 2 * CZ, NFL)
+        p_, q_, ld_pq = pq, pq[:, CZ:], 2 * CZ
+    else:
+        p_ = empty((R, CZ), dev); q_ = empty((R, CZ), dev)
+        ops.linear((nf, 0, 65), (W0, 0, 120), P[f"{pre}.0.bias"], mv(p_), R, CZ, 33)
+        ops.linear((nf, 0, 65), (W0, 33, 120), None, mv(q_), R, CZ, 33)
     use_zb = (opts.zb_from_edge and zb_next is not None and zb_next[0].is_contiguous() and zb_next[0].data_ptr() % 16 == 0
               and zb_next[1].data_ptr() % 16 == 0)
     key = ("ee_img", pre, use_zb)
@@ -156,7 +181,7 @@ def embed_fwd(P, feats, B, N, cache=None, save=True, zb_next=None):
             mh1 = empty((Pn, 4), dev, torch.int32); mh2 = empty((Pn, 4), dev, torch.int32)
             kw.update(mask1=mh1, mask2=mh2)
     ops.edge_embed(seq, feats["sc_ca_t"], idenom, lower, upper, img, p_, q_, P[f"{pre}.2.bias"], P[f"{pre}.4.bias"],
-                   P[f"{pre}.5.weight"], P[f"{pre}.5.bias"], edge, Pn, N, rowscale=emask, **kw)
+                   P[f"{pre}.5.weight"], P[f"{pre}.5.bias"], edge, Pn, N, rowscale=emask, ld_pq=ld_pq, **kw)
     sv_e = None
     if save:
         # the backward is the unfused MLP backward; its first-layer weight gradient needs the [P,120] feature tensor,

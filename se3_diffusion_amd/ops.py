@@ -542,7 +542,7 @@ def edge_embed_pack(W0, W2, W4, out=None, W40=None):
 
 def edge_embed(seq_idx, sc_ca, idenom, dg_lower, dg_upper, img, p, q, bias2, bias3, gamma, beta, out, rows, nres, *,
                rowscale=None, h1=None, h2=None, h3=None, mean=None, rstd=None, blocks=0, zb_out=None, zb_bias=None, mask1=None,
-               mask2=None):
+               mask2=None, ld_pq=0):
     d = hip.FdEdgeEmbedDesc()
     tens = []
     for name, t in (("seq_idx", seq_idx), ("sc_ca", sc_ca), ("idenom", idenom), ("dg_lower", dg_lower), ("dg_upper", dg_upper),
@@ -553,6 +553,7 @@ def edge_embed(seq_idx, sc_ca, idenom, dg_lower, dg_upper, img, p, q, bias2, bia
         if t is not None:
             tens.append(t)
     d.rows, d.nres, d.eps, d.blocks = int(rows), int(nres), 1e-5, int(blocks)
+    d.ld_pq = int(ld_pq)
     L = lib()
     stream = L._stream(tens)
     prof = L.gemm_profile

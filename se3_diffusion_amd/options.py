@@ -79,6 +79,8 @@ class Options:
                                       # consume them (fd_ln_gemm) instead of launches of their own
     sampler_device_steps: bool = True # FD_SAMPLER_DEVICE_STEPS: sampling -- the captured step takes t, the step's scalars and its normal draws
                                       # from device arrays indexed by a device counter (fd_sample_advance) instead of three launches per step
+    embed_first_padded: bool = True   # FD_EMBED_FIRST_PADDED: sampling -- the per-residue features at a row stride of 72 (fd_node_feats_ld) so that the
+                                      # embedders' first layers (K = 65 / 33) run on the latency GEMM; p | q of the edge embedder as ONE product
     merge_skip_embed: bool = True     # FD_MERGE_SKIP: sampling -- the skip_embed products of all trunk blocks as ONE GEMM per forward
     graph_fork: bool = False          # FD_GRAPH_FORK (measured, OFF: 1.33-1.40 against 1.61 backbones/s at N=128, 1.06-1.09 against 1.23 at
                                       # N=256 -- a cross-queue edge of the hipGraph costs ~20 us, more than the 5-12 us launch it hides): sampling -- launches that do not depend on each other (skip_embed, the IPA point
@@ -96,7 +98,7 @@ class Options:
             fused_edge=_flag("FD_EDGE_FUSED", True), fused_embed=_flag("FD_EMBED_FUSED", True),
             fused_embed_bwd=_flag("FD_EMBED_BWD_FUSED", True),
             grouped_pair_dw=_flag("FD_PAIR_DW", True), pair_dw_blocks=_int("FD_PAIR_DW_BLOCKS", 160),
-            edge_blocks=_int("FD_EDGE_BLOCKS", 0), edge_shape=_int("FD_EDGE_SHAPE", 0), edge_pair=_flag("FD_EDGE_PAIR", True), zb_from_edge=_flag("FD_ZB_FUSED", True),
+            edge_blocks=_int("FD_EDGE_BLOCKS", 0), edge_shape=_int("FD_EDGE_SHAPE", 0), edge_pair=_flag("FD_EDGE_PAIR", True), embed_first_padded=_flag("FD_EMBED_FIRST_PADDED", True), zb_from_edge=_flag("FD_ZB_FUSED", True),
             fused_ln_bwd=_flag("FD_EDGE_LN_BWD", True), edge_dynamic_tiles=_flag("FD_EDGE_DYN_TILES", True), packed_gates=_flag("FD_PACKED_GATES", True),
             fold_node_terms=_flag("FD_FOLD_NODE_TERMS", True),
             fused_ipa_attn=_flag("FD_IPA_ATTN_FUSED", True),

@@ -106,6 +106,11 @@ def _fold_vs_launches(dev, B, N, blocks):
     e = _infer(dev, B, N, blocks, static_cache=True, edge_pair=False)
     for k in a:
         assert float((c[k] - e[k]).abs().max()) <= 2e-5 * float(e[k].abs().max() + 1e-3), k
+    # the embedders' first layers on per-residue features padded to K = 72 (options.embed_first_padded: fd_node_feats_ld, p | q of the
+    # edge embedder as one product read through FdEdgeEmbedDesc.ld_pq) against the K = 65 / 33 launches
+    e = _infer(dev, B, N, blocks, static_cache=True, embed_first_padded=False)
+    for k in a:
+        assert float((c[k] - e[k]).abs().max()) <= 2e-5 * float(e[k].abs().max() + 1e-3), k
 
 
 def test_inference_fold_vs_layernorm_launches_emu(use_emu):
