@@ -5,7 +5,7 @@
 // One block = one 32 x 32 output tile; its four waves SPLIT K (wave w takes the 8-k groups g = w mod 4), so the serial
 // MFMA chain is a quarter of K.  Operand fragments go global -> registers directly in MFMA layout (no LDS, no
 // barrier in the loop): lane (i = l & 31, h = l >> 5) loads the float4 A[i][8g+4h .. +3] (k-contiguous operand) or
-// four coalesced dwords (row-contiguous operand); four v_mfma_f32_32x32x2_f32 consume it.  Two groups are kept in
+// four coalesced dwords (row-contiguous operand); four v_mfma_f32_32x32x2_f32 consume it.  DPF groups are kept in
 // flight.  The four partial tiles meet in LDS and every thread finishes one float4 of the tile with the full fused
 // epilogue.  fp32 MFMA: exact fp32 products and sums (the k order differs from the 64x64 kernel's).
 // gemm_direct16_kernel (round 5): the same kernel on 16 x 16 tiles (v_mfma_f32_16x16x4_f32, 16-k groups) for LONG-K products with few
