@@ -383,7 +383,9 @@ int fd_ipa_opair_fwd(const float* A, const float* zb, float* feats, int B, int N
 int fd_ipa_opair_bwd(const float* A, const float* zb, const float* dfeats, float* dA, float* dzb, int B, int N,
                      void* stream);
 
-/* softmax + o_pair of a query row in one launch (fd_ipa_softmax_fwd followed by fd_ipa_opair_fwd, bit-identical), and
+/* softmax + o_pair of a query row in one launch (fd_ipa_softmax_fwd followed by fd_ipa_opair_fwd: the probabilities bit-identical,
+ * o_pair equal to fp32 rounding -- up to 512 query rows the block is 512 threads, one wave per head, and sums o_pair in two halves
+ * of the keys), and
  * their backward (fd_ipa_opair_bwd followed by fd_ipa_softmax_bwd): the probabilities / the updated dA stay in LDS.
  * kp_soa (may be null): fd_ipa_points_fwd's [B, 8, 24, N] copy of kp; when given, the key points are read from it */
 int fd_ipa_attn_fwd(float* S, const float* zb, const float* qp, const float* kp, const float* kp_soa,

@@ -158,9 +158,12 @@ __device__ __forceinline__ void load_pts_soa(float (&v)[PQ * 3], const float* __
 // SLAB (N <= NMAX = 256): the row's [N, 40] block of zb -- one contiguous 160 N bytes -- is copied to LDS with whole-line
 // float4 loads and both the bias column of the logits and the 32 o_pair columns are served from there; the direct reads
 // (4 bytes at a 160-byte stride for the bias, 128 of every 160 bytes for o_pair) fetched about twice the bytes they used.
+constexpr long FD_IPA_ATTN_WIDE_MAX_ROWS = 512;     // fd_ipa_attn_fwd: up to this many query rows on the 512-thread form
 constexpr int ZPAD = ZB + 1;    // floats per zb row in LDS (41: conflict-free for lanes along j and along the columns)
-template <int NMAX, bool SLAB>
-__global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict__ S, const float* __restrict__ zb,
+// NT (round 5): 256 threads = four waves x two heads each, or 512 = one wave per head with the o_pair sums split in two halves of the
+// keys -- for launches with few query rows (a lone backbone: 128 / 256 blocks on 256 CUs), where a row's serial chain is the launch
+template <int NMAX, bool SLAB, int NT = 256>
+__global__ __launch_bounds__(NT) void ipa_softmax_fwd_kernel(float* __restrict__ S, const float* __restrict__ zb,
                                                               const float* __restrict__ qp,
                                                               const float* __restrict__ kp,
                                                               const float* __restrict__ kp_soa,
@@ -169,14 +172,16 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict_
                                                               int N) {
   // feats != nullptr: o_pair of the same (b, i) row is taken from the probabilities while they are in LDS
   // (fd_ipa_attn_fwd: one launch and one pass over A less than softmax + opair)
+  constexpr int HPW = H / (NT / 64);      // heads per wave
   __shared__ float lg[H][NMAX];
   __shared__ float zs[SLAB ? NMAX * ZPAD : 1];
+  __shared__ float opart[NT > 256 ? 256 : 1];
   const long bi = blockIdx.x;
   const int b = (int)(bi / N), i = (int)(bi % N);
   const int lane = fd::lane_id(), wave = fd::wave_id();
   if (SLAB) {
     const float4* src = reinterpret_cast<const float4*>(zb + bi * N * ZB);     // (N * 40 floats: a multiple of 4, 16-byte aligned)
-    for (int e = (int)threadIdx.x; e < N * (ZB / 4); e += 256) {
+    for (int e = (int)threadIdx.x; e < N * (ZB / 4); e += NT) {
       const float4 v = src[e];
       const int j = e / (ZB / 4), c = 4 * (e % (ZB / 4));
       float* d = zs + j * ZPAD + c;
@@ -187,8 +192,8 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict_
   const float mi = mask[bi];
   const float sq13 = sqrtf(1.0f / 3.0f);
   const float gscale = sqrtf(1.0f / (3.0f * ((float)PQ * 9.0f / 2.0f)));
-  for (int hh = 0; hh < 2; ++hh) {
-    const int h = wave * 2 + hh;
+  for (int hh = 0; hh < HPW; ++hh) {
+    const int h = wave * HPW + hh;
     const float gamma = softplus_f(head_w[h]) * gscale;
     float q[PQ * 3];
     const float* qsrc = qp + (bi * H + h) * (PQ * 3);
@@ -231,16 +236,26 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(float* __restrict_
   }
   if (feats != nullptr) {
     __syncthreads();
-    const int h = (int)threadIdx.x / CZ4, c = (int)threadIdx.x % CZ4;
+    const int t = (int)threadIdx.x & 255, half = (int)threadIdx.x >> 8;
+    const int h = t / CZ4, c = t % CZ4;
+    // (NT = 512: the upper half of the block takes the second half of the keys)
+    const int j0 = NT > 256 ? half * ((N + 1) / 2) : 0;
+    const int j1 = NT > 256 ? (half == 0 ? (N + 1) / 2 : N) : N;
     float acc = 0.f;
     if (SLAB) {
       const float* z = zs + H + c;
-      for (int j = 0; j < N; ++j) acc += lg[h][j] * z[j * ZPAD];
+      for (int j = j0; j < j1; ++j) acc += lg[h][j] * z[j * ZPAD];
     } else {
       const float* z = zb + bi * N * ZB + H + c;
-      for (int j = 0; j < N; ++j) acc += lg[h][j] * z[(long)j * ZB];
+      for (int j = j0; j < j1; ++j) acc += lg[h][j] * z[(long)j * ZB];
     }
-    feats[bi * LDF + F_PAIR + h * CZ4 + c] = acc;
+    if (NT > 256) {
+      if (half == 1) opart[t] = acc;
+      __syncthreads();
+      if (half == 0) feats[bi * LDF + F_PAIR + h * CZ4 + c] = acc + opart[t];
+    } else {
+      feats[bi * LDF + F_PAIR + h * CZ4 + c] = acc;
+    }
   }
 }
 
@@ -658,7 +673,16 @@ extern "C" int fd_ipa_attn_fwd(float* S, const float* zb, const float* qp, const
   FD_CHECK_ARG(N <= MAXN, "fd_ipa_attn_fwd: N=%d exceeds %d", N, MAXN);
   FD_CHECK_ARG(feats != nullptr, "fd_ipa_attn_fwd: feats is required");
   if (B == 0 || N == 0) return FD_OK;
-  if (N <= 128 && fd_aligned16(zb))
+  // few query rows (a lone backbone): one wave per head (see the kernel)
+  static const int nt_env = getenv("FD_IPA_ATTN_THREADS") ? atoi(getenv("FD_IPA_ATTN_THREADS")) : 0;
+  const bool wide = nt_env ? nt_env == 512 : (long)B * N <= FD_IPA_ATTN_WIDE_MAX_ROWS;
+  if (N <= 128 && fd_aligned16(zb) && wide)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_fwd_kernel<128, true, 512>), dim3((unsigned)((long)B * N)), dim3(512), 0,
+                       (hipStream_t)stream, S, zb, qp, kp, kp_soa, head_w, mask, feats, N);
+  else if (N <= 256 && fd_aligned16(zb) && wide)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_fwd_kernel<256, true, 512>), dim3((unsigned)((long)B * N)), dim3(512), 0,
+                       (hipStream_t)stream, S, zb, qp, kp, kp_soa, head_w, mask, feats, N);
+  else if (N <= 128 && fd_aligned16(zb))
     hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_softmax_fwd_kernel<128, true>), dim3((unsigned)((long)B * N)), dim3(256), 0,
                        (hipStream_t)stream, S, zb, qp, kp, kp_soa, head_w, mask, feats, N);
   else if (N <= 256 && fd_aligned16(zb))
