@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define FD_ABI_VERSION 1
+#define FD_ABI_VERSION 2
 
 const char* fd_last_error(void);
 int fd_abi_version(void);
@@ -76,9 +76,21 @@ typedef struct FdGemmDesc {
   int mtiles;            /* 0 = auto; >0: consecutive M tiles pipelined per block (un-batched, ksplit 1) */
   float* a_rowsum;       /* optional [M]: += alpha * sum_k A(m,k), accumulated atomically (fused bias gradient
                             of dW = dY^T X: A = dY^T, so this is sum over rows of dY) */
+  const void* b_planes;  /* optional: B pre-split into its three exact bf16 planes (fd_split_planes of the buffer B lives in):
+                            the address of plane 0's element of B[0]; plane p of B(k,n) is b_planes[p * b_plane_stride +
+                            k * b_rs + n * b_cs] (16-bit elements).  With it fd_gemm may run the node-level layers (nn.Linear
+                            forward y = x W^T and activation gradient dx = dy W, model/ipa_pytorch.py:101-166) on tiles
+                            12: 128x128, 13: 64x128, 14: 64x64 -- split-bf16 arithmetic as tile 4, the weight operand moved as
+                            6-byte elements with no split work in the kernel.  Needs A k-contiguous, K % 16 == 0, B unit-stride
+                            along k or along n (then N % 8 == 0), un-batched, 16-byte aligned operands. */
+  long b_plane_stride;   /* 16-bit elements between two planes (% 8 == 0) */
 } FdGemmDesc;
 
 int fd_gemm(const FdGemmDesc* desc, void* stream);
+/* planes[p * n + e] = p-th bf16 term of x[e] (x = t0 + t1 + t2 exactly, round-to-nearest at every stage), p = 0..2: the
+ * weight operand format of fd_gemm tiles 12-14.  One launch over the flat parameter buffer per optimiser step
+ * (experiments/train_se3_diffusion.py:139: the parameters change once per step).  n % 8 == 0. */
+int fd_split_planes(const float* x, long n, void* planes, void* stream);
 /* the tile code (1..6) fd_gemm would run this descriptor with; no launch */
 int fd_gemm_plan(const FdGemmDesc* desc);
 /* exact != 0: every later fd_gemm runs on the fp32-MFMA kernels (as FD_GEMM_EXACT_F32=1); returns the previous mode */

@@ -153,7 +153,8 @@ def main():
         print("trajectory golden (N=128) written", flush=True)
 
     for name, Bt, Nt, num_t, seed, stride in (("traj_n256", 1, 256, 5, 42, 1), ("traj_n512_b2", 2, 512, 5, 43, 1),
-                                              ("traj_n128_t50", 1, 128, 50, 44, 1), ("traj_n128_t500", 1, 128, 500, 45, 10)):
+                                              ("traj_n128_t50", 1, 128, 50, 44, 1), ("traj_n128_t500", 1, 128, 500, 45, 10),
+                                              ("traj_n256_t500", 1, 256, 500, 46, 10)):
         if not only or name in only.split(","):
             t0 = time.time()
             traj_via_experiment(name, Bt, Nt, num_t, seed, stride=stride)

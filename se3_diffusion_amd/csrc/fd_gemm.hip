@@ -512,6 +512,7 @@ bool epilogue_vectorisable(const FdGemmDesc& d, int ksplit) {
 }
 
 #include "fd_gemm_s64.h"     // gemm_s64_kernel: tile code 10
+#include "fd_gemm_w.h"       // gemm_w_kernel: tile codes 12 / 13 / 14 (pre-split weights)
 
 // split-bf16 kernel: instantiated for A k-contiguous (activations [rows, features]) with either B layout
 // (y = x W^T and dx = dy W) and for both operands row-contiguous (dW = dY^T X)
@@ -592,6 +593,12 @@ bool s64_enabled() {
   return on;
 }
 
+// FD_GEMM_NO_W=1: the automatic choice ignores pre-split weight planes (A/B measurements)
+bool w_enabled() {
+  static const bool on = getenv("FD_GEMM_NO_W") == nullptr;
+  return on;
+}
+
 // tile selection: 1 = 128x128, 2 = 64x64, 3 = 128x32 (fp32 MFMA); 4 = 256x128 split-bf16; 10 = 64x64 split-bf16.
 // Wide tiles when the problem fills the chip, narrow otherwise.
 int plan_tile(const FdGemmDesc& d, bool fast) {
@@ -618,6 +625,29 @@ int plan_tile(const FdGemmDesc& d, bool fast) {
     // gradients (both operands row-contiguous, split-K) and the batched attention products are not faster on it)
     if (cfg == 2 && fast && d.a_cs == 1 && d.batch <= 1 && d.K >= 256 && split_enabled() && s64_enabled()) cfg = 10;
   }
+  if (d.tile == 0 && w_ok(d) && fast && split_enabled() && w_enabled() && (cfg == 10 || cfg == 4 || cfg == 2) && d.K >= 128) {
+    // activations x PRE-SPLIT weights (FdGemmDesc.b_planes: the host split the flat parameter buffer once per step).  Which tile,
+    // measured at M = 3,840 rows (profiles/r06_node_gemm.log): many output tiles and a short reduction (IPA's projections,
+    // N = 6816, K = 256) stay on tile 4, whose 256-row tile moves half the weight bytes per output; k-contiguous weights from
+    // ~224 tiles of 128 x 128 up on tile 12, row-contiguous ones (dx = dy W) from ~480 tiles of 64 x 128 up on tile 13; split-K
+    // launches (a long reduction over few tiles) on tile 12 when their blocks fill the chip; a long un-split reduction over few
+    // tiles stays on tile 10; everything else on the 64 x 64 tile 14
+    const int ks = d.ksplit > 1 ? d.ksplit : 1;
+    const long t128 = (long)fd_cdiv(d.M, 128) * fd_cdiv(d.N, 128), t64 = (long)fd_cdiv(d.M, 64) * fd_cdiv(d.N, 128);
+    const bool b_kc = d.b_rs == 1;
+    if (d.N >= 4096 && d.K <= 256 && cfg == 4) {
+    } else if (ks > 1) {
+      cfg = t128 * ks >= 224 ? 12 : 14;
+    } else if (b_kc && t128 >= 224) {
+      cfg = 12;
+    } else if (!b_kc && t64 >= 480) {
+      cfg = 13;
+    } else if (d.K > 1024 && t128 < 128 && cfg == 10) {
+    } else {
+      cfg = 14;
+    }
+  }
+  if (cfg >= 12 && cfg <= 14 && !(w_ok(d) && fast && split_enabled())) cfg = (fast && split_enabled() && d.a_cs == 1 && d.batch <= 1) ? 10 : 2;
   if (cfg == 10 && !(fast && split_enabled())) cfg = 2;   // (explicit requests: exact-fp32 mode, unaligned operands)
   if ((cfg == 4 || cfg == 6) && !split_enabled()) {
     // FD_GEMM_EXACT_F32=1 also overrides explicit requests for the split-bf16 kernel (the host asks for it on the
@@ -691,6 +721,18 @@ extern "C" int fd_gemm_set_persistent_blocks(int blocks) {
   return was;
 }
 
+extern "C" int fd_split_planes(const float* x, long n, void* planes, void* stream_) {
+  FD_CHECK_ARG(x != nullptr && planes != nullptr, "fd_split_planes: null operand");
+  FD_CHECK_ARG(n >= 0 && (n % 8) == 0 && fd_aligned16(x) && fd_aligned16(planes), "fd_split_planes: n %% 8 == 0, 16-byte aligned buffers");
+  if (n == 0) return FD_OK;
+  const long n8 = n / 8;
+  const int blocks = (int)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, x, n8, n,
+                     reinterpret_cast<unsigned short*>(planes));
+  FD_CHECK_LAUNCH("fd_split_planes");
+  return FD_OK;
+}
+
 extern "C" int fd_gemm_plan(const FdGemmDesc* desc) {
   FD_CHECK_ARG(desc != nullptr, "fd_gemm_plan: null descriptor");
   return plan_tile(*desc, operands_vectorisable(*desc));
@@ -731,6 +773,9 @@ extern "C" int fd_gemm(const FdGemmDesc* desc, void* stream_) {
     case 4: return launch_bx3<256>(d, stream);
     case 6: return launch_bx3<128>(d, stream);
     case 10: return launch_s64(d, stream);
+    case 12: return launch_w<128, 128>(d, stream);
+    case 13: return launch_w<64, 128>(d, stream);
+    case 14: return launch_w<64, 64>(d, stream);
     case 5:
       FD_CHECK_ARG(direct_ok(d), "fd_gemm: tile 5 (latency kernel) needs K %% 8 == 0, unit-stride 16-byte aligned operands, "
                                  "no pair epilogue / split-K / row sum");

@@ -9,6 +9,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace fd {
 
+// 16 bytes moved as one register quad (global_load_dwordx4 / ds_write_b128) without HIP's uint4 struct semantics
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 // v_mfma_f32_32x32x2_f32: exact f32 (k-ordered fmaf chain), 64 cycles / SIMD.
 //   A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D reg r -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31
 __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {

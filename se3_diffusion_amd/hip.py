@@ -46,6 +46,7 @@ class FdGemmDesc(Structure):
         ("rowscale", c_void_p),
         ("relu", c_int), ("tile", c_int), ("ksplit", c_int), ("mtiles", c_int),
         ("a_rowsum", c_void_p),
+        ("b_planes", c_void_p), ("b_plane_stride", c_long),
     ]
 
 
@@ -158,6 +159,9 @@ class FdGroupDwDesc(Structure):
     _fields_ = [("item", FdGroupDwItem * GROUP_DW_MAX_ITEMS), ("nitems", c_int), ("rows", c_long), ("blocks", c_int)]
 
 
+ABI_VERSION = 2          # FD_ABI_VERSION of include/fd_hip.h (bumped whenever a descriptor layout or a signature changes)
+
+
 def _ptr(t, off=0):
     """Raw address of a tensor (plus an element offset)."""
     if t is None:
@@ -172,6 +176,7 @@ def _ptr(t, off=0):
 _SIGS = {
     "fd_gemm": "Ss",
     "fd_gemm_plan": "S",
+    "fd_split_planes": "plps",
     "fd_gemm_set_exact_f32": "i",
     "fd_gemm_set_persistent_blocks": "i",
     "fd_edge_mlp_pack": "ppplps",
@@ -254,6 +259,10 @@ class FdLib:
             fn = getattr(self.cdll, name)  # AttributeError if the symbol is missing
             fn.restype = c_int
             fn.argtypes = [_CT[c] for c in sig]
+        if self.cdll.fd_abi_version() != ABI_VERSION:
+            # descriptors are passed by layout: a library built from another header revision would read them misaligned
+            raise FdError(f"{path} implements C-ABI version {self.cdll.fd_abi_version()}, this binding is version {ABI_VERSION}: "
+                          f"rebuild it (python -m se3_diffusion_amd.build)")
         self.backend = self.cdll.fd_backend().decode()
         self.is_device = self.backend == "gfx950"
         # mirror of the library's FD_GEMM_EXACT_F32 switch (the fused split-bf16 kernels consult it on the host side)
@@ -315,7 +324,9 @@ class FdLib:
     def gemm(self, A, B, C, M, N, K, a_str, b_str, ldc, *, a_off=0, b_off=0, c_off=0,
              batch=1, bdiv=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), alpha=1.0, beta=False,
              bias=None, pair=None, resid=None, ld_resid=0, gate=None, ld_gate=0,
-             rowscale=None, relu=False, tile=0, ksplit=1, mtiles=0, a_rowsum=None):
+             rowscale=None, relu=False, tile=0, ksplit=1, mtiles=0, a_rowsum=None, b_planes=None):
+        """b_planes = (address of plane 0's element of B[b_off], elements between planes) when B lives in a buffer that
+        fd_split_planes has split (ops.weight_planes): fd_gemm may then pick the pre-split tiles 12-14."""
         d = FdGemmDesc()
         d.A, d.B, d.C = _ptr(A, a_off), _ptr(B, b_off), _ptr(C, c_off)
         d.M, d.N, d.K = int(M), int(N), int(K)
@@ -338,6 +349,8 @@ class FdLib:
         d.rowscale = _ptr(rowscale)
         d.relu, d.tile, d.ksplit, d.mtiles = int(bool(relu)), int(tile), int(ksplit), int(mtiles)
         d.a_rowsum = _ptr(a_rowsum)
+        if b_planes is not None:
+            d.b_planes, d.b_plane_stride = int(b_planes[0]), int(b_planes[1])
         for x in (bias, resid, gate, rowscale):
             if x is not None:
                 tens.append(x[0] if isinstance(x, tuple) else x)

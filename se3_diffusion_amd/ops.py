@@ -66,6 +66,55 @@ def mv(t, off=0, ld=None):
     return (t, off, ld if ld is not None else t.shape[-1])
 
 
+# ---------------------------------------------------------------------------
+# pre-split weights.  In training the parameters change once per step; when they live in ONE flat fp32 buffer (optim.FlatAdam,
+# dist.FlatGrads) trunk.forward splits that buffer into its three exact bf16 planes with one launch (fd_split_planes) and every
+# node-level GEMM of the forward and of the backward reads its weight operand from the planes (fd_gemm tiles 12-14: no split
+# work and no register staging for the weights inside the kernel).  _PLANES = (first byte, bytes, [3, n] int16 planes) of the
+# buffer that is currently split, or None: a weight outside it takes the old tiles.
+# ---------------------------------------------------------------------------
+_PLANES = None
+
+
+def weight_planes(P):
+    """Split the flat buffer that holds every tensor of P (a state-dict-like mapping) and make it the current plane set.  Returns the
+    plane set (for trunk.backward, which re-installs it), or None when the parameters are not views of one 16-byte aligned buffer,
+    the option is off or the library is in exact-fp32 mode."""
+    global _PLANES
+    _PLANES = None
+    if not opts.weight_planes or lib().exact_f32:
+        return None
+    ts = list(P.values())
+    st = ts[0].untyped_storage()
+    base, nbytes = st.data_ptr(), st.nbytes()
+    if base % 16 or nbytes % 32 or any(t.dtype != F32 or t.untyped_storage().data_ptr() != base for t in ts):
+        return None
+    n = nbytes // 4
+    flat = torch.empty(0, dtype=F32, device=ts[0].device).set_(st, 0, (n,), (1,))
+    planes = torch.empty((3, n), dtype=torch.int16, device=ts[0].device)
+    lib().call("fd_split_planes", flat, n, planes)
+    _PLANES = (base, nbytes, planes)
+    return _PLANES
+
+
+def set_weight_planes(ps):
+    """Install (or clear, ps = None) a plane set returned by weight_planes(); returns the previous one."""
+    global _PLANES
+    was, _PLANES = _PLANES, ps
+    return was
+
+
+def _planes_of(wt, wo):
+    """b_planes argument of FdLib.gemm for the weight view (wt, element offset wo), or None"""
+    ps = _PLANES
+    if ps is None:
+        return None
+    a = wt.data_ptr() + 4 * wo
+    if not (ps[0] <= a < ps[0] + ps[1]):
+        return None
+    return (ps[2].data_ptr() + (a - ps[0]) // 2, ps[1] // 4)
+
+
 def linear(x, W, b, out, M, N, K, *, relu=False, resid=None, rowscale=None, pair=None, beta=False,
            gate=None, alpha=1.0, tile=0):
     """out[M,N] = epi(x[M,K] @ W[N,K]^T + b).  x, W, out, resid, gate are matrix views."""
@@ -73,6 +122,9 @@ def linear(x, W, b, out, M, N, K, *, relu=False, resid=None, rowscale=None, pair
     wt, wo, wl = W
     ot, oo, ol = out
     kw = {}
+    bp = _planes_of(wt, wo)
+    if bp is not None:
+        kw["b_planes"] = bp
     if resid is not None:
         kw.update(resid=(resid[0], resid[1]), ld_resid=resid[2])
     if gate is not None:
@@ -92,16 +144,17 @@ def linear_dx(dy, W, dx, M, N, K, *, beta=False, gate=None, rowscale=None, alpha
         kw.update(gate=(gate[0], gate[1]), ld_gate=gate[2])
     if resid is not None:
         kw.update(resid=(resid[0], resid[1]), ld_resid=resid[2])
+    bp = _planes_of(wt, wo)
     if beta and not kw and rowscale is None and N >= 1024 and opts.dx_splitk and not lib().exact_f32:
         # an accumulating dX with a long reduction and few output tiles (IPA projections: 3840 x 256 over N = 2048 / 4096
         # is 240 tiles of 64 x 64 walking 64..128 stages each): split the reduction, the partial tiles add atomically
         # into the accumulator that is already there (order-nondeterministic: off in exact-fp32 mode, whose contract is a
         # bitwise reproducible fmaf chain)
         lib().gemm(dt, wt, xt, M, K, N, (dl, 1), (wl, 1), xl, a_off=do, b_off=wo, c_off=xo, alpha=alpha,
-                   ksplit=min(8, N // 512))
+                   ksplit=min(8, N // 512), b_planes=bp)
         return
     lib().gemm(dt, wt, xt, M, K, N, (dl, 1), (wl, 1), xl, a_off=do, b_off=wo, c_off=xo, beta=beta,
-               rowscale=rowscale, alpha=alpha, **kw)
+               rowscale=rowscale, alpha=alpha, b_planes=bp, **kw)
 
 
 # ---------------------------------------------------------------------------

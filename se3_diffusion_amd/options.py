@@ -75,6 +75,8 @@ class Options:
     defer_node_dw: bool = True        # FD_DEFER_NODE_DW: ... launched behind the NEXT edge transition's fused backward (beside that block's
                                       # node-level phase) instead of at the end of its own block (in front of that full-chip kernel)
     node_dw_blocks: int = 0           # FD_NODE_DW_BLOCKS: its persistent blocks (0 = 512: two per CU)
+    weight_planes: bool = True        # FD_WEIGHT_PLANES: training -- the flat parameter buffer split into its three bf16 planes once per step
+                                      # (fd_split_planes); the node-level GEMMs then read the weight operand pre-split (fd_gemm tiles 12-14)
     ln_fold: bool = True              # FD_LN_FOLD: sampling -- the sequence transformer's LayerNorms inside the GEMM launches that
                                       # consume them (fd_ln_gemm) instead of launches of their own
     sampler_device_steps: bool = True # FD_SAMPLER_DEVICE_STEPS: sampling -- the captured step takes t, the step's scalars and its normal draws
@@ -109,7 +111,7 @@ class Options:
             proj_merge=_flag("FD_PROJ_MERGE", True),
             fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),
             grouped_node_dw=_flag("FD_NODE_DW", True), defer_node_dw=_flag("FD_DEFER_NODE_DW", True), node_dw_blocks=_int("FD_NODE_DW_BLOCKS", 0),
-            ln_fold=_flag("FD_LN_FOLD", True),
+            ln_fold=_flag("FD_LN_FOLD", True), weight_planes=_flag("FD_WEIGHT_PLANES", True),
             sampler_device_steps=_flag("FD_SAMPLER_DEVICE_STEPS", True), merge_skip_embed=_flag("FD_MERGE_SKIP", True), graph_fork=_flag("FD_GRAPH_FORK", False),
             zero_arena=_flag("FD_ZERO_ARENA", True), dx_splitk=_flag("FD_DX_SPLITK", True))
 

@@ -463,6 +463,10 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
     """ScoreNetwork.forward.  Returns (outputs, saved-for-backward or None).  `cache`: see _cached (no-grad only)."""
     if save:
         cache = None
+    # training: the weight operand of every node-level GEMM of this step, pre-split once (ops.weight_planes; None = not a flat buffer)
+    planes = ops.weight_planes(P) if save else None
+    if not save:
+        ops.set_weight_planes(None)
     f = _prep_feats(feats)
     B, N = f["res_mask"].shape
     R = B * N
@@ -596,7 +600,7 @@ def forward(P, feats, num_blocks, dconf=(0.1, 0.1, 20.0, 0.1, 1.5, 1000), tfmr_b
     if not save:
         return out, None
     return out, dict(feats=f, embed=sv_embed, stages=stages, heads=sv_h, B=B, N=N, num_blocks=num_blocks,
-                     bool_mask=tfmr_bool_mask, mask=mask, dmask=dmask)
+                     bool_mask=tfmr_bool_mask, mask=mask, dmask=dmask, planes=planes)
 
 
 def backward(P, G, sv, d_out, on_done=None):
@@ -615,12 +619,15 @@ def backward(P, G, sv, d_out, on_done=None):
     # every zero-initialised accumulator of the pass from one memset (per block: the node-term sums of the edge transition
     # [R,2*(128+384)], du0, ds, dframe, ...: ~R * 1,650 floats; IPA's dproj [R,6816] is assigned, not accumulated)
     ops.reset_dw_queue()        # nothing an interrupted earlier pass queued may leak into this one's gradients
+    ops.set_weight_planes(sv.get("planes"))     # the forward's split of the parameter buffer (the weights have not changed since)
     try:
         with ops.zero_arena(R * (nb * 2048 + 1024) + 65536 if opts.zero_arena else 0, dev):
             _backward(P, G, sv, d_out, notify, hooked)
     except BaseException:
         ops.reset_dw_queue()
         raise
+    finally:
+        ops.set_weight_planes(None)
 
 
 def _backward(P, G, sv, d_out, notify, hooked=False):

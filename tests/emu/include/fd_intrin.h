@@ -24,6 +24,9 @@ struct f32x4 {
 
 namespace fd {
 
+// 16 bytes moved as one unit (the device header: a native vector type)
+struct alignas(16) u32x4 { unsigned v[4]; };
+
 static inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
   struct AB { float a, b; } ab{a, b};
   auto tab = hipemu::wave_exchange(&ab, sizeof(ab));

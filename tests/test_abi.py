@@ -42,7 +42,7 @@ def test_product_library_exports_every_symbol():
         build.build(verbose=False)
     lib = hip.FdLib(hip.LIB_PATH)            # binds every symbol; AttributeError if one is missing
     assert lib.backend == "gfx950"
-    assert lib.cdll.fd_abi_version() == 1
+    assert lib.cdll.fd_abi_version() == hip.ABI_VERSION == 2
     # built without the probe switch: none of the timing / ablation hooks of the kernel sources (csrc/fd_probe.h) is in it
     assert lib.cdll.fd_build_flags() == b""
     for s in header_symbols():

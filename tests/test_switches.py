@@ -39,8 +39,13 @@ def _step(dev, B, N, blocks, **kw):
         cb = {k: v.cpu() for k, v in batch.items()}
         gt37, _ = fo.backbone_atoms(cb["rigids_0"][..., :4], cb["rigids_0"][..., 4:], cb["torsion_angles_sin_cos"][..., 2, :])
         opt.zero_grad()
-        loss = ts.dsm_loss(batch, m(batch), gt37.to(dev))
+        out = m(batch)
+        from se3_diffusion_amd import ops
+        # (FlatAdam: one flat parameter buffer -> the forward split it, unless the option or exact-fp32 mode says no)
+        assert (ops._PLANES is not None) == bool(options.opts.weight_planes and not ops.lib().exact_f32)
+        loss = ts.dsm_loss(batch, out, gt37.to(dev))
         loss.backward()
+        assert ops._PLANES is None            # (released at the end of the backward)
         return float(loss.detach()), {n: p.grad.detach().double().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}
 
 
@@ -58,6 +63,7 @@ GROUPS = [
     (dict(zero_arena=False, dx_splitk=False, grad_stream=False), 1e-4),
     (dict(grouped_pair_dw=False), 1e-4),
     (dict(grouped_node_dw=False), 1e-4),
+    (dict(weight_planes=False), 1e-4),        # node-level GEMMs on pre-split weight planes (fd_gemm tiles 12-14) vs tiles 2 / 4 / 10
     (dict(defer_node_dw=False), 1e-4),        # the grouped launch at the end of its own block instead of behind the next fused backward
     (dict(fused_embed_bwd=False), 1e-4),
     (dict(zb_from_edge=False), 1e-4),
