@@ -14,6 +14,7 @@ from the UNMODIFIED reference (model/score_network.py:170-215, experiments/train
                   config/inference.yaml) of the unmodified Experiment.inference_fn at B=1 x N=128; every 10th step's frames are
                   stored, and instead of the 3 MB of normal draws the state of numpy's global generator at the first
                   diffuser.reverse call (the generator checks that the draws of all 500 calls are consecutive from it)
+    traj_n256_t500  BASELINE.json configs[2] exactly ("500 steps, N=256"): the same at B=1 x N=256 (631 s of reference CPU time)
 
 Run in the build container only (needs /root/reference):  python oracle/make_golden_full.py
 The oracle (oracle/framediff_oracle.py) is pinned against the same runs (PINNING_REPORT_FULL.txt).

@@ -526,7 +526,11 @@ def _edge_sched(like, stream):
         key = int(stream or 0)
         slot = slots.get(key)
         if slot is None:
-            slot = slots[key] = len(slots) % (_SCHED_WORDS // 4)     # (4-word stride: 16-byte aligned words)
+            if len(slots) >= _SCHED_WORDS // 4:
+                # (never wrap: two streams sharing a word would skip / duplicate tiles of concurrent launches without an error)
+                raise RuntimeError(f"ops._edge_sched: more than {_SCHED_WORDS // 4} streams have used the dynamic tile hand-out on "
+                                   f"{like.device}; raise ops._SCHED_WORDS")
+            slot = slots[key] = len(slots)                           # (4-word stride: 16-byte aligned words)
         STATS["edge_dynamic_launches"] += 1
     return buf.data_ptr() + 16 * slot
 

@@ -40,7 +40,12 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
     """Run the reverse process on `feats` (from init_feats).  noise_fn(step, shape) -> (z_rot, z_trans) injects
     draws (e.g. the numpy stream, for trajectory parity); default draws on the device.
     Returns dict(rigids [B,N,7], atom37 [B,N,37,3], psi, (rigid_traj list)).  `stats` (a dict) receives loop_ms = device
-    time of the reverse loop itself (HIP events; excludes the one-off warm-up + graph capture) and its step count."""
+    time of the reverse loop itself (HIP events; excludes the one-off warm-up + graph capture) and its step count.
+
+    Random stream: with device-drawn noise the graph path (options.sampler_device_steps) fills the draws of 50 steps with ONE
+    normal_ launch on a [50, 2, B, N, 3] buffer, the eager path draws [2, B, N, 3] per step: for one generator seed the two paths
+    consume the Philox stream differently and give different (equally distributed) trajectories.  Injected noise (noise_fn) is
+    consumed in step order on both paths -- that is what the trajectory parity tests compare."""
     dev = feats["rigids_t"].device
     B, N = feats["res_mask"].shape
     steps = np.linspace(min_t, 1.0, num_t)[::-1]
@@ -85,6 +90,14 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
     # reference quirk kept (train_se3_diffusion.py:753-756 vs :763-765): `self_condition` gates only the initial extra
     # forward; the per-step sc_ca_t update depends on the MODEL's embed_self_conditioning flag alone
     embed_sc = bool(getattr(getattr(getattr(model, "_model_conf", None), "embed", None), "embed_self_conditioning", True))
+    # The heads kernel of THIS package's ScoreNetwork can write the predicted CA positions straight into st["sc_ca_t"]
+    # (module attribute _fd_sc_ca_out, read by _ScoreNetFn.forward); any other callable -- a wrapper (DDP, a stub in a test) that
+    # does not reach that code -- gets the explicit copy after its forward.  The first forward checks that the kernel really wrote.
+    from .model.score_network import ScoreNetwork as _SN
+    inner = model
+    while not isinstance(inner, _SN) and isinstance(getattr(inner, "module", None), torch.nn.Module):
+        inner = inner.module
+    sc = dict(kernel=bool(embed_sc and isinstance(inner, _SN)), checked=False, on=False)
 
     # Device-side step bookkeeping (graph replays with device-drawn noise): the captured step starts with fd_sample_advance,
     # which takes t, {g_rot(t), b(t)} and the step's draws from device arrays indexed by a device counter -- no fill_ / copy_ /
@@ -96,7 +109,15 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
         if adv is not None:
             lib.call("fd_sample_advance", adv["counter"], adv["all_t"], all_tp, adv["z_all"], NOISE_STEPS, z_both.numel(),
                      st["t"], B, tparams, z_both)
-        out = model(st)      # (embed_sc: the heads kernel writes the predicted CA positions into st["sc_ca_t"] itself: _fd_sc_ca_out)
+        out = model(st)      # (sc["kernel"]: the heads kernel writes the predicted CA positions into st["sc_ca_t"] itself)
+        if embed_sc and sc["on"]:
+            if sc["kernel"] and not sc["checked"] and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+                sc["checked"] = True
+                if not torch.equal(st["sc_ca_t"], out["rigids"][..., 4:].to(torch.float32)):
+                    sc["kernel"] = False            # (the attribute was not honoured: fall back to the copy, for good)
+                    inner.__dict__.pop("_fd_sc_ca_out", None)
+            if not sc["kernel"]:
+                st["sc_ca_t"].copy_(out["rigids"][..., 4:])
         # (in place: fd_se3_reverse_step reads every row it needs for the centring mean before it writes any)
         diffuser.reverse_device(st["rigids_t"], out["rot_score"], out["trans_score"], 0.5, dt, diffuse_mask=diffuse_mask,
                                 center=center, noise_scale=noise_scale, noise=(z_rot, z_trans), tparams=tparams,
@@ -112,9 +133,13 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
             # from here on every forward leaves its predicted CA positions in st["sc_ca_t"] (an input of the NEXT forward; this
             # forward's own readers -- the edge embedder's distogram -- are launched before the heads kernel that writes it)
             st["sc_ca_t"] = st["sc_ca_t"].to(torch.float32).contiguous()
-            model._fd_sc_ca_out = st["sc_ca_t"]
+            if sc["kernel"]:
+                inner._fd_sc_ca_out = st["sc_ca_t"]
+        sc["on"] = True
         graph = None
         n_rev = int(np.sum(steps > min_t))
+        # (the device step counter of fd_sample_advance equals the loop index only because every reverse step precedes the final one)
+        assert bool(np.all(steps[:n_rev] > min_t)) and n_rev >= len(steps) - 1
         if use_graph and lib.is_device and n_rev > 3:
             # warm up on a side stream (allocator, lazily-built constant tables), then capture one step
             saved = {k: st[k].clone() for k in ("rigids_t", "sc_ca_t")}
@@ -175,7 +200,7 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
     finally:
         # an exception mid-trajectory must not leave the weight-derived cache, eval mode or the profiling switch behind
         model.__dict__.pop("_fd_static", None)
-        model.__dict__.pop("_fd_sc_ca_out", None)
+        inner.__dict__.pop("_fd_sc_ca_out", None)
         from . import ops as _ops
         _ops.join()                      # (options.graph_fork: nothing of an interrupted forward stays referenced on the branch)
         if was_training:

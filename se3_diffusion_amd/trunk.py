@@ -182,9 +182,10 @@ def edge_transition_bwd(P, G, b, sv, dz2, dz, dn3, dzb_next=None, flush_behind_l
     L = lib()
     W1, W2, Wf = P[f"{pre}.trunk.0.weight"], P[f"{pre}.trunk.2.weight"], P[f"{pre}.final_layer.weight"]
     z, e, h1, h2 = sv["z"], sv["e"], sv["h1"], sv["h2"]
-    # the fused dX kernel gates on the packed masks the FUSED forward wrote; a forward that ran unfused (exact-fp32 mode switched
-    # on in between) is followed by the unfused backward
-    fused = fused_edge() and sv.get("mh1") is not None
+    # which backward runs is decided by what the FORWARD saved, not by the options of this moment: the fused dX kernel gates on the
+    # packed masks the fused forward wrote, and that forward's h2 save carries the residual z (h2_has_z) -- only the fused backward
+    # can consume it; a forward that ran unfused is followed by the unfused backward
+    fused = sv.get("mh1") is not None and (fused_edge() or bool(sv.get("h2_has_z")))
     h2_has_z = bool(sv.get("h2_has_z"))      # the fused forward saved h2 + [z | 0 | 0] (the operand of dWf), not h2
     assert fused or not h2_has_z, "a fused edge-transition forward needs the fused backward (its h2 save carries z)"
     fused_ln = fused and opts.fused_ln_bwd and (dzb_next is None or dzb_next[1].is_contiguous())

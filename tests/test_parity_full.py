@@ -47,6 +47,8 @@ TOL_TRAJ50 = (1.5e-4, 1.5e-3, 1e-4)
 # perturbation of its input frames 6-8 x: measured 1.4e-3 / 1.6e-3 A there (6 of 128 residues above 1e-4, median 1e-5), psi 6.4e-5;
 # eager = graph-replayed (profiles/r05_traj500_error_growth.txt, tools/probes/traj500_probe.py)
 TOL_TRAJ500 = (5e-3, 1.5e-2, 6e-4)
+# ... and the 499 chained reverse steps on their own (every compared step but the last): 3 x the measured 1.6e-5 / 1.4e-4 A
+TOL_TRAJ500_CHAIN = (5e-5, 5e-4)
 TOL_GSIG = 2e-3       # gradient signatures (sum, norm) of the reference's large tensors
 
 
@@ -327,7 +329,8 @@ def test_reference_golden_n512(hip_lib):
 
 
 # 5-step trajectories: measured worst 4.2e-5 (rotation matrices), 9e-4 A (translations, B=2 x N=512), 1e-5 (psi)
-def _trajectory(fixture, use_graph, tol_rot=4e-4, tol_trans=9e-3, tol_psi=1e-4):
+def _trajectory(fixture, use_graph, tol_rot=4e-4, tol_trans=9e-3, tol_psi=1e-4, tol_chain=None):
+    """tol_chain = (rot, trans): a tighter bound for every compared step except the last one (the network's own frame prediction)"""
     from se3_diffusion_amd import sampler, train_step as ts
     from se3_diffusion_amd.data import se3_diffuser, utils as du
     from se3_diffusion_amd.model.score_network import ScoreNetwork
@@ -367,6 +370,10 @@ def _trajectory(fixture, use_graph, tol_rot=4e-4, tol_trans=9e-3, tol_psi=1e-4):
             parity_log.out("trans_angstrom_abs", et)
             assert er < tol_rot, (i, growth)
             assert et < tol_trans, (i, growth)          # Angstrom (coordinates of +-30 A)
+            if tol_chain is not None and i != step_index[-1]:
+                parity_log.out("chain_rot_matrix_abs", er)
+                parity_log.out("chain_trans_angstrom_abs", et)
+                assert er < tol_chain[0] and et < tol_chain[1], (i, growth)
         ep = np.abs(out["psi"].cpu().numpy() - T["final_psi"]).max()
         parity_log.out("psi_abs", ep)
         assert ep < tol_psi
@@ -411,4 +418,15 @@ def test_reference_trajectory_n128_500_steps(hip_lib, use_graph):
     g(t) / b(t) sequence than the 5- and 50-step fixtures) of the UNMODIFIED Experiment.inference_fn at B=1 x N=128
     (experiments/train_se3_diffusion.py:746-781; fixture traj_n128_t500, oracle/make_golden_full.py::traj_via_experiment), the
     reference's noise stream injected, eager and hipGraph-replayed.  Every 10th step is compared; error growth is printed."""
-    _trajectory("traj_n128_t500", use_graph, tol_rot=TOL_TRAJ500[0], tol_trans=TOL_TRAJ500[1], tol_psi=TOL_TRAJ500[2])
+    _trajectory("traj_n128_t500", use_graph, tol_rot=TOL_TRAJ500[0], tol_trans=TOL_TRAJ500[1], tol_psi=TOL_TRAJ500[2],
+                tol_chain=TOL_TRAJ500_CHAIN)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_reference_trajectory_n256_500_steps(hip_lib, use_graph):
+    """BASELINE.json configs[2] EXACTLY: reverse-diffusion inference, 500 steps, N=256 -- 500 reverse steps (501 forwards) of the
+    UNMODIFIED Experiment.inference_fn at B=1 x N=256 (fixture traj_n256_t500, oracle/make_golden_full.py::traj_via_experiment;
+    631 s of reference CPU time), the reference's noise stream injected, eager and hipGraph-replayed; every 10th step compared, the
+    chained reverse steps against their own tight bound, the last step (the network's frame prediction) separately."""
+    _trajectory("traj_n256_t500", use_graph, tol_rot=TOL_TRAJ500[0], tol_trans=TOL_TRAJ500[1], tol_psi=TOL_TRAJ500[2],
+                tol_chain=TOL_TRAJ500_CHAIN)

@@ -20,12 +20,39 @@ from se3_diffusion_amd.data import se3_diffuser  # noqa: E402
 T = np.load(os.path.join(ROOT, "tests", "golden", "traj.npz"))
 
 
-def _run(dev):
+class _Opaque(torch.nn.Module):
+    """a model the sampler cannot see through (no .module, not a ScoreNetwork): its self-conditioning input has to be updated by
+    the loop's explicit copy, not by the heads kernel (the kernel-side write was the only path)"""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+        self._model_conf = net._model_conf
+
+    def forward(self, feats):
+        return self.net(feats)
+
+
+class _Wrapped(torch.nn.Module):
+    """DDP-style wrapper: the sampler unwraps .module and lets the heads kernel write sc_ca_t"""
+
+    def __init__(self, net):
+        super().__init__()
+        self.module = net
+        self._model_conf = net._model_conf
+
+    def forward(self, feats):
+        return self.module(feats)
+
+
+def _run(dev, wrap=None):
     diff = se3_diffuser.SE3Diffuser(dconf())
     blocks = int(T["blocks"])
     m = ScoreNetwork(ts.base_model_conf(blocks), diff)
     m.load_state_dict(fo.synth_params(seed=int(T["seed"]), conf=dict(fo.CONF, num_blocks=blocks)), strict=True)
     m = m.to(dev).eval()
+    if wrap is not None:
+        m = wrap(m)
     B, N = int(T["B"]), int(T["N"])
     feats = sampler.init_feats(diff, B, N, dev, noise=(T["init_randn"], T["init_rand"], T["init_normal"]))
     ref0 = T["rig_init"]
@@ -45,6 +72,12 @@ def _run(dev):
 
 def test_trajectory_emu(use_emu):
     _run("cpu")
+
+
+@pytest.mark.parametrize("wrap", [_Opaque, _Wrapped])
+def test_trajectory_wrapped_model_emu(use_emu, wrap):
+    """the same trajectory through a model wrapper: self-conditioning must still be updated every step"""
+    _run("cpu", wrap)
 
 
 @pytest.mark.gpu
