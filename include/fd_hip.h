@@ -442,6 +442,14 @@ int fd_ipa_flash_bwd(const float* proj, const float* A, const float* zb, const f
                      const float* doptg, const float* ptdot, const float* qp, const float* kp, const float* vp,
                      const float* head_w, const float* trans, float* dL, float* dzb, float* dqp, float* dkp,
                      float* dhead_w, float* hw_part, int B, int N, void* stream);
+/* KEY side of the same backward in one launch (se3_diffusion_amd/csrc/fd_ipa_flash.hip, ipa_flash_bwd_keys_kernel): autograd of
+ * model/ipa_pytorch.py:380-457 with respect to keys / values and their points, from the probabilities A and the logit gradient dL
+ * ([B,8,N,N] each, read once):  dproj[:, 2048 + 512 h + 256 ..] = dV = A^T dO;  dproj[:, 2048 + 512 h ..] = dK = sqrt(1/3C) dL^T Q;
+ * dvp [R,8,36] = A^T doptg;  dkp [R,8,24] = gamma_h sum_i dL_ij (qp_i - kp_j).  Replaces three batched fd_gemm launches and
+ * fd_ipa_kpts_bwd (pass dkp = NULL to fd_ipa_flash_bwd to skip its own fd_ipa_kpts_bwd).  heads_per_block: 0 = by size, 2 / 4 / 8. */
+int fd_ipa_flash_bwd_keys(const float* A, const float* dL, const float* proj, const float* dfeats, const float* doptg,
+                          const float* qp, const float* kp, const float* head_w, float* dproj, float* dvp, float* dkp,
+                          int B, int N, int heads_per_block, void* stream);
 /* fd_ipa_opt_bwd that also returns ptdot [R, 8] = sum_p d(o_pt, global frame) . (o_pt, global frame) per head (the o_pt term
  * of the softmax backward's row constant; model/ipa_pytorch.py:432-449) */
 int fd_ipa_opt_bwd_dot(const float* dfeats, const float* feats, const float* quat, const float* trans, float* doptg,

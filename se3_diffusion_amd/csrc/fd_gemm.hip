@@ -36,6 +36,7 @@ struct GemmArgs {
   int ksplit;
   int mtiles;   // consecutive M tiles pipelined by one block
   int epi_vec;  // 16-byte epilogue through LDS (needs mtiles == 1 and 4-element aligned C / gate / resid / pair)
+  int raster;   // tiles 12-14: 1 = consecutive blocks walk the M tiles of one column block (see launch_w)
   int zbatch;   // > 0: the batch index rides in blockIdx.x (grid.x = tiles x zbatch), XCD-swizzled over the WHOLE grid so that
                 // the tiles of one batch element -- which re-read its A rows / B columns -- share an XCD's L2
 };

@@ -885,6 +885,144 @@ __global__ __launch_bounds__(HPB * 64) void ipa_flash_bwd_kernel(FlashBwdArgs a)
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// KEY side of the IPA attention backward as one kernel (round 6): autograd of model/ipa_pytorch.py:380-457 with respect to the
+// keys, the values and their points --
+//   dV_j   = sum_i A_ij dO_i              (:424-428)          dv_pts_j = sum_i A_ij dO_pt_i          (:432-441, global frame)
+//   dK_j   = sqrt(1/3C) sum_i dL_ij Q_i   (:380-384)          dk_pts_j = gamma sum_i dL_ij (q_pts_i - k_pts_j)   (:398-412)
+// from the probabilities A (the forward's) and the logit gradient dL (the query-side kernel's), both [B, 8, N, N].  Replaces three
+// batched fp32 GEMMs over those tensors (A^T dO, A^T dO_pt, dL^T Q) and fd_ipa_kpts_bwd of network.ipa_bwd: A and dL are read
+// once here instead of three times each, dO / Q stream from L2 as MFMA operands, nothing is staged through LDS.
+// Decomposition: a block owns a tile of 16 KEYS of one backbone and HPB heads, one wave per head (the key side has no sum over
+// heads, so any HPB works); it walks the query tiles.  Per query tile and wave (v_mfma_f32_16x16x4_f32, exact fp32 products,
+// transposed accumulation X^T[channel, key] += operand^T[channel, query] P[query, key] -- the forward's O^T += V^T P^T with the
+// roles of queries and keys exchanged):
+//   dV^T 64 + dV_pts^T 16 + dK^T 64 + [sum_i dL q_pts ; sum_i dL] 16 MFMAs; the operand of k-step r is the query row 4 kk + r of
+//   the tile, channels 64 c + 4 m + q of lane (m = lane & 15, kk = lane >> 4) feed output tile 4 c + q, so every operand load is a
+//   float4 along the channels and every lane ends up with 16 consecutive channels of its key per 64-channel group (float4 stores).
+// 160 accumulator registers + one operand set in flight: two waves per SIMD.
+struct FlashKeysArgs {
+  const float *A, *dL, *proj, *dfeats, *doptg, *qp, *kp, *head_w;
+  float *dproj, *dvp, *dkp;
+  int B, N;
+};
+
+template <int HPB>
+__global__ __launch_bounds__(HPB * 64, 2) void ipa_flash_bwd_keys_kernel(FlashKeysArgs a) {
+  constexpr int NG = H / HPB;
+  const int N = a.N;
+  const int nti = (N + TI - 1) / TI;
+  const int lid = fd_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+  const int g = lid % NG, jt = (lid / NG) % nti, b = lid / (NG * nti);
+  const int lane = fd::lane_id();
+  const int wave = fd::uniform(fd::wave_id());
+  const int n = lane & 15, kk = lane >> 4;
+  const int h = g * HPB + wave;
+  const int j0 = jt * TI;
+  const long rb = (long)b * N;
+  const int jn = imin(j0 + n, N - 1);                         // this lane's key (clamped; keys past N are not stored)
+  const bool key_ok = j0 + n < N;
+  const float sc = sqrtf(1.0f / (3.0f * (float)C));
+  const float gamma = softplus_f(a.head_w[h]) * sqrtf(1.0f / (3.0f * ((float)PQ * 9.0f / 2.0f)));
+
+  f32x4 dV[C / 16], dK[C / 16], dP[4], dX[4];
+#pragma unroll
+  for (int c = 0; c < C / 16; ++c) { dV[c] = zero4(); dK[c] = zero4(); }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { dP[c] = zero4(); dX[c] = zero4(); }
+
+  const float* __restrict__ Ab = a.A + ((long)b * H + h) * N * N + jn;        // column jn of the head's [N, N] block
+  const float* __restrict__ Lb = a.dL + ((long)b * H + h) * N * N + jn;
+  const float* __restrict__ dOb = a.dfeats + rb * LDF + h * C + 4 * n;         // channels 64 c + 4 n + q of a query row
+  const float* __restrict__ Qb = a.proj + rb * LDP + h * C + 4 * n;
+  const float* __restrict__ dGb = a.doptg + (rb * H + h) * (PV * 3) + 4 * n;   // 36 floats per (row, head): lanes n < 9
+  const float* __restrict__ qpb = a.qp + (rb * H + h) * (PQ * 3) + 4 * n;      // 24 floats: lanes n < 6; lane 6 carries the 1 of sum_i dL
+
+  // operands of one k-step = one query row per lane group, requested a row ahead of the MFMAs that consume them (two named
+  // register sets of native vectors: a struct of HIP float4s copied whole goes through scratch memory)
+  auto ldv = [](const float* p) -> f32x4 { return *reinterpret_cast<const f32x4*>(p); };
+  auto request = [&](int i, f32x4 (&o)[4], f32x4 (&q)[4], f32x4& gp, f32x4& pp, float& pa, float& pl) __attribute__((always_inline)) {
+    const bool ok = i < N;                                  // (a row past N: clamped address, weight zero)
+    const unsigned ic = (unsigned)imin(i, N - 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      o[c] = ldv(dOb + ic * LDF + 64 * c);
+      q[c] = ldv(Qb + ic * LDP + 64 * c);
+    }
+    f32x4 z = zero4();
+    gp = n < 9 ? ldv(dGb + ic * (H * PV * 3)) : z;
+    z[0] = n == 6 ? 1.f : 0.f;
+    pp = n < 6 ? ldv(qpb + ic * (H * PQ * 3)) : z;
+    const float va = Ab[(long)ic * N], vl = Lb[(long)ic * N];
+    pa = ok ? va : 0.f;
+    pl = ok ? vl : 0.f;
+  };
+  auto multiply = [&](const f32x4 (&o)[4], const f32x4 (&q)[4], const f32x4& gp, const f32x4& pp, float pa, float pl)
+                      __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dV[4 * c + e] = fd::mfma_16x16x4(o[c][e], pa, dV[4 * c + e]);
+        dK[4 * c + e] = fd::mfma_16x16x4(q[c][e], pl, dK[4 * c + e]);
+      }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dP[e] = fd::mfma_16x16x4(gp[e], pa, dP[e]);
+      dX[e] = fd::mfma_16x16x4(pp[e], pl, dX[e]);
+    }
+  };
+
+  // k-step s of the walk contracts the query rows {4 s + kk' : kk' = 0..3}: lane group kk supplies row 4 s + kk
+  const int nsteps = 4 * nti;                               // (even)
+  f32x4 oA[4], qA[4], gA, pA, oB[4], qB[4], gB, pB;
+  float paA, plA, paB, plB;
+  request(kk, oA, qA, gA, pA, paA, plA);
+#pragma unroll 1
+  for (int s = 0; s < nsteps; s += 2) {
+    request(4 * (s + 1) + kk, oB, qB, gB, pB, paB, plB);
+    multiply(oA, qA, gA, pA, paA, plA);
+    request(4 * (s + 2) + kk, oA, qA, gA, pA, paA, plA);
+    multiply(oB, qB, gB, pB, paB, plB);
+  }
+
+  // ---- epilogue.  D layout: register r of tile 4 c + q = channel 64 c + 4 (4 kk + r) + q of key n: the four tiles of a group give
+  // 16 consecutive channels 64 c + 16 kk + 4 r + q per lane
+  if (key_ok) {
+    float* __restrict__ dk = a.dproj + (rb + j0 + n) * LDP + KV_OFF + h * 2 * C + 16 * kk;
+    float* __restrict__ dv = dk + C;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        *reinterpret_cast<float4*>(dk + 64 * c + 4 * r) =
+            make_float4(sc * dK[4 * c][r], sc * dK[4 * c + 1][r], sc * dK[4 * c + 2][r], sc * dK[4 * c + 3][r]);
+        *reinterpret_cast<float4*>(dv + 64 * c + 4 * r) = make_float4(dV[4 * c][r], dV[4 * c + 1][r], dV[4 * c + 2][r], dV[4 * c + 3][r]);
+      }
+  }
+  // value points: floats 16 kk + 4 r + q < 36
+  if (key_ok) {
+    float* __restrict__ dvp = a.dvp + ((rb + j0 + n) * H + h) * (PV * 3) + 16 * kk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * kk + 4 * r < PV * 3) *reinterpret_cast<float4*>(dvp + 4 * r) = make_float4(dP[0][r], dP[1][r], dP[2][r], dP[3][r]);
+  }
+  // key points: dk_pts = gamma (sum_i dL q_pts - k_pts sum_i dL); the column sum is float 24 = tile 0, register 2 of lane group 1
+  const float csum = __shfl(dX[0][2], n + 16);
+  if (key_ok) {
+    const float* __restrict__ kpr = a.kp + ((rb + j0 + n) * H + h) * (PQ * 3) + 16 * kk;
+    float* __restrict__ dkp = a.dkp + ((rb + j0 + n) * H + h) * (PQ * 3) + 16 * kk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * kk + 4 * r < PQ * 3) {
+        const float4 kv = ld4(kpr + 4 * r);
+        *reinterpret_cast<float4*>(dkp + 4 * r) = make_float4(gamma * (dX[0][r] - kv.x * csum), gamma * (dX[1][r] - kv.y * csum),
+                                                              gamma * (dX[2][r] - kv.z * csum), gamma * (dX[3][r] - kv.w * csum));
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" int fd_ipa_flash_fwd(const float* proj, const float* zb, const float* qp, const float* kp, const float* vp,
@@ -949,5 +1087,32 @@ extern "C" int fd_ipa_flash_bwd(const float* proj, const float* A, const float* 
     int rc = fd_colsum_acc(hw_part, H, (long)B * N, H, dhead_w, stream);
     if (rc != FD_OK) return rc;
   }
+  if (dkp == nullptr) return FD_OK;        // (the key-side kernel, fd_ipa_flash_bwd_keys, forms dk_pts with dK / dV)
   return fd_ipa_kpts_bwd(dL, qp, kp, head_w, dkp, B, N, stream);
+}
+
+extern "C" int fd_ipa_flash_bwd_keys(const float* A, const float* dL, const float* proj, const float* dfeats, const float* doptg,
+                                     const float* qp, const float* kp, const float* head_w, float* dproj, float* dvp, float* dkp,
+                                     int B, int N, int heads_per_block, void* stream) {
+  FD_CHECK_ARG(N <= MAXN, "fd_ipa_flash_bwd_keys: N=%d exceeds %d", N, MAXN);
+  FD_CHECK_ARG(A && dL && proj && dfeats && doptg && qp && kp && head_w && dproj && dvp && dkp, "fd_ipa_flash_bwd_keys: null operand");
+  FD_CHECK_ARG(fd_aligned16(proj) && fd_aligned16(dfeats) && fd_aligned16(doptg) && fd_aligned16(qp) && fd_aligned16(kp) &&
+                   fd_aligned16(dproj) && fd_aligned16(dvp) && fd_aligned16(dkp),
+               "fd_ipa_flash_bwd_keys: tensor arguments must be 16-byte aligned");
+  FD_CHECK_ARG(heads_per_block == 0 || heads_per_block == 2 || heads_per_block == 4 || heads_per_block == 8,
+               "fd_ipa_flash_bwd_keys: heads_per_block must be 0 (pick), 2, 4 or 8, got %d", heads_per_block);
+  if (B == 0 || N == 0) return FD_OK;
+  const long tiles = (long)B * ((N + TI - 1) / TI);
+  int hpb = heads_per_block;
+  if (hpb == 0) hpb = N >= 256 ? 4 : 2;      // (measured, tools/bench_ipa_keys.py: B=12 x N=200 113 against 127 us, B=7 x N=256 114 against 132)
+  FlashKeysArgs a{A, dL, proj, dfeats, doptg, qp, kp, head_w, dproj, dvp, dkp, B, N};
+  const dim3 grid((unsigned)(tiles * (H / hpb)));
+  if (hpb == 8)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_flash_bwd_keys_kernel<8>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  else if (hpb == 4)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_flash_bwd_keys_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ipa_flash_bwd_keys_kernel<2>), grid, dim3(128), 0, (hipStream_t)stream, a);
+  FD_CHECK_LAUNCH("fd_ipa_flash_bwd_keys");
+  return FD_OK;
 }

@@ -208,6 +208,7 @@ _SIGS = {
     "fd_ipa_flash_fwd": "ppppppppppp" + "iiis",
     "fd_ipa_flash_fwd_split": "ppppppppppp" + "iiii" + "ps",
     "fd_ipa_flash_bwd": "pppppppppppp" + "pppppp" + "iis",
+    "fd_ipa_flash_bwd_keys": "pppppppp" + "ppp" + "iiis",
     "fd_ipa_opt_bwd_dot": "ppppppp" + "ls",
     "fd_seq_attn_fwd": "ppppfiis",
     "fd_ipa_attn_bwd": "pppppppppppppiis",

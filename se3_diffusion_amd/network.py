@@ -423,8 +423,9 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True, defer_dz=Fal
         ptdot = empty((R, H), dev)
         L.call("fd_ipa_opt_bwd_dot", dfeats, feats, quat, sv["trans"], doptg, dframe, ptdot, R)
         dA = empty((B, H, N, N), dev)          # receives dL
+        keys = bool(opts.flash_ipa_keys and N <= opts.flash_ipa_keys_max_n)       # the key side in one launch too, below
         L.call("fd_ipa_flash_bwd", proj, A, zb, dfeats, feats, doptg, ptdot, qp, kp, vp, P[f"{pre}.head_weights"], sv["trans"],
-               dA, dzb, dqp, dkp, dhw, hw_part, B, N)
+               dA, dzb, dqp, None if keys else dkp, dhw, hw_part, B, N)
     else:
         # dA = dO V^T
         dA = empty((B, H, N, N), dev)
@@ -441,18 +442,26 @@ def ipa_bwd(P, G, pre, sv, dx1, ds, dz, dframe, dz_accumulate=True, defer_dz=Fal
         else:
             L.call("fd_ipa_opair_bwd", A, zb, dfeats, dA, dzb, B, N)
             L.call("fd_ipa_softmax_bwd", A, dA, qp, kp, P[f"{pre}.head_weights"], dzb, dqp, dkp, dhw, hw_part, B, N)
-    # dV = A^T dO ; dvp = A^T dOpt
-    L.gemm(A, dfeats, dproj, N, C, N, (1, N), (LDF, 1), LDP, c_off=2048 + C, batch=B * H, bdiv=H,
-           a_bs=(H * N * N, N * N), b_bs=(N * LDF, C), c_bs=(N * LDP, 2 * C))
     dvp = empty((R, H, PV * 3), dev)
-    L.gemm(A, doptg, dvp, N, PV * 3, N, (1, N), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
-           a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
     sc = math.sqrt(1.0 / (3 * C))
+    keys = flash and bool(opts.flash_ipa_keys and N <= opts.flash_ipa_keys_max_n)
+    ops.STATS["ipa_flash_bwd_keys" if keys else "ipa_keys_gemms"] += 1
+    if keys:
+        # dV = A^T dO, dvp = A^T dOpt, dK = sc dL^T Q and dkp = gamma sum_i dL (qp_i - kp_j) of every (key tile, head) in ONE launch:
+        # A and dL are read once instead of three times each (fd_ipa_flash_bwd_keys)
+        L.call("fd_ipa_flash_bwd_keys", A, dA, proj, dfeats, doptg, qp, kp, P[f"{pre}.head_weights"], dproj, dvp, dkp, B, N, 0)
+    else:
+        # dV = A^T dO ; dvp = A^T dOpt
+        L.gemm(A, dfeats, dproj, N, C, N, (1, N), (LDF, 1), LDP, c_off=2048 + C, batch=B * H, bdiv=H,
+               a_bs=(H * N * N, N * N), b_bs=(N * LDF, C), c_bs=(N * LDP, 2 * C))
+        L.gemm(A, doptg, dvp, N, PV * 3, N, (1, N), (H * PV * 3, 1), H * PV * 3, batch=B * H, bdiv=H,
+               a_bs=(H * N * N, N * N), b_bs=(N * H * PV * 3, PV * 3), c_bs=(N * H * PV * 3, PV * 3))
     # dQ = sc * dL K ; dK = sc * dL^T Q
     L.gemm(dA, proj, dproj, N, C, N, (N, 1), (LDP, 1), LDP, b_off=2048, batch=B * H, bdiv=H,
            a_bs=(H * N * N, N * N), b_bs=(N * LDP, 2 * C), c_bs=(N * LDP, C), alpha=sc)
-    L.gemm(dA, proj, dproj, N, C, N, (1, N), (LDP, 1), LDP, c_off=2048, batch=B * H, bdiv=H,
-           a_bs=(H * N * N, N * N), b_bs=(N * LDP, C), c_bs=(N * LDP, 2 * C), alpha=sc)
+    if not keys:
+        L.gemm(dA, proj, dproj, N, C, N, (1, N), (LDP, 1), LDP, c_off=2048, batch=B * H, bdiv=H,
+               a_bs=(H * N * N, N * N), b_bs=(N * LDP, C), c_bs=(N * LDP, 2 * C), alpha=sc)
     L.call("fd_ipa_points_bwd", proj, quat, dqp, dkp, dvp, dproj, dframe, R, H, C, PQ, PV)
     # z path: dz += dzb W40 (streaming kernel, W40 resident in registers) ; dW40 += dzb^T z
     if defer_dz:

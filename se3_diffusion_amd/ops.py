@@ -495,7 +495,8 @@ def edge_mlp_pack_bwd(Wf, W2, W1, W40=None, out=None):
 _SCHED = {}
 _SCHED_LOCK = threading.Lock()
 # launches that took the dynamic tile hand-out since the process started (tests assert that the benchmarked step uses it)
-STATS = {"edge_dynamic_launches": 0, "ipa_flash_fwd": 0, "ipa_sequence_fwd": 0, "ipa_flash_bwd": 0, "ipa_sequence_bwd": 0}
+STATS = {"edge_dynamic_launches": 0, "ipa_flash_fwd": 0, "ipa_sequence_fwd": 0, "ipa_flash_bwd": 0, "ipa_sequence_bwd": 0,
+         "ipa_flash_bwd_keys": 0, "ipa_keys_gemms": 0}
 
 
 _SCHED_WORDS = 256           # counter words per device: one per (stream, launch site) that ever used the dynamic hand-out

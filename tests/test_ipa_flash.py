@@ -235,6 +235,61 @@ def test_ipa_flash_bwd_gpu(hip_lib):
             _run_bwd("cuda", B, N, seed, spread=spread, log=True)
 
 
+# --------------------------------------------------------------------------------------------------------- backward, key side
+def _run_bwd_keys(dev, B, N, seed, hpb=0, tol=5e-6, log=False):
+    """fd_ipa_flash_bwd_keys (dV, dK, dv_pts, dk_pts of a block in one launch) against float64 contractions of the same A, dL --
+    autograd of model/ipa_pytorch.py:380-457 with respect to keys / values: dV = A^T dO, dvp = A^T dO_pt, dK = sqrt(1/3C) dL^T Q,
+    dkp = gamma sum_i dL_ij (qp_i - kp_j).  Columns of dproj the kernel does not own must stay untouched."""
+    L = ops.lib()
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *sh: torch.randn(*sh, generator=g).to(dev)
+    R = B * N
+    A = torch.softmax(rn(B, H, N, N), -1).contiguous()
+    dL = (rn(B, H, N, N) * 0.1).contiguous()
+    proj, dfeats, doptg = rn(R, LDP), rn(R, LDF), rn(R, H, PV * 3)
+    qp, kp, hw = rn(R, H, PQ * 3), rn(R, H, PQ * 3), rn(H)
+    dproj = torch.full((R, LDP), 7.0, device=dev)
+    dvp = torch.full((R, H, PV * 3), float("nan"), device=dev)
+    dkp = torch.full((R, H, PQ * 3), float("nan"), device=dev)
+    L.call("fd_ipa_flash_bwd_keys", A, dL, proj, dfeats, doptg, qp, kp, hw, dproj, dvp, dkp, B, N, hpb)
+    d = lambda t: t.double().cpu()
+    A6, dL6 = d(A), d(dL)
+    dO = d(dfeats)[:, :H * C].view(B, N, H, C)
+    Q = d(proj)[:, :H * C].view(B, N, H, C)
+    ref_dV = torch.einsum("bhij,bihc->bjhc", A6, dO)
+    ref_dK = math.sqrt(1.0 / (3 * C)) * torch.einsum("bhij,bihc->bjhc", dL6, Q)
+    ref_dvp = torch.einsum("bhij,bihc->bjhc", A6, d(doptg).view(B, N, H, PV * 3))
+    gamma = torch.nn.functional.softplus(d(hw)) * math.sqrt(1.0 / (3 * (PQ * 9.0 / 2)))
+    qp6, kp6 = d(qp).view(B, N, H, PQ * 3), d(kp).view(B, N, H, PQ * 3)
+    ref_dkp = gamma[None, None, :, None] * (torch.einsum("bhij,bihc->bjhc", dL6, qp6) - kp6 * dL6.sum(2).permute(0, 2, 1)[..., None])
+    kv = d(dproj)[:, 2048:2048 + 2 * H * C].view(B, N, H, 2, C)
+    errs = {}
+    for name, got, ref in (("dK", kv[..., 0, :], ref_dK), ("dV", kv[..., 1, :], ref_dV), ("dvp", d(dvp).view(B, N, H, -1), ref_dvp),
+                           ("dkp", d(dkp).view(B, N, H, -1), ref_dkp)):
+        assert bool(torch.isfinite(got).all()), name
+        errs[name] = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+        if log:
+            parity_log.out(f"flash_bwd_keys.{name}", errs[name])
+    other = torch.cat([d(dproj)[:, :2048], d(dproj)[:, 2048 + 2 * H * C:]], 1)
+    assert bool((other == 7.0).all()), "columns outside dK / dV were written"
+    for k, e in errs.items():
+        assert e < tol, (k, e, errs)
+    return errs
+
+
+def test_ipa_flash_bwd_keys_emu(use_emu):
+    _run_bwd_keys("cpu", 1, 16, 0, hpb=2)
+    _run_bwd_keys("cpu", 2, 37, 1, hpb=4)        # ragged: rows and keys past N
+    _run_bwd_keys("cpu", 1, 18, 2, hpb=8)
+
+
+@pytest.mark.gpu
+def test_ipa_flash_bwd_keys_gpu(hip_lib):
+    with parity_log.case("ipa_flash_bwd_keys"):
+        for (B, N, seed, hpb) in ((2, 128, 0, 0), (30, 128, 1, 0), (3, 100, 2, 2), (1, 257, 3, 4), (2, 400, 4, 8), (1, 512, 5, 0)):
+            _run_bwd_keys("cuda", B, N, seed, hpb=hpb, log=True)
+
+
 # ------------------------------------------------------------------------------------------------- inside the network forward
 def _forward_paths(dev, B, N, blocks=2):
     """the eval-mode ScoreNetwork forward with IPA attention as (a) the launch sequence, (b) the one-launch kernel, (c) the

@@ -60,6 +60,7 @@ GROUPS = [
     (dict(flash_ipa=False), 1e-4),            # fd_ipa_flash_fwd (probabilities written for the backward) vs the launch sequence
     (dict(flash_ipa_hpb=2), 1e-4),            # (its 2-heads-per-block shape against the default pick)
     (dict(flash_ipa_bwd=False), 1e-4),        # fd_ipa_flash_bwd vs dA GEMMs + fd_ipa_attn_bwd
+    (dict(flash_ipa_keys=False), 1e-4),       # fd_ipa_flash_bwd_keys vs the dV / dv_pts / dK GEMMs + fd_ipa_kpts_bwd
     (dict(zero_arena=False, dx_splitk=False, grad_stream=False), 1e-4),
     (dict(grouped_pair_dw=False), 1e-4),
     (dict(grouped_node_dw=False), 1e-4),
