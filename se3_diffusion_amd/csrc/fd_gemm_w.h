@@ -26,6 +26,9 @@
 //     row, the epilogue (bias / ReLU / gate / row scale / residual / old C) moves float4s between registers and memory
 //     (store_tile_t); split-K launches accumulate row-major and add their partial tiles atomically (store_tile).
 // Needs: A k-contiguous, K % 16 == 0, 16-byte aligned operands, un-batched, B unit-stride along k (KC) or along n (N % 8 == 0).
+#ifdef GW_RING
+#include "fd_probe.h"
+#endif
 #ifdef GW_ABL               // timing-only ablations (WRONG RESULTS by design): 1 no loop loads, 2 no LDS writes, 4 no split, 8 no MFMAs,
 #include "fd_probe.h"       // 16 no epilogue, 32 no fragment reads -- tools/probes builds only (-DFD_PROBE_BUILD)
 #else
@@ -43,16 +46,21 @@ struct WCfg {
   static constexpr int B_PLANE = B_KC ? BN * 32 : (BN / 32) * W_TR_PST;
   static constexpr int B_BYTES = 3 * B_PLANE;
   static constexpr int STAGE = A_BYTES + B_BYTES;
+#ifdef GW_RING
+  static constexpr int RING = GW_RING;                      // (probe builds: ring depth A/B)
+#else
   static constexpr int RING = 3;
+#endif
   static constexpr int LDS = RING * STAGE;
   static constexpr int NIA = BM / 16;                       // LDS-DMA wave-instructions (1 KB each) of A per stage
   static constexpr int NIB = 3 * BN / 32;                   // ... of the three B planes
   static constexpr int NPW = (NIA + NIB + 3) / 4;           // per wave (a wave whose share is short repeats a piece)
-  static_assert(2 * LDS <= 160 * 1024, "two blocks per CU");
+  static constexpr int BLOCKS_PER_CU = 2 * LDS <= 160 * 1024 ? 2 : 1;
+  static_assert(LDS <= 160 * 1024, "LDS");
 };
 
 template <int BM, int BN, bool B_KC, bool TRANS>
-__global__ __launch_bounds__(256, 2) void gemm_w_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (WCfg<BM, BN, B_KC>::BLOCKS_PER_CU)) void gemm_w_kernel(GemmArgs g) {
   using Cfg = WCfg<BM, BN, B_KC>;
   constexpr int TM = Cfg::TM, TN = Cfg::TN, NPW = Cfg::NPW, NIA = Cfg::NIA, NIB = Cfg::NIB;
   constexpr int B_PLANE = Cfg::B_PLANE, A_BYTES = Cfg::A_BYTES, STAGE = Cfg::STAGE;
@@ -198,30 +206,26 @@ __global__ __launch_bounds__(256, 2) void gemm_w_kernel(GemmArgs g) {
     }
   };
 
-  // stage s lives in ring slot s % 3 and is copied two stages before it is multiplied.  The vector-memory counter retires in issue
-  // order and the loop issues nothing but these copies: vmcnt(NPW) at the end of a stage = the next stage has landed, the one behind
-  // it stays in flight; __syncthreads() (lgkmcnt(0) + s_barrier) publishes it and frees the slot the next copy overwrites
-  char* const S0 = lds;
-  char* const S1 = lds + STAGE;
-  char* const S2 = lds + 2 * STAGE;
-  copy(S0);
-  copy(S1);
-  fd::wait_vmem_keep<NPW>();
+  // stage s lives in ring slot s % RING and is copied RING - 1 stages before it is multiplied.  The vector-memory counter retires in
+  // issue order and the loop issues nothing but these copies: vmcnt((RING - 2) NPW) at the end of a stage = the next stage has
+  // landed, the RING - 2 behind it stay in flight; __syncthreads() (lgkmcnt(0) + s_barrier) publishes it and frees the slot the
+  // next copy overwrites
+  constexpr int RING = Cfg::RING;
+  int wslot = 0, rslot = 0;
+#pragma unroll
+  for (int u = 0; u < RING - 1; ++u) {
+    copy(lds + wslot * STAGE);
+    wslot = wslot + 1 == RING ? 0 : wslot + 1;
+  }
+  fd::wait_vmem_keep<(RING - 2) * NPW>();
   __syncthreads();
-  for (int s = 0; s < nk; s += 3) {
-    copy(S2);
-    step(S0);
-    fd::wait_vmem_keep<NPW>();
-    __syncthreads();
-    if (s + 1 >= nk) break;
-    copy(S0);
-    step(S1);
-    fd::wait_vmem_keep<NPW>();
-    __syncthreads();
-    if (s + 2 >= nk) break;
-    copy(S1);
-    step(S2);
-    fd::wait_vmem_keep<NPW>();
+#pragma unroll 1
+  for (int s = 0; s < nk; ++s) {
+    copy(lds + wslot * STAGE);
+    wslot = wslot + 1 == RING ? 0 : wslot + 1;
+    step(lds + rslot * STAGE);
+    rslot = rslot + 1 == RING ? 0 : rslot + 1;
+    fd::wait_vmem_keep<(RING - 2) * NPW>();
     __syncthreads();
   }
   fd::wait_vmem();
@@ -267,6 +271,8 @@ int launch_w(const FdGemmDesc& d, hipStream_t stream) {
   g.ksplit = d.ksplit > 1 ? d.ksplit : 1;
   const int nkt_all = d.K / W_BK;
   if (g.ksplit > nkt_all) g.ksplit = nkt_all > 0 ? nkt_all : 1;
+  // (non-temporal stores of a large C -- 105 MB for IPA's projections -- measured: 181 against 115 us; the float4-per-row epilogue
+  //  lives on the L2's write combining)
   g.mtiles = 1;
   g.epi_vec = epilogue_vectorisable(d, g.ksplit);
   const bool b_kc = (d.b_rs == 1);
