@@ -321,6 +321,9 @@ def sampling_rates(dev, blocks, num_t_run, lib, cases=((128, 1, True), (128, 8, 
         out[f"N{N}_B{B}"] = {
             "backbones_per_s": round(B / (per_fwd * 501), 4), "ms_per_diffusion_step": round(per_fwd * 1e3, 3),
             "measured_steps": steps_run, "full_trajectory": bool(full),
+            # kernels of the library in one captured diffusion step = network forward + fd_sample_advance + fd_se3_reverse_step
+            # (fd_launch_count across the hipGraph capture, sampler.sample)
+            "kernels_per_step": st.get("kernels_per_step"), "kernels_per_forward": (st["kernels_per_step"] - 2) if st.get("kernels_per_step") else None,
             "frac_of_fp32_mfma_floor": round(floor / (per_fwd * 1e3), 4),
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "launches_per_forward": n_l // 3,

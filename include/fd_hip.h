@@ -28,6 +28,10 @@ const char* fd_backend(void);
 /* "" for a product build; "FD_PROBE_BUILD" when the library was built by tools/probes with the timing / ablation hooks of the
  * kernel sources enabled (csrc/fd_probe.h: those hooks do not compile in a product build). */
 const char* fd_build_flags(void);
+/* kernel launches this library has issued since it was loaded, including launches recorded into a hipGraph capture: the
+ * difference across one captured diffusion step (experiments/train_se3_diffusion.py:746-781: one ScoreNetwork forward + one reverse
+ * step) is the number of kernels a replay of that step runs. */
+long fd_launch_count(void);
 
 /* ---- dense: C = epi(alpha * A*B) --------------------------------------
  * Replaces torch Linear/matmul on the path: model/ipa_pytorch.py:101-166

@@ -11,6 +11,7 @@
 #define FD_ERR_UNSUPPORTED -3
 
 void fd_set_error(const char* fmt, ...);
+void fd_count_launch();      // one kernel launch issued by the library (fd_launch_count, include/fd_hip.h)
 
 #define FD_CHECK_ARG(cond, ...)            \
   do {                                     \
@@ -27,6 +28,7 @@ void fd_set_error(const char* fmt, ...);
       fd_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
       return FD_ERR_LAUNCH;                                                     \
     }                                                                           \
+    fd_count_launch();                                                          \
   } while (0)
 
 static inline int fd_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

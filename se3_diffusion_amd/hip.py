@@ -252,7 +252,7 @@ class FdLib:
                 f"`python -m se3_diffusion_amd.build` (hipcc, gfx950). There is no CPU fallback.")
         self.path = path
         self.cdll = ctypes.CDLL(path)
-        for name, (res, args) in {"fd_last_error": (c_char_p, []), "fd_abi_version": (c_int, []),
+        for name, (res, args) in {"fd_last_error": (c_char_p, []), "fd_abi_version": (c_int, []), "fd_launch_count": (c_long, []),
                                   "fd_backend": (c_char_p, []), "fd_build_flags": (c_char_p, [])}.items():
             fn = getattr(self.cdll, name)
             fn.restype, fn.argtypes = res, args
@@ -390,4 +390,4 @@ def get_lib() -> FdLib:
 
 
 def exported_symbols():
-    return sorted(list(_SIGS) + ["fd_last_error", "fd_abi_version", "fd_backend", "fd_build_flags"])
+    return sorted(list(_SIGS) + ["fd_last_error", "fd_abi_version", "fd_backend", "fd_build_flags", "fd_launch_count"])

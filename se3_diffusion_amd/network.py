@@ -327,7 +327,7 @@ def ipa_fwd(P, pre, s, z, quat, trans, mask, B, N, cache=None, zb=None, out_view
     flash = (opts.flash_ipa and B * ((N + 15) // 16) >= opts.flash_ipa_min_tiles and N <= 1024
              and (lib().is_device or opts.flash_ipa_min_tiles <= 0))
     # a long lone backbone (inference): too few query tiles for the kernel above, but enough keys to split them over 4 blocks
-    split = 4 if (opts.flash_ipa and not flash and not train and opts.flash_ipa_split_min_n <= N <= 1024
+    split = int(opts.flash_ipa_splits) if (opts.flash_ipa and not flash and not train and opts.flash_ipa_split_min_n <= N <= 1024
                   and (lib().is_device or opts.flash_ipa_split_min_n <= 16)) else 1      # (<= 16: the interpreter tests)
     flash = flash or split > 1
     # which backward will run is decided HERE, with the forward's options and tile count, and recorded for ipa_bwd: the saved

@@ -71,6 +71,7 @@ class Options:
     flash_ipa_split_min_n: int = 384  # FD_IPA_FLASH_SPLIT_MIN_N: inference below flash_ipa_min_tiles -- from this N up the KEYS of a query tile are
                                       # split over 4 blocks + a merge launch (fd_ipa_flash_fwd_split: 86 against 112 us at N=512 B=1; 55
                                       # against 49 at N=256, 42 against 39 at N=128: the launch sequence stays there)
+    flash_ipa_splits: int = 4         # FD_IPA_FLASH_SPLITS: ... key splits of that form
     flash_ipa_hpb: int = 0            # FD_IPA_FLASH_HPB: heads per block of that kernel (0 = by size, 8 / 4 / 2)
     proj_merge: bool = True           # FD_PROJ_MERGE: IPA's four projections of s as one GEMM over back-to-back weights
     # -- node level
@@ -112,7 +113,7 @@ class Options:
             flash_ipa=_flag("FD_IPA_FLASH", True), flash_ipa_min_tiles=_int("FD_IPA_FLASH_MIN_TILES", 80),
             flash_ipa_bwd_min_tiles=_int("FD_IPA_FLASH_BWD_MIN_TILES", 128),
             flash_ipa_split_min_n=_int("FD_IPA_FLASH_SPLIT_MIN_N", 384),
-            flash_ipa_hpb=_int("FD_IPA_FLASH_HPB", 0), flash_ipa_bwd=_flag("FD_IPA_FLASH_BWD", True), flash_ipa_keys=_flag("FD_IPA_FLASH_KEYS", True), flash_ipa_keys_max_n=_int("FD_IPA_FLASH_KEYS_MAX_N", 224),
+            flash_ipa_hpb=_int("FD_IPA_FLASH_HPB", 0), flash_ipa_splits=_int("FD_IPA_FLASH_SPLITS", 4), flash_ipa_bwd=_flag("FD_IPA_FLASH_BWD", True), flash_ipa_keys=_flag("FD_IPA_FLASH_KEYS", True), flash_ipa_keys_max_n=_int("FD_IPA_FLASH_KEYS_MAX_N", 224),
             proj_merge=_flag("FD_PROJ_MERGE", True),
             fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),
             grouped_node_dw=_flag("FD_NODE_DW", True), defer_node_dw=_flag("FD_DEFER_NODE_DW", True), node_dw_blocks=_int("FD_NODE_DW_BLOCKS", 0),

@@ -155,8 +155,12 @@ def sample(model, diffuser, feats, num_t=500, min_t=0.01, noise_scale=0.1, self_
                            all_t=torch.tensor(np.ascontiguousarray(steps), dtype=torch.float32).to(dev),
                            z_all=torch.zeros((NOISE_STEPS,) + tuple(z_both.shape), dtype=torch.float64, device=dev))
             graph = torch.cuda.CUDAGraph()
+            n_launch = lib.cdll.fd_launch_count()
             with torch.cuda.graph(graph):
                 cap_out = step_body()          # (static buffers: every replay rewrites them)
+            if stats is not None:
+                # kernels of this library in ONE captured diffusion step (network forward + reverse step + fd_sample_advance)
+                stats["kernels_per_step"] = int(lib.cdll.fd_launch_count() - n_launch)
             for k, v in saved.items():
                 st[k].copy_(v)
             # (capture records the launches without running them: the counter is still 0 = the index of the first step)
