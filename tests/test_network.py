@@ -118,7 +118,11 @@ def quat_align(a, b):
 # trunk.0.weight at N=512, where the oracle itself is 5.5e-4 from the reference): TOL_GRAD = 2e-3 is 1.7 - 4 x those, per-family
 # bounds below are tighter where the code achieves more.  TOL_GRAD_L2: relative L2 error of a tensor (worst measured 5.1e-4).
 TOL_OUT, TOL_ROT, TOL_GRAD, ABS_GRAD, TOL_GRAD_L2 = 2e-4, 8e-4, 2e-3, 2e-5, 2e-3
-TOL_GRAD_FAMILY = {"bb_update": 2e-4, "torsion_pred": 1.2e-3}
+# per parameter family: <= 3 x the worst value any GPU case achieves (profiles/r05_parity_errors.md, re-taken in round 6:
+# profiles/r06_parity_errors.md); edge_transition / node_transition / seq_tfmr (1.0e-3 .. 1.3e-3 measured, at N = 512 and at the
+# B = 30 step: sums over up to 30 x 128^2 pair rows in fp32 on both sides) keep TOL_GRAD
+TOL_GRAD_FAMILY = {"bb_update": 2e-5, "torsion_pred": 2e-4, "embed.edge": 6e-4, "embed.node": 5e-4, "ipa.head_weights": 8e-4,
+                   "ipa.pair_proj": 8e-4, "ipa.proj": 6e-4, "ipa_ln": 6e-4, "post_tfmr": 5e-4, "skip_embed": 7e-4}
 
 
 def run_case(dev, B, N, blocks, seed, n_pad=0, n_fixed=0, check_grad=True, tol_out=TOL_OUT, tol_grad=TOL_GRAD, rot_floor=1e-12,
