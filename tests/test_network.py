@@ -118,11 +118,13 @@ def quat_align(a, b):
 # trunk.0.weight at N=512, where the oracle itself is 5.5e-4 from the reference): TOL_GRAD = 2e-3 is 1.7 - 4 x those, per-family
 # bounds below are tighter where the code achieves more.  TOL_GRAD_L2: relative L2 error of a tensor (worst measured 5.1e-4).
 TOL_OUT, TOL_ROT, TOL_GRAD, ABS_GRAD, TOL_GRAD_L2 = 2e-4, 8e-4, 2e-3, 2e-5, 2e-3
-# per parameter family: <= 3 x the worst value any GPU case achieves (profiles/r05_parity_errors.md, re-taken in round 6:
-# profiles/r06_parity_errors.md); edge_transition / node_transition / seq_tfmr (1.0e-3 .. 1.3e-3 measured, at N = 512 and at the
-# B = 30 step: sums over up to 30 x 128^2 pair rows in fp32 on both sides) keep TOL_GRAD
-TOL_GRAD_FAMILY = {"bb_update": 2e-5, "torsion_pred": 2e-4, "embed.edge": 6e-4, "embed.node": 5e-4, "ipa.head_weights": 8e-4,
-                   "ipa.pair_proj": 8e-4, "ipa.proj": 6e-4, "ipa_ln": 6e-4, "post_tfmr": 5e-4, "skip_embed": 7e-4}
+# per parameter family: <= 3 x the worst value any GPU case achieves (profiles/r06_parity_errors.md: 9.1e-6 bb_update, 5.4e-5
+# torsion_pred, 2.3e-4 .. 3.9e-4 the embedders / IPA / ipa_ln / post_tfmr / skip_embed -- all at the B = 30 benchmarked step, sums
+# over 30 x 128 residue rows or 30 x 128^2 pair rows in fp32 on both sides, whose value moves with the tile shapes of the node-level
+# GEMMs: 1.4e-4 .. 2.6e-4 with the round-5 tiles); edge_transition / node_transition / seq_tfmr (1.0e-3 .. 1.3e-3 measured, at
+# N = 512 and at the B = 30 step) keep TOL_GRAD
+TOL_GRAD_FAMILY = {"bb_update": 3e-5, "torsion_pred": 2e-4, "embed.edge": 7e-4, "embed.node": 8e-4, "ipa.head_weights": 8e-4,
+                   "ipa.pair_proj": 1.2e-3, "ipa.proj": 1e-3, "ipa_ln": 1e-3, "post_tfmr": 8e-4, "skip_embed": 8e-4}
 
 
 def run_case(dev, B, N, blocks, seed, n_pad=0, n_fixed=0, check_grad=True, tol_out=TOL_OUT, tol_grad=TOL_GRAD, rot_floor=1e-12,
