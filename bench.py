@@ -730,6 +730,7 @@ def main():
                    "batches": "one pre-generated batch per step of the schedule" if a.mixed_n else
                               "one HBM-resident synthetic batch per rank, reused by every step (priming, warm-up and timed)", "parallelism": f"dp{world}", "global_batch": world * B, "n_res": N,
                    "ranks": world, "collective_backend": (torch.distributed.get_backend() if world > 1 else None),
+                   "dp_overlap": overlap is not None,
                    "rccl_ranks": world if (world > 1 and torch.distributed.get_backend() == "nccl") else 0,
                    "ms_per_step_by_rank": per_rank_ms,
                    "step_ms_spread": {"min": round(per_step[0], 3), "median": round(per_step[len(per_step) // 2], 3),

@@ -71,15 +71,18 @@ def test_bench_under_torchrun(hip_lib):
     _check(_line(r.stdout), 2)
 
 
-def test_bench_two_ranks_over_rccl(hip_lib):
-    """`python bench.py --gpus 2` over nccl (= RCCL over xGMI) on a box that HAS two GPUs: the first multi-rank RCCL init, the
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_bench_two_ranks_over_rccl(hip_lib, overlap):
+    """(overlap = "1": FD_DP_OVERLAP=1 -- the slice all-reduces of dist.OverlapAllReduce issued from the gradient side stream while
+    the backward is still enqueueing -- so that the first time that path meets RCCL is not in front of the driver.)
+    `python bench.py --gpus 2` over nccl (= RCCL over xGMI) on a box that HAS two GPUs: the first multi-rank RCCL init, the
     parameter broadcast, the flat-gradient all-reduce and the barrier-bracketed timing with one rank per device -- the path
     the driver's SCALE run takes (reference DDP launch: experiments/train_se3_diffusion.py:83-91,273-277).  Skipped on the
     one-GPU boxes this repository is developed on (RCCL has so far only run with ONE rank: tests/test_dist.py)."""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (the gpurun boxes have one)")
-    env = dict(os.environ, FD_BENCH_PRIME="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, FD_BENCH_PRIME="1", HSA_ENABLE_IPC_MODE_LEGACY="0", FD_DP_OVERLAP=overlap)
     for k in ("WORLD_SIZE", "FD_DIST_BACKEND", "FD_FORCE_DEVICE"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL],
@@ -89,6 +92,7 @@ def test_bench_two_ranks_over_rccl(hip_lib):
     _check(d, 2)
     c = d["config"]
     assert c["ranks"] == 2 and c["collective_backend"] == "nccl" and c["rccl_ranks"] == 2 and len(c["ms_per_step_by_rank"]) == 2
+    assert bool(c.get("dp_overlap", False)) == (overlap == "1")
 
 
 def test_bench_takes_world_size_from_the_launcher(hip_lib):
