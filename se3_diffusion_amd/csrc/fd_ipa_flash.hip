@@ -1023,6 +1023,130 @@ __global__ __launch_bounds__(HPB * 64, 2) void ipa_flash_bwd_keys_kernel(FlashKe
   }
 }
 
+
+// The same key-side backward with the query operands SHARED: a block owns FOUR consecutive key tiles of one head (one wave each), so
+// the 16 dO rows and 16 Q rows of a query tile -- 32 KB that every key tile of the head multiplies -- are fetched from L2 once per
+// block (global -> registers -> LDS, two stages) and read by all four waves as MFMA operands (ds_read_b128 of a row-major [16][256]
+// image: lanes 0..15 of a lane group cover 256 contiguous bytes, the four row groups of an instruction fall into disjoint bank
+// windows).  The per-key-tile kernel above moved 503 MB through the CUs per launch at B=30 x N=128 for 63 MB of operands.
+__global__ __launch_bounds__(256, 2) void ipa_flash_bwd_keys4_kernel(FlashKeysArgs a) {
+  constexpr int KT = 4;                                        // key tiles (= waves) of a block
+  __shared__ __attribute__((aligned(16))) float stage[2][2][TI][C];      // [buffer][dO | Q][query row][channel]
+  const int N = a.N;
+  const int nti = (N + TI - 1) / TI;
+  const int njg = (nti + KT - 1) / KT;
+  const int lid = fd_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+  const int jg = lid % njg, h = (lid / njg) % H, b = lid / (njg * H);
+  const int lane = fd::lane_id();
+  const int wave = fd::uniform(fd::wave_id());
+  const int n = lane & 15, kk = lane >> 4;
+  const int jt = jg * KT + wave;                               // (a wave past the last key tile computes on clamped rows, stores nothing)
+  const int j0 = jt * TI;
+  const long rb = (long)b * N;
+  const int jn = imin(j0 + n, N - 1);
+  const bool key_ok = j0 + n < N;
+  const float sc = sqrtf(1.0f / (3.0f * (float)C));
+  const float gamma = softplus_f(a.head_w[h]) * sqrtf(1.0f / (3.0f * ((float)PQ * 9.0f / 2.0f)));
+
+  f32x4 dV[C / 16], dK[C / 16], dP[4], dX[4];
+#pragma unroll
+  for (int c = 0; c < C / 16; ++c) { dV[c] = zero4(); dK[c] = zero4(); }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { dP[c] = zero4(); dX[c] = zero4(); }
+
+  const float* __restrict__ Ab = a.A + ((long)b * H + h) * N * N + jn;
+  const float* __restrict__ Lb = a.dL + ((long)b * H + h) * N * N + jn;
+  const float* __restrict__ dGb = a.doptg + (rb * H + h) * (PV * 3) + 4 * n;
+  const float* __restrict__ qpb = a.qp + (rb * H + h) * (PQ * 3) + 4 * n;
+  // staging: wave w copies rows 4 w .. 4 w + 3 of the tile's dO and Q, lane l the 16 bytes at channel 4 l
+  const float* __restrict__ dOs = a.dfeats + rb * LDF + h * C + 4 * lane;
+  const float* __restrict__ Qs = a.proj + rb * LDP + h * C + 4 * lane;
+  auto ldv = [](const float* p) -> f32x4 { return *reinterpret_cast<const f32x4*>(p); };
+  f32x4 so[4], sq[4];
+  auto fetch = [&](int it) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned ic = (unsigned)imin(TI * it + 4 * wave + r, N - 1);
+      so[r] = ldv(dOs + ic * LDF);
+      sq[r] = ldv(Qs + ic * LDP);
+    }
+  };
+  auto deposit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      *reinterpret_cast<f32x4*>(&stage[buf][0][4 * wave + r][4 * lane]) = so[r];
+      *reinterpret_cast<f32x4*>(&stage[buf][1][4 * wave + r][4 * lane]) = sq[r];
+    }
+  };
+  fetch(0);
+  deposit(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int it = 0; it < nti; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nti) fetch(it + 1);                          // (lands under this tile's 160 MFMAs)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int i = TI * it + 4 * s + kk;                     // this lane group's query row of the k-step
+      const bool ok = i < N;
+      const unsigned ic = (unsigned)imin(i, N - 1);
+      f32x4 z = zero4();
+      const f32x4 gp = n < 9 ? ldv(dGb + ic * (H * PV * 3)) : z;
+      z[0] = n == 6 ? 1.f : 0.f;
+      const f32x4 pp = n < 6 ? ldv(qpb + ic * (H * PQ * 3)) : z;
+      const float va = Ab[(long)ic * N], vl = Lb[(long)ic * N];
+      const float pa = ok ? va : 0.f, pl = ok ? vl : 0.f;
+      const float* orow = &stage[buf][0][4 * s + kk][4 * n];
+      const float* qrow = &stage[buf][1][4 * s + kk][4 * n];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 o = ldv(orow + 64 * c), q = ldv(qrow + 64 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dV[4 * c + e] = fd::mfma_16x16x4(o[e], pa, dV[4 * c + e]);
+          dK[4 * c + e] = fd::mfma_16x16x4(q[e], pl, dK[4 * c + e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dP[e] = fd::mfma_16x16x4(gp[e], pa, dP[e]);
+        dX[e] = fd::mfma_16x16x4(pp[e], pl, dX[e]);
+      }
+    }
+    if (it + 1 < nti) deposit(buf ^ 1);                        // (buffer buf ^ 1 was last read in tile it - 1: a barrier ago)
+    __syncthreads();
+  }
+
+  if (key_ok) {
+    float* __restrict__ dk = a.dproj + (rb + j0 + n) * LDP + KV_OFF + h * 2 * C + 16 * kk;
+    float* __restrict__ dv = dk + C;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        *reinterpret_cast<float4*>(dk + 64 * c + 4 * r) =
+            make_float4(sc * dK[4 * c][r], sc * dK[4 * c + 1][r], sc * dK[4 * c + 2][r], sc * dK[4 * c + 3][r]);
+        *reinterpret_cast<float4*>(dv + 64 * c + 4 * r) = make_float4(dV[4 * c][r], dV[4 * c + 1][r], dV[4 * c + 2][r], dV[4 * c + 3][r]);
+      }
+    float* __restrict__ dvp = a.dvp + ((rb + j0 + n) * H + h) * (PV * 3) + 16 * kk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * kk + 4 * r < PV * 3) *reinterpret_cast<float4*>(dvp + 4 * r) = make_float4(dP[0][r], dP[1][r], dP[2][r], dP[3][r]);
+  }
+  const float csum = __shfl(dX[0][2], n + 16);
+  if (key_ok) {
+    const float* __restrict__ kpr = a.kp + ((rb + j0 + n) * H + h) * (PQ * 3) + 16 * kk;
+    float* __restrict__ dkp = a.dkp + ((rb + j0 + n) * H + h) * (PQ * 3) + 16 * kk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * kk + 4 * r < PQ * 3) {
+        const float4 kv = ld4(kpr + 4 * r);
+        *reinterpret_cast<float4*>(dkp + 4 * r) = make_float4(gamma * (dX[0][r] - kv.x * csum), gamma * (dX[1][r] - kv.y * csum),
+                                                              gamma * (dX[2][r] - kv.z * csum), gamma * (dX[3][r] - kv.w * csum));
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" int fd_ipa_flash_fwd(const float* proj, const float* zb, const float* qp, const float* kp, const float* vp,
@@ -1099,10 +1223,19 @@ extern "C" int fd_ipa_flash_bwd_keys(const float* A, const float* dL, const floa
   FD_CHECK_ARG(fd_aligned16(proj) && fd_aligned16(dfeats) && fd_aligned16(doptg) && fd_aligned16(qp) && fd_aligned16(kp) &&
                    fd_aligned16(dproj) && fd_aligned16(dvp) && fd_aligned16(dkp),
                "fd_ipa_flash_bwd_keys: tensor arguments must be 16-byte aligned");
-  FD_CHECK_ARG(heads_per_block == 0 || heads_per_block == 2 || heads_per_block == 4 || heads_per_block == 8,
-               "fd_ipa_flash_bwd_keys: heads_per_block must be 0 (pick), 2, 4 or 8, got %d", heads_per_block);
+  FD_CHECK_ARG(heads_per_block == 0 || heads_per_block == 1 || heads_per_block == 2 || heads_per_block == 4 || heads_per_block == 8,
+               "fd_ipa_flash_bwd_keys: heads_per_block must be 0 (pick), 1 (four key tiles of one head per block), 2, 4 or 8, got %d",
+               heads_per_block);
   if (B == 0 || N == 0) return FD_OK;
   const long tiles = (long)B * ((N + TI - 1) / TI);
+  if (heads_per_block == 0 || heads_per_block == 1) {
+    // four key tiles of one head per block: the query operands go through LDS once per block
+    FlashKeysArgs a4{A, dL, proj, dfeats, doptg, qp, kp, head_w, dproj, dvp, dkp, B, N};
+    const int njg = ((N + TI - 1) / TI + 3) / 4;
+    hipLaunchKernelGGL(ipa_flash_bwd_keys4_kernel, dim3((unsigned)((long)B * H * njg)), dim3(256), 0, (hipStream_t)stream, a4);
+    FD_CHECK_LAUNCH("fd_ipa_flash_bwd_keys");
+    return FD_OK;
+  }
   int hpb = heads_per_block;
   if (hpb == 0) hpb = N >= 256 ? 4 : 2;      // (measured, tools/bench_ipa_keys.py: B=12 x N=200 113 against 127 us, B=7 x N=256 114 against 132)
   FlashKeysArgs a{A, dL, proj, dfeats, doptg, qp, kp, head_w, dproj, dvp, dkp, B, N};

@@ -63,9 +63,9 @@ class Options:
                                       # in HBM) instead of two batched GEMMs + fd_ipa_attn_bwd's per-row kernel ...
     flash_ipa_keys: bool = True       # FD_IPA_FLASH_KEYS: ... and its key side (dV, dv_pts, dK, dk_pts) in one launch (fd_ipa_flash_bwd_keys: A and dL
                                       # read once) instead of three batched GEMMs + fd_ipa_kpts_bwd, where the query side runs fused ...
-    flash_ipa_keys_max_n: int = 224   # FD_IPA_FLASH_KEYS_MAX_N: ... up to this N (B=30 x N=128: 94-97 against 102 us, B=12 x N=200: 113 against 119;
-                                      # B=7 x N=256: 114 against 110, B=8 x N=512: 328 against 228 -- every key tile re-reads all queries' dO / Q
-                                      # from L2, the batched GEMMs' 64 x 64 tiles with K = N reuse them better on long chains)
+    flash_ipa_keys_max_n: int = 384   # FD_IPA_FLASH_KEYS_MAX_N: ... up to this N (four key tiles of a head per block, the query operands through
+                                      # LDS once per block: B=30 x N=128 78 against 102 us, B=12 x N=200 97 against 119, B=7 x N=256 82 against
+                                      # 109; B=8 x N=512 248 against 225, B=1 x N=512 138 against 102: long chains keep the batched GEMMs)
     flash_ipa_bwd_min_tiles: int = 128  # FD_IPA_FLASH_BWD_MIN_TILES: ... from this many query tiles up (8 heads per block only: 112 tiles
                                       # 195 against 199 us, 95 tiles 224 against 207)
     flash_ipa_split_min_n: int = 384  # FD_IPA_FLASH_SPLIT_MIN_N: inference below flash_ipa_min_tiles -- from this N up the KEYS of a query tile are
@@ -113,7 +113,7 @@ class Options:
             flash_ipa=_flag("FD_IPA_FLASH", True), flash_ipa_min_tiles=_int("FD_IPA_FLASH_MIN_TILES", 80),
             flash_ipa_bwd_min_tiles=_int("FD_IPA_FLASH_BWD_MIN_TILES", 128),
             flash_ipa_split_min_n=_int("FD_IPA_FLASH_SPLIT_MIN_N", 384),
-            flash_ipa_hpb=_int("FD_IPA_FLASH_HPB", 0), flash_ipa_splits=_int("FD_IPA_FLASH_SPLITS", 4), flash_ipa_bwd=_flag("FD_IPA_FLASH_BWD", True), flash_ipa_keys=_flag("FD_IPA_FLASH_KEYS", True), flash_ipa_keys_max_n=_int("FD_IPA_FLASH_KEYS_MAX_N", 224),
+            flash_ipa_hpb=_int("FD_IPA_FLASH_HPB", 0), flash_ipa_splits=_int("FD_IPA_FLASH_SPLITS", 4), flash_ipa_bwd=_flag("FD_IPA_FLASH_BWD", True), flash_ipa_keys=_flag("FD_IPA_FLASH_KEYS", True), flash_ipa_keys_max_n=_int("FD_IPA_FLASH_KEYS_MAX_N", 384),
             proj_merge=_flag("FD_PROJ_MERGE", True),
             fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),
             grouped_node_dw=_flag("FD_NODE_DW", True), defer_node_dw=_flag("FD_DEFER_NODE_DW", True), node_dw_blocks=_int("FD_NODE_DW_BLOCKS", 0),

@@ -279,6 +279,9 @@ def _run_bwd_keys(dev, B, N, seed, hpb=0, tol=5e-6, log=False):
 
 def test_ipa_flash_bwd_keys_emu(use_emu):
     _run_bwd_keys("cpu", 1, 16, 0, hpb=2)
+    _run_bwd_keys("cpu", 1, 16, 3, hpb=1)        # (1: four key tiles of one head per block, operands through LDS)
+    _run_bwd_keys("cpu", 2, 70, 4, hpb=1)        # 5 key tiles: a block with three idle waves, ragged rows
+    _run_bwd_keys("cpu", 1, 37, 5, hpb=0)
     _run_bwd_keys("cpu", 2, 37, 1, hpb=4)        # ragged: rows and keys past N
     _run_bwd_keys("cpu", 1, 18, 2, hpb=8)
 
@@ -286,7 +289,8 @@ def test_ipa_flash_bwd_keys_emu(use_emu):
 @pytest.mark.gpu
 def test_ipa_flash_bwd_keys_gpu(hip_lib):
     with parity_log.case("ipa_flash_bwd_keys"):
-        for (B, N, seed, hpb) in ((2, 128, 0, 0), (30, 128, 1, 0), (3, 100, 2, 2), (1, 257, 3, 4), (2, 400, 4, 8), (1, 512, 5, 0)):
+        for (B, N, seed, hpb) in ((2, 128, 0, 0), (30, 128, 1, 0), (3, 100, 2, 2), (1, 257, 3, 4), (2, 400, 4, 8), (1, 512, 5, 0),
+                                  (12, 200, 6, 1), (3, 101, 7, 1)):
             _run_bwd_keys("cuda", B, N, seed, hpb=hpb, log=True)
 
 

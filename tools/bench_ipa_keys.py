@@ -36,7 +36,7 @@ def main():
             L.call("fd_ipa_kpts_bwd", dL, qp, kp, hw, dkp, B, N)
 
         line = [f"B={B:3d} N={N:4d}: launch sequence {timeit(seq):7.1f} us | one launch"]
-        for hpb in (0, 2, 4, 8):
+        for hpb in (1, 2, 4, 8):
             t = timeit(lambda: L.call("fd_ipa_flash_bwd_keys", A, dL, proj, dfeats, doptg, qp, kp, hw, dproj, dvp, dkp, B, N, hpb))
             line.append(f"hpb {hpb}: {t:7.1f}")
         print(" ".join(line), flush=True)
