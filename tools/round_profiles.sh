@@ -19,12 +19,17 @@ python tools/bench_embed_bwd.py > $O/embed_bwd_microbench.log 2>&1
 python tools/bench_ipa_attn.py 30 128 > $O/ipa_attn_microbench.log 2>&1
 (timeout 200 python tools/bench_ipa_flash.py; timeout 200 python tools/bench_ipa_flash.py --bwd) > $O/ipa_flash_microbench.log 2>&1
 python tools/bench_gemm.py --only kk --iters 50 > $O/gemm_s64_microbench.log 2>&1
+python tools/bench_node_gemm.py 3840 > $O/node_gemm.log 2>&1
+python tools/gemm_shapes.py 30 128 > $O/gemm_shapes.log 2>&1
+python tools/bench_ipa_keys.py > $O/ipa_keys_microbench.log 2>&1
 # per-kernel time of the training step, launches serialised
 FD_BENCH_PROFILE=1 FD_GRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d $O/kt -o p --output-format csv -- python bench.py --steps 5 --warmup 2 --no-sampling --no-cpu-baseline > $O/kt.log 2>&1
 python tools/kernel_stats_md.py $O/kt/p_kernel_stats.csv "training step B=30 x N=128, FD_GRAD_STREAM=0 (serialised): 4 priming + 2 warm-up + 5 timed + 3 profiled steps of bench.py" > $O/train_kernel_stats.md
 # sampling forward kernels
 rocprofv3 --kernel-trace --stats -d $O/ks -o p --output-format csv -- python bench.py --mode sample --n-res 128 --batch 1 --num-t 100 --steps 1 --warmup 0 --no-graph > $O/ks.log 2>&1
 python tools/kernel_stats_md.py $O/ks/p_kernel_stats.csv "sampling N=128 B=1, 100 steps, eager launches" > $O/sample_n128_b1_kernel_stats.md
+rocprofv3 --kernel-trace --stats -d $O/ks2 -o p --output-format csv -- python bench.py --mode sample --n-res 256 --batch 1 --num-t 100 --steps 1 --warmup 0 --no-graph > $O/ks2.log 2>&1
+python tools/kernel_stats_md.py $O/ks2/p_kernel_stats.csv "sampling N=256 B=1, 100 steps, eager launches" > $O/sample_n256_b1_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d $O/ks5 -o p --output-format csv -- python bench.py --mode sample --n-res 512 --batch 8 --num-t 12 --steps 1 --warmup 0 --no-graph > $O/ks5.log 2>&1
 python tools/kernel_stats_md.py $O/ks5/p_kernel_stats.csv "sampling N=512 B=8, 12 steps, eager launches" > $O/sample_n512_b8_kernel_stats.md
 if [ -z "$LITE" ]; then   # (LITE=1: the counter passes are skipped -- kernels unchanged since the last full run)
