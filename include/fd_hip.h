@@ -363,6 +363,12 @@ int fd_group_dw(const FdGroupDwDesc* desc, void* stream);
  * key mask or null; out [B*N, 320]; A_out [B, 4, N, N] optional (the probabilities, for the backward).  N <= 1024. */
 int fd_seq_attn_fwd(const float* qkv, const float* key_add, float* out, float* A_out, float scale, int B, int N,
                     void* stream);
+/* Backward of that attention in ONE launch (autograd of softmax(q k^T / sqrt(d) + mask) v, model/ipa_pytorch.py:584-593, with
+ * respect to q, k, v): dqkv [B*N, 960] = [dQ | dK | dV] from qkv, the saved probabilities A [B,4,N,N], the saved output out [B*N,320]
+ * and its gradient dout; replaces two batched fd_gemm launches, fd_row_softmax_bwd and two more batched fd_gemm launches; dA / dS
+ * never reach HBM.  16-byte aligned tensors. */
+int fd_seq_attn_bwd(const float* qkv, const float* A, const float* dout, const float* out, float* dqkv, float scale, int B, int N,
+                    void* stream);
 
 /* ---- embedder features: score_network.py:14-47,97-148; data/utils.py:570-580 ----
  * tscaled = (t*1e4) as fp32 [B]; tfreq[16], idenom[16], dg_lower[22], dg_upper[22] are the

@@ -211,6 +211,7 @@ _SIGS = {
     "fd_ipa_flash_bwd_keys": "pppppppp" + "ppp" + "iiis",
     "fd_ipa_opt_bwd_dot": "ppppppp" + "ls",
     "fd_seq_attn_fwd": "ppppfiis",
+    "fd_seq_attn_bwd": "pppppfiis",
     "fd_ipa_attn_bwd": "pppppppppppppiis",
     "fd_ipa_softmax_bwd": "ppppppppppiis",
     "fd_ipa_kpts_bwd": "pppppiis",

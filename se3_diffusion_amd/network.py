@@ -600,18 +600,24 @@ def tfmr_layer_bwd(P, G, pre, sv, dy2):
     ops.linear_dx(mv(dt1), mv(P[f"{pre}.self_attn.out_proj.weight"]), mv(do), R, TD, TD)
     qkv, A = sv["qkv"], sv["A"]
     dqkv = empty((R, 3 * TD), dev)
-    dA = empty((B, TH, N, N), dev)
-    # dA = do V^T ; dV = A^T do
-    L.gemm(do, qkv, dA, N, N, THD, (TD, 1), (1, 3 * TD), N, b_off=2 * TD, batch=B * TH, bdiv=TH,
-           a_bs=(N * TD, THD), b_bs=(N * 3 * TD, THD), c_bs=(TH * N * N, N * N))
-    L.gemm(A, do, dqkv, N, THD, N, (1, N), (TD, 1), 3 * TD, c_off=2 * TD, batch=B * TH, bdiv=TH,
-           a_bs=(TH * N * N, N * N), b_bs=(N * TD, THD), c_bs=(N * 3 * TD, THD))
-    L.call("fd_row_softmax_bwd", A, dA, B * TH * N, N)
     sc = 1.0 / math.sqrt(THD)
-    L.gemm(dA, qkv, dqkv, N, THD, N, (N, 1), (3 * TD, 1), 3 * TD, b_off=TD, batch=B * TH, bdiv=TH,
-           a_bs=(TH * N * N, N * N), b_bs=(N * 3 * TD, THD), c_bs=(N * 3 * TD, THD), alpha=sc)
-    L.gemm(dA, qkv, dqkv, N, THD, N, (1, N), (3 * TD, 1), 3 * TD, c_off=TD, batch=B * TH, bdiv=TH,
-           a_bs=(TH * N * N, N * N), b_bs=(N * 3 * TD, THD), c_bs=(N * 3 * TD, THD), alpha=sc)
+    if opts.fused_seq_attn_bwd and not L.exact_f32 and (N <= 256 or (B * N >= 4096 and N <= 1024)):
+        # (a long lone backbone -- 64 blocks walking 32 tiles each -- keeps the batched GEMMs: 62 against 33 us at B=1 x N=512)
+        # dQ, dK, dV of every (batch, head) in ONE launch from the saved probabilities and the saved output (fd_seq_attn_bwd):
+        # dA / dS never reach HBM (five launches before: two batched GEMMs, the row-softmax backward, two batched GEMMs)
+        L.call("fd_seq_attn_bwd", qkv, A, do, sv["o"], dqkv, sc, B, N)
+    else:
+        dA = empty((B, TH, N, N), dev)
+        # dA = do V^T ; dV = A^T do
+        L.gemm(do, qkv, dA, N, N, THD, (TD, 1), (1, 3 * TD), N, b_off=2 * TD, batch=B * TH, bdiv=TH,
+               a_bs=(N * TD, THD), b_bs=(N * 3 * TD, THD), c_bs=(TH * N * N, N * N))
+        L.gemm(A, do, dqkv, N, THD, N, (1, N), (TD, 1), 3 * TD, c_off=2 * TD, batch=B * TH, bdiv=TH,
+               a_bs=(TH * N * N, N * N), b_bs=(N * TD, THD), c_bs=(N * 3 * TD, THD))
+        L.call("fd_row_softmax_bwd", A, dA, B * TH * N, N)
+        L.gemm(dA, qkv, dqkv, N, THD, N, (N, 1), (3 * TD, 1), 3 * TD, b_off=TD, batch=B * TH, bdiv=TH,
+               a_bs=(TH * N * N, N * N), b_bs=(N * 3 * TD, THD), c_bs=(N * 3 * TD, THD), alpha=sc)
+        L.gemm(dA, qkv, dqkv, N, THD, N, (1, N), (3 * TD, 1), 3 * TD, c_off=TD, batch=B * TH, bdiv=TH,
+               a_bs=(TH * N * N, N * N), b_bs=(N * 3 * TD, THD), c_bs=(N * 3 * TD, THD), alpha=sc)
     _lin_grads(G, f"{pre}.self_attn.in_proj_weight", f"{pre}.self_attn.in_proj_bias", mv(dqkv), mv(sv["x"]), R, 3 * TD, TD)
     dx = empty((R, TD), dev)  # dx = dt1 (residual) + dqkv W_in
     ops.linear_dx(mv(dqkv), mv(P[f"{pre}.self_attn.in_proj_weight"]), mv(dx), R, 3 * TD, TD, resid=mv(dt1))

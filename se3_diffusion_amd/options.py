@@ -77,6 +77,8 @@ class Options:
     # -- node level
     fused_seq_attn: bool = True       # FD_SEQ_ATTN_FUSED: sequence-transformer attention in one launch ...
     seq_attn_min_rows: int = 1024     # FD_SEQ_ATTN_MIN_ROWS: ... from this many residue rows up
+    fused_seq_attn_bwd: bool = True   # FD_SEQ_ATTN_BWD_FUSED: its backward (dQ, dK, dV from the saved probabilities and output) in one launch
+                                      # (fd_seq_attn_bwd) instead of four batched GEMMs + the row-softmax backward
     grouped_node_dw: bool = True      # FD_NODE_DW: the node-level weight gradients of a trunk block in one grouped launch
     defer_node_dw: bool = True        # FD_DEFER_NODE_DW: ... launched behind the NEXT edge transition's fused backward (beside that block's
                                       # node-level phase) instead of at the end of its own block (in front of that full-chip kernel)
@@ -115,7 +117,7 @@ class Options:
             flash_ipa_split_min_n=_int("FD_IPA_FLASH_SPLIT_MIN_N", 384),
             flash_ipa_hpb=_int("FD_IPA_FLASH_HPB", 0), flash_ipa_splits=_int("FD_IPA_FLASH_SPLITS", 4), flash_ipa_bwd=_flag("FD_IPA_FLASH_BWD", True), flash_ipa_keys=_flag("FD_IPA_FLASH_KEYS", True), flash_ipa_keys_max_n=_int("FD_IPA_FLASH_KEYS_MAX_N", 384),
             proj_merge=_flag("FD_PROJ_MERGE", True),
-            fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024),
+            fused_seq_attn=_flag("FD_SEQ_ATTN_FUSED", True), seq_attn_min_rows=_int("FD_SEQ_ATTN_MIN_ROWS", 1024), fused_seq_attn_bwd=_flag("FD_SEQ_ATTN_BWD_FUSED", True),
             grouped_node_dw=_flag("FD_NODE_DW", True), defer_node_dw=_flag("FD_DEFER_NODE_DW", True), node_dw_blocks=_int("FD_NODE_DW_BLOCKS", 0),
             ln_fold=_flag("FD_LN_FOLD", True), weight_planes=_flag("FD_WEIGHT_PLANES", True),
             sampler_device_steps=_flag("FD_SAMPLER_DEVICE_STEPS", True), merge_skip_embed=_flag("FD_MERGE_SKIP", True), graph_fork=_flag("FD_GRAPH_FORK", False),

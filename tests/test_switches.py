@@ -56,6 +56,7 @@ def _step(dev, B, N, blocks, **kw):
 # (fp32-accurate) against fp32 fmaf chains in the unfused sequence: ReLU-kink entries aside, 2e-4.
 GROUPS = [
     (dict(proj_merge=False, fused_seq_attn=False), 1e-4),
+    (dict(fused_seq_attn_bwd=False), 1e-4),   # fd_seq_attn_bwd vs four batched GEMMs + fd_row_softmax_bwd
     (dict(fused_ipa_attn=False), 1e-4),
     (dict(flash_ipa=False), 1e-4),            # fd_ipa_flash_fwd (probabilities written for the backward) vs the launch sequence
     (dict(flash_ipa_hpb=2), 1e-4),            # (its 2-heads-per-block shape against the default pick)
