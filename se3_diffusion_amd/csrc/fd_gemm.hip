@@ -626,7 +626,8 @@ int plan_tile(const FdGemmDesc& d, bool fast) {
     // gradients (both operands row-contiguous, split-K) and the batched attention products are not faster on it)
     if (cfg == 2 && fast && d.a_cs == 1 && d.batch <= 1 && d.K >= 256 && split_enabled() && s64_enabled()) cfg = 10;
   }
-  if (d.tile == 0 && w_ok(d) && fast && split_enabled() && w_enabled() && (cfg == 10 || cfg == 4 || cfg == 2) && d.K >= 128) {
+  if (d.tile == 0 && w_ok(d) && fast && split_enabled() && w_enabled() && (cfg == 10 || cfg == 4 || cfg == 2) && d.K >= 128 &&
+      d.M <= 65536) {      // (residue rows: the pair-level GEMMs of the unfused paths keep the persistent 256 x 128 kernel)
     // activations x PRE-SPLIT weights (FdGemmDesc.b_planes: the host split the flat parameter buffer once per step).  Which tile,
     // measured at M = 3,840 rows (profiles/r06_node_gemm.log): many output tiles and a short reduction (IPA's projections,
     // N = 6816, K = 256) stay on tile 4, whose 256-row tile moves half the weight bytes per output; k-contiguous weights from
