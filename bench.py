@@ -630,6 +630,7 @@ def main():
     gc.collect()
     gc.disable()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    dev_allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)     # hipMalloc calls of the caching allocator so far
     marks[0].record()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -638,7 +639,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    dev_allocs = torch.cuda.memory_stats().get("num_device_alloc", 0) - dev_allocs0
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    slowest_step = max(range(a.steps), key=lambda i: per_step[i])
     if os.environ.get("FD_BENCH_STEP_TRACE"):
         sys.stderr.write("per-step ms (HIP events, in order): " + " ".join(f"{x:.2f}" for x in per_step) + "\n")
     per_step = sorted(per_step)
@@ -734,8 +737,12 @@ def main():
                    "rccl_ranks": world if (world > 1 and torch.distributed.get_backend() == "nccl") else 0,
                    "ms_per_step_by_rank": per_rank_ms,
                    "step_ms_spread": {"min": round(per_step[0], 3), "median": round(per_step[len(per_step) // 2], 3),
-                                      "max": round(per_step[-1], 3),
-                                      "note": "HIP events between consecutive optimiser launches of the timed steps (rank 0)"},
+                                      "max": round(per_step[-1], 3), "slowest_step": slowest_step,
+                                      "device_allocations_in_timed_region": int(dev_allocs),
+                                      "note": "HIP events between consecutive optimiser launches of the timed steps (rank 0); step 0 "
+                                              "starts on an empty queue behind the barrier (the host enqueues ~8 ms per step), so it is "
+                                              "the slow one of every run (~ +2.5 ms); device_allocations = hipMalloc calls of torch's "
+                                              "caching allocator inside the timed region (0 = every buffer came out of the cache)"},
                    "scaling_curve": "not measured by this line (one N per invocation; the driver composes 1/2/4/8)",
                    "ms_per_step_exact_f32_gemms": None if exact_ms is None else round(exact_ms, 3),
                    "self_conditioning_50pct": None if sc_ms is None else {
