@@ -30,6 +30,8 @@ def _check(d, n):
     r = d["roofline"]
     assert r["bound"] in ("mfma", "hbm") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert "workload" in d["config"] and "model" not in d["config"]
+    sp = d["config"]["step_ms_spread"]
+    assert sp["min"] <= sp["median"] <= sp["max"] and 0 <= sp["slowest_step"] < d["steps"] and sp["device_allocations_in_timed_region"] >= 0
 
 
 def test_bench_line_single(hip_lib):

@@ -161,3 +161,18 @@ def test_device_steps_match_host_steps_gpu(hip_lib):
         feats = sampler.init_feats(diff, B, N, dev, generator=gen)
         res.append(sampler.sample(m, diff, feats, num_t=60, generator=gen, use_graph=True)["rigids"].clone())
     assert torch.equal(res[0], res[1]) and torch.isfinite(res[0]).all()
+
+
+@pytest.mark.gpu
+def test_kernels_per_captured_step_gpu(hip_lib):
+    """the library's launches inside ONE captured diffusion step of a lone backbone on the full-depth model (fd_launch_count across the
+    capture; bench.py reports it as config.sampling.*.kernels_per_step): 130 at the end of round 6 -- a launch added to the sampling
+    forward shows up here, not as a slower benchmark"""
+    dev = "cuda"
+    diff = se3_diffuser.SE3Diffuser(dconf())
+    m = ScoreNetwork(ts.base_model_conf(4), diff).to(dev).eval()
+    st = {}
+    feats = sampler.init_feats(diff, 1, 128, dev, generator=torch.Generator(device=dev).manual_seed(1))
+    sampler.sample(m, diff, feats, num_t=8, min_t=0.01, noise_scale=0.1, generator=torch.Generator(device=dev).manual_seed(2), use_graph=True,
+                   stats=st)
+    assert 100 <= st["kernels_per_step"] <= 132, st
